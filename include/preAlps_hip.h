@@ -1,0 +1,97 @@
+/*
+ * preAlps_hip.h -- entry points of libprealps_hip.so that have no counterpart
+ * in the reference: device/context management, the process-group hooks, the
+ * in-memory operator builder and host<->HBM panel transfers.  Everything a
+ * reference driver needs is in preAlps_abi.h; this header is what a new
+ * binding (ctypes, cgo, JNI, Fortran ISO_C) adds on top.  Plain C ABI: only
+ * pointers, ints, doubles.
+ */
+#ifndef PREALPS_HIP_H
+#define PREALPS_HIP_H
+
+#include "preAlps_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- context ----------------------------------------------------------- */
+/* Select the HIP device of this process and create the library's stream.
+ * Fails (non-zero) when no gfx950 device is usable: there is no CPU fallback. */
+int preAlps_hip_init(int device);
+void preAlps_hip_shutdown(void);
+/* Run every kernel on the caller's stream (a hipStream_t), e.g. the stream a
+ * host framework issues its collectives on.  NULL restores the own stream. */
+int preAlps_hip_set_stream(void* hip_stream);
+void* preAlps_hip_get_stream(void);
+int preAlps_hip_sync(void);
+/* 1 (default): errors print "ABORTING from <fn> : [Proc: r] ..." and abort(),
+ * like CPLM_Abort (utils/cplm_core/cplm_utils.c:17-58).  0: entry points
+ * return non-zero and preAlps_hip_last_error() holds the message. */
+void preAlps_hip_set_abort_mode(int abort_on_error);
+const char* preAlps_hip_last_error(void);
+/* Row stride (in doubles) of a device panel for a given enlarging factor. */
+int preAlps_hip_panel_stride(int enlFac);
+
+/* ---- process group ----------------------------------------------------- */
+/* One process per GPU.  rank/size describe the processes that share one
+ * operator; the library itself never opens a socket: sums and halo rows go
+ * through the two hooks, which the host binds to RCCL (torch.distributed
+ * backend "nccl", MPI, ...).  Buffers handed to the hooks are device memory
+ * and all work queued on preAlps_hip_get_stream() must be ordered before the
+ * hook's own communication (the hook is responsible for that ordering). */
+typedef int (*preAlps_allreduce_fn)(void* ctx, double* dev_buf, int count);
+/* peers[i] sends recv_counts[i] doubles to us and gets send_counts[i] doubles
+ * from us; both buffers are packed peer after peer in the order of `peers`. */
+typedef int (*preAlps_exchange_fn)(void* ctx, const double* dev_send,
+                                   const int* send_counts, double* dev_recv,
+                                   const int* recv_counts, const int* peers,
+                                   int npeers);
+int preAlps_hip_set_world(int rank, int size);
+int preAlps_hip_set_comm(preAlps_allreduce_fn allreduce,
+                         preAlps_exchange_fn exchange, void* ctx);
+
+/* ---- operator from memory ---------------------------------------------- */
+/* Same pipeline as preAlps_OperatorBuild (utils/operator.c:38-134) with the
+ * matrix taken from memory instead of a MatrixMarket file and an explicit
+ * partition vector instead of METIS:  [scale: A <- D A D]  ->  rows grouped
+ * part by part (original order inside a part)  ->  symmetric permutation  ->
+ * row panel of this process (parts [rank*nparts/size, (rank+1)*nparts/size)).
+ * part == NULL selects part[r] = floor(r*nparts/N).  Every process passes the
+ * whole matrix (global CSR, 0-based, full symmetric pattern). */
+int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd,
+                                 const double* val, int nparts, const int* part,
+                                 int scale);
+/* perm[new] = old, of the whole problem (library-owned, N ints). */
+int preAlps_OperatorGetPermPtr(int** perm, int* n);
+int preAlps_hip_nparts(void);
+
+/* ---- helpers for drivers and tests ------------------------------------- */
+/* The rhs of examples/test_ecg_prealps_op.c:172-184 for the local rows, as a
+ * run of the reference with np = nparts ranks would build it. */
+int preAlps_hip_reference_rhs(double* rhs_local);
+/* The driver loop of examples/test_ecg_prealps_op.c:203-223 (fused variant:
+ * examples/test_ecg_bench_fused.c:243-259). res_hist may be NULL. */
+int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol,
+                     double* res_hist, int* bs_hist, int max_hist, int* n_hist);
+/* Device panel <-> host column-major array (ld >= m). */
+int preAlps_hip_panel_alloc(CPLM_Mat_Dense_t* A, int M, int N, int m, int n, int enlFac);
+void preAlps_hip_panel_free(CPLM_Mat_Dense_t* A);
+int preAlps_hip_panel_to_host(const CPLM_Mat_Dense_t* A, int enlFac, double* host, int ld);
+int preAlps_hip_panel_from_host(CPLM_Mat_Dense_t* A, int enlFac, const double* host, int ld);
+/* Numeric facts about the built operator / preconditioner, by name:
+ * "nnz_local", "rows_local", "halo_rows", "spmm_blocks", "bj_factor_bytes",
+ * "bj_max_bandwidth", "bj_parts_local".  Returns non-zero for unknown keys. */
+int preAlps_hip_get_stat(const char* key, double* value);
+/* Per-phase device time in seconds accumulated since the last reset, from
+ * hipEvents on the library stream when timing is enabled (it adds a stream
+ * sync per call, so it is off by default).  Keys: "operator", "precond",
+ * "gram", "trsm", "update", "small", "comm". */
+void preAlps_hip_timing(int enable);
+void preAlps_hip_timing_reset(void);
+int preAlps_hip_get_time(const char* key, double* seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

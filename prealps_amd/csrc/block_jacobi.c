@@ -1,0 +1,317 @@
+/*
+ * block_jacobi.c -- block-Jacobi preconditioner Z = blockdiag(A)^-1 X with one
+ * exact SPD solve per subdomain, factors resident in HBM.
+ *
+ * Reference behaviour kept (under /root/reference):
+ *   preAlps_BlockJacobiCreate  src/preconditioners/block_jacobi.c:26-63
+ *       diagonal block of the local row panel = entries whose column lies in
+ *       the part's own row range (utils/cplm_v0/cplm_v0_matcsr.c:287-463),
+ *       Cholesky factorisation (PARDISO phase 12, cplm_kernels.c:741-784)
+ *   preAlps_BlockJacobiApply   block_jacobi.c:93-109 -> PARDISO phase 33 with
+ *       nrhs = A_in->info.n (cplm_kernels.c:790-853)
+ *   preAlps_BlockJacobiFree    block_jacobi.c:111-118
+ *
+ * MI355X design: a sparse direct solver with supernodes and pivoting queues
+ * does not map onto 64-wide wavefronts; instead every block is reordered by
+ * reverse Cuthill-McKee, factored once as a dense-band Cholesky L L^T (exact:
+ * no fill leaves the band) and stored twice, column-wise for the forward sweep
+ * and row-wise (reversed) for the backward sweep, so both sweeps stream their
+ * band with coalesced loads (kernels.hip: k_bj_apply).  One process owns
+ * nparts/size blocks; one wavefront solves one block.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pa_host.h"
+
+typedef struct {
+  int created;
+  int np;                 /* local blocks */
+  int m;
+  /* device */
+  int* d_row0; int* d_nrows; int* d_bw; long long* d_off;
+  int* d_map_f; int* d_map_b;
+  double* d_Lf; double* d_Lb; double* d_invd_f; double* d_invd_b;
+  /* classes by register sets */
+  int nclass; int class_R[16]; int class_count[16]; int* class_list[16];
+  const int* class_list_c[16];
+  pa_bj_plan_t plan;
+  double factor_bytes; int max_bw;
+} pa_bj_t;
+
+static pa_bj_t g_bj;
+
+double pa_bj_factor_bytes(void) { return g_bj.created ? g_bj.factor_bytes : 0.0; }
+int pa_bj_max_bandwidth(void) { return g_bj.created ? g_bj.max_bw : 0; }
+int pa_bj_nparts(void) { return g_bj.created ? g_bj.np : 0; }
+
+void preAlps_BlockJacobiFree(void) {
+  pa_bj_t* s = &g_bj;
+  pa_rt_free(s->d_row0); pa_rt_free(s->d_nrows); pa_rt_free(s->d_bw); pa_rt_free(s->d_off);
+  pa_rt_free(s->d_map_f); pa_rt_free(s->d_map_b);
+  pa_rt_free(s->d_Lf); pa_rt_free(s->d_Lb); pa_rt_free(s->d_invd_f); pa_rt_free(s->d_invd_b);
+  for (int c = 0; c < 16; ++c) pa_rt_free(s->class_list[c]);
+  memset(s, 0, sizeof(*s));
+}
+
+/* ---- reverse Cuthill-McKee of one block ---------------------------------- */
+typedef struct { int* xadj; int* adj; int* deg; int* order; int* pos; int* queue; int* level; } rcm_ws_t;
+
+static int bfs_levels(int b, const int* xadj, const int* adj, int root, int* level, int* queue,
+                      int stamp_unvisited, int* last_out) {
+  /* level[] must hold stamp_unvisited for nodes of this component not yet seen */
+  int head = 0, tail = 0, maxl = 0;
+  (void)b;
+  queue[tail++] = root; level[root] = 0;
+  while (head < tail) {
+    int u = queue[head++];
+    for (int k = xadj[u]; k < xadj[u + 1]; ++k) {
+      int v = adj[k];
+      if (level[v] == stamp_unvisited) { level[v] = level[u] + 1; if (level[v] > maxl) maxl = level[v]; queue[tail++] = v; }
+    }
+  }
+  *last_out = tail; /* nodes reached */
+  return maxl;
+}
+
+static void rcm_order(int b, const int* xadj, const int* adj, const int* deg, int* order, int* pos,
+                      int* queue, int* level) {
+  const int UNSEEN = -1, DONE = -2;
+  int placed = 0;
+  for (int i = 0; i < b; ++i) pos[i] = UNSEEN; /* pos doubles as "placed" marker */
+  while (placed < b) {
+    /* seed: unplaced node of minimum degree */
+    int seed = -1;
+    for (int i = 0; i < b; ++i) if (pos[i] == UNSEEN && (seed < 0 || deg[i] < deg[seed])) seed = i;
+    /* pseudo-peripheral root: repeat BFS from the min-degree node of the last level */
+    int root = seed, ecc = -1;
+    for (int it = 0; it < 6; ++it) {
+      for (int i = 0; i < b; ++i) level[i] = (pos[i] == UNSEEN) ? UNSEEN : DONE;
+      int reached = 0;
+      int e = bfs_levels(b, xadj, adj, root, level, queue, UNSEEN, &reached);
+      if (e <= ecc) break;
+      ecc = e;
+      int cand = -1;
+      for (int q = 0; q < reached; ++q) { int u = queue[q]; if (level[u] == e && (cand < 0 || deg[u] < deg[cand])) cand = u; }
+      if (cand < 0 || cand == root) break;
+      root = cand;
+    }
+    /* Cuthill-McKee from root, neighbours by increasing degree */
+    int head = placed, tail = placed;
+    order[tail++] = root; pos[root] = DONE;
+    while (head < tail) {
+      int u = order[head++];
+      int s0 = tail;
+      for (int k = xadj[u]; k < xadj[u + 1]; ++k) { int v = adj[k]; if (pos[v] == UNSEEN) { pos[v] = DONE; order[tail++] = v; } }
+      for (int a = s0 + 1; a < tail; ++a) { /* insertion sort by degree */
+        int v = order[a], c = a;
+        while (c > s0 && deg[order[c - 1]] > deg[v]) { order[c] = order[c - 1]; --c; }
+        order[c] = v;
+      }
+    }
+    placed = tail;
+  }
+  for (int i = 0; i < b / 2; ++i) { int t = order[i]; order[i] = order[b - 1 - i]; order[b - 1 - i] = t; }
+  for (int i = 0; i < b; ++i) pos[order[i]] = i;
+}
+
+int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, int* colPos,
+                              int sizeColPos) {
+  (void)colPos; (void)sizeColPos;
+  PA_REQUIRE_GPU();
+  const pa_operator_info_t* op = pa_operator_info();
+  if (!op) return PA_FAIL("the operator must be built before the preconditioner");
+  if (!A || !A->rowPtr || !rowPos || sizeRowPos != op->nparts + 1)
+    return PA_FAIL(" wrong test 'A != NULL && sizeRowPos == nparts + 1'");
+  if (g_bj.created) preAlps_BlockJacobiFree();
+  pa_bj_t* s = &g_bj;
+  int np = op->part1 - op->part0, m = op->m, row_off = op->row_off;
+  s->np = np; s->m = m;
+  int* row0 = (int*)malloc(np * sizeof(int));
+  int* nrows = (int*)malloc(np * sizeof(int));
+  int* bw = (int*)calloc(np, sizeof(int));
+  long long* off = (long long*)malloc((np + 1) * sizeof(long long));
+  int* map_f = (int*)malloc((size_t)(m ? m : 1) * sizeof(int));
+  int* map_b = (int*)malloc((size_t)(m ? m : 1) * sizeof(int));
+  double* invd_f = (double*)malloc((size_t)(m ? m : 1) * sizeof(double));
+  double* invd_b = (double*)malloc((size_t)(m ? m : 1) * sizeof(double));
+  double** bands = (double**)calloc(np, sizeof(double*));
+  int fail_row = -1;
+  for (int q = 0; q < np; ++q) { row0[q] = rowPos[op->part0 + q] - row_off; nrows[q] = rowPos[op->part0 + q + 1] - rowPos[op->part0 + q]; }
+
+  /* pass 1 (parallel over blocks): RCM order, bandwidth, band Cholesky */
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int q = 0; q < np; ++q) {
+    int r0 = row0[q], b = nrows[q];
+    int g0 = rowPos[op->part0 + q], g1 = g0 + b;
+    int nadj = 0;
+    for (int i = 0; i < b; ++i)
+      for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) { int c = A->colInd[k]; if (c >= g0 && c < g1 && c != g0 + i) ++nadj; }
+    int* xadj = (int*)malloc((b + 1) * sizeof(int));
+    int* adj = (int*)malloc((nadj ? nadj : 1) * sizeof(int));
+    int* deg = (int*)malloc(b * sizeof(int));
+    int* order = (int*)malloc(b * sizeof(int));
+    int* pos = (int*)malloc(b * sizeof(int));
+    int* queue = (int*)malloc(b * sizeof(int));
+    int* level = (int*)malloc(b * sizeof(int));
+    xadj[0] = 0;
+    for (int i = 0; i < b; ++i) {
+      int e = xadj[i];
+      for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) { int c = A->colInd[k]; if (c >= g0 && c < g1 && c != g0 + i) adj[e++] = c - g0; }
+      xadj[i + 1] = e; deg[i] = e - xadj[i];
+    }
+    rcm_order(b, xadj, adj, deg, order, pos, queue, level);
+    int w = 0;
+    for (int i = 0; i < b; ++i)
+      for (int k = xadj[i]; k < xadj[i + 1]; ++k) { int dd = pos[i] - pos[adj[k]]; if (dd < 0) dd = -dd; if (dd > w) w = dd; }
+    bw[q] = w;
+    /* band[i*(w+1) + d] = A(new i, new i-d) */
+    double* band = (double*)calloc((size_t)b * (w + 1), sizeof(double));
+    for (int i = 0; i < b; ++i) {
+      int ni = pos[i];
+      for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) {
+        int c = A->colInd[k];
+        if (c < g0 || c >= g1) continue;
+        int nj = pos[c - g0];
+        if (nj <= ni) band[(size_t)ni * (w + 1) + (ni - nj)] = A->val[k];
+      }
+    }
+    size_t ld = (size_t)w + 1;
+    for (int i = 0; i < b; ++i) {
+      double* Li = band + (size_t)i * ld; /* Li[d] = L(i, i-d) */
+      int jlo = i - w > 0 ? i - w : 0;
+      for (int j = jlo; j < i; ++j) {
+        const double* Lj = band + (size_t)j * ld;
+        int klo = j - w > jlo ? j - w : jlo;
+        double sum = Li[i - j];
+        for (int k = klo; k < j; ++k) sum -= Li[i - k] * Lj[j - k];
+        Li[i - j] = sum / Lj[0];
+      }
+      double dsum = Li[0];
+      for (int k = jlo; k < i; ++k) dsum -= Li[i - k] * Li[i - k];
+      if (!(dsum > 0.0)) {
+#pragma omp critical
+        { if (fail_row < 0) fail_row = row_off + r0 + order[i]; }
+        dsum = NAN;
+      }
+      Li[0] = sqrt(dsum);
+    }
+    bands[q] = band;
+    for (int j = 0; j < b; ++j) {
+      map_f[r0 + j] = order[j];
+      map_b[r0 + j] = order[b - 1 - j];
+      invd_f[r0 + j] = 1.0 / band[(size_t)j * ld];
+      invd_b[r0 + j] = 1.0 / band[(size_t)(b - 1 - j) * ld];
+    }
+    free(xadj); free(adj); free(deg); free(order); free(pos); free(queue); free(level);
+  }
+  int rc = 0;
+  if (fail_row >= 0) rc = PA_FAIL("diagonal block is not SPD (global row %d)", fail_row);
+  /* pass 2: sweep layouts */
+  off[0] = 0;
+  int maxw = 0;
+  for (int q = 0; q < np; ++q) { off[q + 1] = off[q] + (long long)nrows[q] * bw[q]; if (bw[q] > maxw) maxw = bw[q]; }
+  s->max_bw = maxw;
+  int maxR = pa_bj_max_R();
+  if (!rc && (maxw + 127) / 64 > maxR)
+    rc = PA_FAIL("block-Jacobi: a diagonal block has bandwidth %d after RCM; the wavefront-resident solve "
+                 "supports up to %d -- use more (smaller) subdomains", maxw, 64 * maxR - 64);
+  size_t tot = (size_t)off[np];
+  double* Lf = NULL; double* Lb = NULL;
+  if (!rc) {
+    Lf = (double*)malloc((tot ? tot : 1) * sizeof(double));
+    Lb = (double*)malloc((tot ? tot : 1) * sizeof(double));
+    if (!Lf || !Lb) rc = PA_FAIL("out of host memory for %zu factor entries", tot);
+  }
+  if (!rc) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int q = 0; q < np; ++q) {
+      int b = nrows[q], w = bw[q];
+      size_t ld = (size_t)w + 1;
+      const double* band = bands[q];
+      double* f = Lf + off[q];
+      double* g = Lb + off[q];
+      for (int j = 0; j < b; ++j)
+        for (int dd = 1; dd <= w; ++dd) {
+          f[(size_t)j * w + dd - 1] = (j + dd < b) ? band[(size_t)(j + dd) * ld + dd] : 0.0;
+          int jr = b - 1 - j;
+          g[(size_t)j * w + dd - 1] = (jr - dd >= 0) ? band[(size_t)jr * ld + dd] : 0.0;
+        }
+    }
+  }
+  for (int q = 0; q < np; ++q) free(bands[q]);
+  free(bands);
+  /* classes */
+  if (!rc) {
+    int* cls = (int*)malloc(np * sizeof(int));
+    s->nclass = 0;
+    for (int q = 0; q < np; ++q) {
+      int R = (bw[q] + 127) / 64, c;
+      for (c = 0; c < s->nclass; ++c) if (s->class_R[c] == R) break;
+      if (c == s->nclass) { s->class_R[c] = R; s->class_count[c] = 0; s->nclass++; }
+      cls[q] = c; s->class_count[c]++;
+    }
+    for (int c = 0; c < s->nclass && !rc; ++c) {
+      int* list = (int*)malloc(s->class_count[c] * sizeof(int));
+      int n = 0;
+      for (int q = 0; q < np; ++q) if (cls[q] == c) list[n++] = q;
+      s->class_list[c] = (int*)pa_rt_malloc(n * sizeof(int));
+      rc = !s->class_list[c] || pa_rt_h2d(s->class_list[c], list, n * sizeof(int));
+      s->class_list_c[c] = s->class_list[c];
+      free(list);
+    }
+    free(cls);
+    if (rc) rc = PA_FAIL("uploading block lists failed: %s", pa_rt_error());
+  }
+  if (!rc) {
+    s->d_row0 = (int*)pa_rt_malloc(np * sizeof(int));
+    s->d_nrows = (int*)pa_rt_malloc(np * sizeof(int));
+    s->d_bw = (int*)pa_rt_malloc(np * sizeof(int));
+    s->d_off = (long long*)pa_rt_malloc((np + 1) * sizeof(long long));
+    s->d_map_f = (int*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(int));
+    s->d_map_b = (int*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(int));
+    s->d_invd_f = (double*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(double));
+    s->d_invd_b = (double*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(double));
+    s->d_Lf = (double*)pa_rt_malloc((tot ? tot : 1) * sizeof(double));
+    s->d_Lb = (double*)pa_rt_malloc((tot ? tot : 1) * sizeof(double));
+    int bad = !s->d_row0 || !s->d_nrows || !s->d_bw || !s->d_off || !s->d_map_f || !s->d_map_b ||
+              !s->d_invd_f || !s->d_invd_b || !s->d_Lf || !s->d_Lb;
+    bad = bad || pa_rt_h2d(s->d_row0, row0, np * sizeof(int)) || pa_rt_h2d(s->d_nrows, nrows, np * sizeof(int)) ||
+          pa_rt_h2d(s->d_bw, bw, np * sizeof(int)) || pa_rt_h2d(s->d_off, off, (np + 1) * sizeof(long long)) ||
+          pa_rt_h2d(s->d_map_f, map_f, (size_t)m * sizeof(int)) || pa_rt_h2d(s->d_map_b, map_b, (size_t)m * sizeof(int)) ||
+          pa_rt_h2d(s->d_invd_f, invd_f, (size_t)m * sizeof(double)) || pa_rt_h2d(s->d_invd_b, invd_b, (size_t)m * sizeof(double)) ||
+          pa_rt_h2d(s->d_Lf, Lf, tot * sizeof(double)) || pa_rt_h2d(s->d_Lb, Lb, tot * sizeof(double));
+    if (bad) rc = PA_FAIL("uploading the block factors failed: %s", pa_rt_error());
+  }
+  free(Lf); free(Lb);
+  free(row0); free(nrows); free(bw); free(off); free(map_f); free(map_b); free(invd_f); free(invd_b);
+  if (rc) { preAlps_BlockJacobiFree(); return rc; }
+  s->factor_bytes = 2.0 * 8.0 * (double)tot + 2.0 * 8.0 * (double)m;
+  pa_bj_plan_t* pl = &s->plan;
+  pl->nparts = np; pl->row0 = s->d_row0; pl->nrows = s->d_nrows; pl->bw = s->d_bw; pl->off = s->d_off;
+  pl->map_f = s->d_map_f; pl->map_b = s->d_map_b; pl->Lf = s->d_Lf; pl->Lb = s->d_Lb;
+  pl->invd_f = s->d_invd_f; pl->invd_b = s->d_invd_b;
+  pl->nclass = s->nclass; pl->class_R = s->class_R; pl->class_count = s->class_count;
+  pl->class_list = s->class_list_c;
+  s->created = 1;
+  return 0;
+}
+
+/* B_out = M^-1 A_in on the A_in->info.n current columns; the output
+ * descriptor takes the input's shape (cplm_kernels.c:819-828). */
+int preAlps_BlockJacobiApply(CPLM_Mat_Dense_t* A_in, CPLM_Mat_Dense_t* B_out) {
+  pa_bj_t* s = &g_bj;
+  if (!s->created) return PA_FAIL("preconditioner not created");
+  if (!A_in || !B_out || !A_in->val || !B_out->val) return PA_FAIL(" wrong test 'A_in->val != NULL && B_out->val != NULL'");
+  int ts = pa_desc_stride(A_in);
+  if (pa_desc_stride(B_out) != ts || A_in->info.m != s->m)
+    return PA_FAIL("panel shapes do not match the preconditioner (m %d vs %d)", A_in->info.m, s->m);
+  B_out->info.n = A_in->info.n; B_out->info.N = A_in->info.N;
+  B_out->info.nval = B_out->info.m * B_out->info.n;
+  pa_time_begin(PA_T_PRECOND);
+  if (pa_k_bj_apply(&s->plan, ts, A_in->val, B_out->val)) return PA_FAIL("block-Jacobi kernel launch failed");
+  pa_time_end(PA_T_PRECOND);
+  return 0;
+}

@@ -1,0 +1,215 @@
+/*
+ * context.c -- process-wide state of libprealps_hip.so: device selection,
+ * error reporting in the reference's CPLM_Abort style, the process-group
+ * hooks, phase timers and the dense descriptor helper.
+ *
+ * Reference behaviour mirrored here:
+ *   CPLM_FAbort / CPLM_efprintf   utils/cplm_core/cplm_utils.c:17-58
+ *   CPLM_MatDenseSetInfo          utils/cplm_light/cplm_matdense.c:124-135
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "pa_host.h"
+
+static int g_abort_mode = 1;
+static char g_last_error[1024] = "";
+static int g_rank = 0, g_size = 1;
+static preAlps_allreduce_fn g_allreduce = NULL;
+static preAlps_exchange_fn g_exchange = NULL;
+static void* g_comm_ctx = NULL;
+
+static int g_timing = 0;
+static double g_times[PA_T_COUNT];
+static void* g_ev0 = NULL;
+static void* g_ev1 = NULL;
+
+double pa_wtime(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int pa_fail_at(const char* func, const char* fmt, ...) {
+  char msg[900];
+  va_list va;
+  va_start(va, fmt);
+  vsnprintf(msg, sizeof(msg), fmt, va);
+  va_end(va);
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s", func, msg);
+  if (g_abort_mode) {
+    /* same shape as the reference's abort banner */
+    fprintf(stderr, "\nABORTING from %s : [Proc: %d] %s\n\n", func, g_rank, msg);
+    fflush(stderr);
+    abort();
+  }
+  return 1;
+}
+
+void preAlps_hip_set_abort_mode(int abort_on_error) { g_abort_mode = abort_on_error ? 1 : 0; }
+const char* preAlps_hip_last_error(void) { return g_last_error; }
+
+int pa_default_device(void) {
+  const char* lr = getenv("LOCAL_RANK");
+  return lr ? atoi(lr) : 0;
+}
+
+int preAlps_hip_init(int device) {
+  if (pa_rt_init(device) != 0) return PA_FAIL("%s", pa_rt_error());
+  return 0;
+}
+
+void preAlps_hip_shutdown(void) {
+  pa_rt_event_destroy(g_ev0);
+  pa_rt_event_destroy(g_ev1);
+  g_ev0 = g_ev1 = NULL;
+  pa_rt_shutdown();
+}
+
+int preAlps_hip_set_stream(void* s) {
+  PA_REQUIRE_GPU();
+  pa_rt_set_stream(s);
+  return 0;
+}
+void* preAlps_hip_get_stream(void) { return pa_rt_stream(); }
+int preAlps_hip_sync(void) {
+  if (!pa_rt_ready()) return 0;
+  PA_CHECK(pa_rt_sync());
+  return 0;
+}
+
+/* ---- panels ------------------------------------------------------------- */
+int pa_panel_stride(int enlFac) {
+  int ts = 2;
+  while (ts < enlFac) ts <<= 1;
+  return ts;
+}
+int preAlps_hip_panel_stride(int enlFac) { return pa_panel_stride(enlFac); }
+
+/* Reference semantics (lda = m for COL_MAJOR, n for ROW_MAJOR). */
+int CPLM_MatDenseSetInfo(CPLM_Mat_Dense_t* A, int M, int N, int m, int n,
+                         CPLM_storage_type_t storage) {
+  A->info.M = M; A->info.N = N; A->info.m = m; A->info.n = n;
+  A->info.lda = (storage == ROW_MAJOR) ? n : m;
+  A->info.nval = m * n;
+  A->info.stor_type = storage;
+  return 0;
+}
+
+/* Device panels: ROW_MAJOR with the fixed stride ts as leading dimension. */
+void pa_set_desc(CPLM_Mat_Dense_t* A, int M, int N, int m, int n, int ts) {
+  CPLM_MatDenseSetInfo(A, M, N, m, n, ROW_MAJOR);
+  A->info.lda = ts;
+}
+
+/* ---- process group -------------------------------------------------------- */
+int preAlps_hip_set_world(int rank, int size) {
+  if (size < 1 || rank < 0 || rank >= size) return PA_FAIL("invalid rank %d of %d", rank, size);
+  g_rank = rank; g_size = size;
+  return 0;
+}
+int preAlps_hip_set_comm(preAlps_allreduce_fn allreduce, preAlps_exchange_fn exchange, void* ctx) {
+  g_allreduce = allreduce; g_exchange = exchange; g_comm_ctx = ctx;
+  return 0;
+}
+int pa_world_rank(void) { return g_rank; }
+int pa_world_size(void) { return g_size; }
+
+int pa_allreduce(double* dev_buf, int count) {
+  if (g_size == 1 || count <= 0) return 0;
+  if (!g_allreduce) return PA_FAIL("%d processes but no all-reduce hook (preAlps_hip_set_comm)", g_size);
+  pa_time_begin(PA_T_COMM);
+  int rc = g_allreduce(g_comm_ctx, dev_buf, count);
+  pa_time_end(PA_T_COMM);
+  if (rc) return PA_FAIL("all-reduce hook returned %d", rc);
+  return 0;
+}
+
+int pa_exchange(const double* dev_send, const int* send_counts, double* dev_recv,
+                const int* recv_counts, const int* peers, int npeers) {
+  if (g_size == 1 || npeers <= 0) return 0;
+  if (!g_exchange) return PA_FAIL("%d processes but no halo-exchange hook (preAlps_hip_set_comm)", g_size);
+  pa_time_begin(PA_T_COMM);
+  int rc = g_exchange(g_comm_ctx, dev_send, send_counts, dev_recv, recv_counts, peers, npeers);
+  pa_time_end(PA_T_COMM);
+  if (rc) return PA_FAIL("halo-exchange hook returned %d", rc);
+  return 0;
+}
+
+/* ---- timing --------------------------------------------------------------- */
+static const char* k_time_keys[PA_T_COUNT] = {"operator", "precond", "gram", "trsm",
+                                              "update", "small", "comm"};
+static int g_time_depth = 0;
+
+void preAlps_hip_timing(int enable) {
+  g_timing = enable ? 1 : 0;
+  if (g_timing && pa_rt_ready() && !g_ev0) {
+    g_ev0 = pa_rt_event_create();
+    g_ev1 = pa_rt_event_create();
+  }
+}
+void preAlps_hip_timing_reset(void) { memset(g_times, 0, sizeof(g_times)); }
+
+void pa_time_begin(int key) {
+  (void)key;
+  if (!g_timing || !g_ev0) return;
+  if (g_time_depth++ == 0) pa_rt_event_record(g_ev0);
+}
+void pa_time_end(int key) {
+  if (!g_timing || !g_ev0) return;
+  if (--g_time_depth == 0) {
+    pa_rt_event_record(g_ev1);
+    double s = pa_rt_event_elapsed_s(g_ev0, g_ev1);
+    if (s > 0) g_times[key] += s;
+  }
+}
+int preAlps_hip_get_time(const char* key, double* seconds) {
+  for (int i = 0; i < PA_T_COUNT; ++i)
+    if (strcmp(key, k_time_keys[i]) == 0) { *seconds = g_times[i]; return 0; }
+  return 1;
+}
+
+/* ---- host <-> device panels ------------------------------------------------ */
+int preAlps_hip_panel_alloc(CPLM_Mat_Dense_t* A, int M, int N, int m, int n, int enlFac) {
+  PA_REQUIRE_GPU();
+  int ts = pa_panel_stride(enlFac);
+  if (n > ts) return PA_FAIL("panel with %d columns does not fit stride %d", n, ts);
+  A->val = (double*)pa_rt_malloc((size_t)(m > 0 ? m : 1) * ts * sizeof(double));
+  if (!A->val) return PA_FAIL("device allocation failed: %s", pa_rt_error());
+  PA_CHECK(pa_rt_memset(A->val, 0, (size_t)m * ts * sizeof(double)));
+  pa_set_desc(A, M, N, m, n, ts);
+  return 0;
+}
+void preAlps_hip_panel_free(CPLM_Mat_Dense_t* A) {
+  if (A && A->val) { pa_rt_free(A->val); A->val = NULL; }
+}
+
+int preAlps_hip_panel_to_host(const CPLM_Mat_Dense_t* A, int enlFac, double* host, int ld) {
+  PA_REQUIRE_GPU();
+  (void)enlFac;
+  int m = A->info.m, n = A->info.n, ts = pa_desc_stride(A);
+  double* tmp = (double*)malloc((size_t)(m > 0 ? m : 1) * ts * sizeof(double));
+  if (!tmp) return PA_FAIL("out of host memory");
+  if (pa_rt_d2h(tmp, A->val, (size_t)m * ts * sizeof(double))) { free(tmp); return PA_FAIL("%s", pa_rt_error()); }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < m; ++i) host[i + (size_t)ld * j] = tmp[(size_t)i * ts + j];
+  free(tmp);
+  return 0;
+}
+
+int preAlps_hip_panel_from_host(CPLM_Mat_Dense_t* A, int enlFac, const double* host, int ld) {
+  PA_REQUIRE_GPU();
+  (void)enlFac;
+  int m = A->info.m, n = A->info.n, ts = pa_desc_stride(A);
+  double* tmp = (double*)calloc((size_t)(m > 0 ? m : 1) * ts, sizeof(double));
+  if (!tmp) return PA_FAIL("out of host memory");
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < m; ++i) tmp[(size_t)i * ts + j] = host[i + (size_t)ld * j];
+  int rc = pa_rt_h2d(A->val, tmp, (size_t)m * ts * sizeof(double));
+  free(tmp);
+  if (rc) return PA_FAIL("%s", pa_rt_error());
+  return 0;
+}

@@ -1,0 +1,645 @@
+/*
+ * ecg.c -- Enlarged Conjugate Gradient, reverse-communication state machine,
+ * with every panel resident in HBM and every O(m) operation a HIP kernel.
+ *
+ * Reference behaviour kept (src/solvers/ecg.c under /root/reference):
+ *   _preAlps_ECGMalloc          :41-96     one pool, V | AV | Z | R | X | small
+ *   _preAlps_ECGReset / Split   :98-171, :201-221
+ *   preAlps_ECGInitialize       :173-199   (size >= enlFac check on nparts)
+ *   preAlps_ECGStoppingCriterion:223-271   Frobenius norm of the residual block
+ *   _preAlps_ECGIterateOmin     :289-400   incl. BF-Omin (dpstrf / dlapmt)
+ *   _preAlps_ECGIterateOdir     :402-530   incl. D-Odir (dgesvd / dgeqrf / dormqr)
+ *   _preAlps_ECGIterateOdirFused:532-658   one reduction per iteration
+ *   preAlps_ECGFinalize/WrapUp/Free :660-692, preAlps_ECGPrint :694-728
+ *
+ * MI355X design instead of the reference's:
+ *   - panels are row-interleaved [m][ts] so one CSR gather touches one 8*ts-byte
+ *     chunk; descriptors say ROW_MAJOR with lda = ts and hold device pointers;
+ *   - without block-size reduction the three mkl_domatcopy per iteration
+ *     (ecg.c:521-523) are pointer rotations among the P / P_prev / Z buffers;
+ *   - t x t blocks stay on the device (Gram partials -> fixed-order finish ->
+ *     all-reduce hook -> one-wave Cholesky); the host only reads the residual
+ *     norm once per iteration, inside preAlps_ECGStoppingCriterion.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pa_host.h"
+#include "smalldense.h"
+
+#define PA_ECG_MAGIC 0x45434731u
+
+typedef struct {
+  unsigned magic;
+  int ts, T, m;
+  size_t pool_doubles;
+  /* panel buffers (device) */
+  double* buf_v[2];   /* P slot, P_prev slot */
+  double* buf_av[2];  /* AP slot, AP_prev slot */
+  double* buf_z;
+  double* d_R; double* d_X;
+  /* small blocks (device): F = [alpha T^2 | beta 2T^2 | mu T^2 | rtr T^2] */
+  double* d_F; double* d_alpha; double* d_beta; double* d_mu; double* d_rtr;
+  double* d_res2; double* d_q;
+  double* d_partials; double* d_rtr_part;
+  int rtr_nblk, rtr_valid;
+  int* d_info; int* d_piv;
+  double* h_pin;      /* pinned: [0] res2, [1..] scratch */
+  int* h_pin_i;
+  int rotate;         /* NO_BS_RED: rotate pointers instead of copying */
+} ecg_priv_t;
+
+static ecg_priv_t* priv_of(preAlps_ECG_t* ecg) {
+  if (!ecg || !ecg->iwork) return NULL;
+  int T = ecg->enlFac;
+  int skip = (T + 3) & ~3; /* iwork[0..T) stays the pivot array of the reference */
+  ecg_priv_t* p = (ecg_priv_t*)(ecg->iwork + skip);
+  return p->magic == PA_ECG_MAGIC ? p : NULL;
+}
+
+static void publish_pointers(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
+  ecg->V->val = pv->buf_v[0];
+  ecg->AV->val = pv->buf_av[0];
+  ecg->P->val = pv->buf_v[0];
+  ecg->AP->val = pv->buf_av[0];
+  ecg->Z->val = pv->buf_z;
+  ecg->R->val = pv->d_R;
+  ecg->X->val = pv->d_X;
+  ecg->alpha->val = pv->d_alpha;
+  ecg->beta->val = pv->d_beta;
+  ecg->P_p = pv->buf_v[0];
+  ecg->AP_p = pv->buf_av[0];
+  ecg->R_p = pv->d_R;
+  ecg->Z_p = pv->buf_z;
+}
+
+/* ------------------------------------------------------------- malloc ---- */
+int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
+  PA_REQUIRE_GPU();
+  int m = ecg->locPbSize, T = ecg->enlFac;
+  if (T < 1 || T > 16) return PA_FAIL("enlarging factor %d outside the supported range 1..16", T);
+  int ts = pa_panel_stride(T);
+  ecg->X = (CPLM_Mat_Dense_t*)calloc(1, sizeof(CPLM_Mat_Dense_t));
+  ecg->R = (CPLM_Mat_Dense_t*)calloc(1, sizeof(CPLM_Mat_Dense_t));
+  ecg->V = (CPLM_Mat_Dense_t*)calloc(1, sizeof(CPLM_Mat_Dense_t));
+  ecg->AV = (CPLM_Mat_Dense_t*)calloc(1, sizeof(CPLM_Mat_Dense_t));
+  ecg->Z = (CPLM_Mat_Dense_t*)calloc(1, sizeof(CPLM_Mat_Dense_t));
+  ecg->alpha = (CPLM_Mat_Dense_t*)calloc(1, sizeof(CPLM_Mat_Dense_t));
+  ecg->beta = (CPLM_Mat_Dense_t*)calloc(1, sizeof(CPLM_Mat_Dense_t));
+  ecg->P = (CPLM_Mat_Dense_t*)calloc(1, sizeof(CPLM_Mat_Dense_t));
+  ecg->AP = (CPLM_Mat_Dense_t*)calloc(1, sizeof(CPLM_Mat_Dense_t));
+  int skip = (T + 3) & ~3;
+  ecg->iwork = (int*)calloc(1, skip * sizeof(int) + sizeof(ecg_priv_t));
+  ecg_priv_t* pv = (ecg_priv_t*)(ecg->iwork + skip);
+  pv->magic = PA_ECG_MAGIC; pv->ts = ts; pv->T = T; pv->m = m;
+  /* pool: same order as the reference (V, AV, Z, R, X, then the small blocks);
+   * Orthomin needs no P_prev / AP_prev slots (ecg.c:55-61) */
+  size_t panel = (size_t)(m > 0 ? m : 1) * ts;
+  int nv = (ecg->ortho_alg == ORTHOMIN) ? 1 : 2;
+  size_t small = 5 * (size_t)T * T + 2 * (size_t)T * T /* q, scratch */ + 8;
+  size_t parts = (size_t)pa_gram_max_blocks() * (2 * (size_t)ts * ts + ts);
+  pv->pool_doubles = (2 * nv + 3) * panel + small + parts;
+  ecg->work = (double*)pa_rt_malloc(pv->pool_doubles * sizeof(double));
+  if (!ecg->work) return PA_FAIL("device pool of %zu doubles: %s", pv->pool_doubles, pa_rt_error());
+  double* w = ecg->work;
+  pv->buf_v[0] = w; w += panel;
+  pv->buf_v[1] = (nv == 2) ? w : NULL; if (nv == 2) w += panel;
+  pv->buf_av[0] = w; w += panel;
+  pv->buf_av[1] = (nv == 2) ? w : NULL; if (nv == 2) w += panel;
+  pv->buf_z = w; w += panel;
+  pv->d_R = w; w += panel;
+  pv->d_X = w; w += panel;
+  pv->d_F = w; pv->d_alpha = w; pv->d_beta = w + (size_t)T * T; pv->d_mu = w + 3 * (size_t)T * T;
+  pv->d_rtr = w + 4 * (size_t)T * T; w += 5 * (size_t)T * T;
+  pv->d_q = w; w += 2 * (size_t)T * T;
+  pv->d_res2 = w; w += 8;
+  pv->d_partials = w; w += (size_t)pa_gram_max_blocks() * 2 * ts * ts;
+  pv->d_rtr_part = w;
+  pv->d_info = (int*)pa_rt_malloc((8 + T) * sizeof(int));
+  if (!pv->d_info) return PA_FAIL("device allocation failed: %s", pa_rt_error());
+  pv->d_piv = pv->d_info + 8;
+  pv->h_pin = (double*)pa_rt_host_alloc((16 + 4 * (size_t)T * T) * sizeof(double));
+  pv->h_pin_i = (int*)pa_rt_host_alloc((8 + T) * sizeof(int));
+  if (!pv->h_pin || !pv->h_pin_i) return PA_FAIL("pinned allocation failed: %s", pa_rt_error());
+  publish_pointers(ecg, pv);
+  return 0;
+}
+
+/* ------------------------------------------------------------- reset ---- */
+int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
+  ecg_priv_t* pv = priv_of(ecg);
+  if (!pv) return PA_FAIL("solver memory not allocated (_preAlps_ECGMalloc)");
+  const pa_operator_info_t* op = pa_operator_info();
+  if (!op) return PA_FAIL("the operator must be built before the solver");
+  if (ecg->locPbSize != op->m) return PA_FAIL("locPbSize %d differs from the operator's %d rows", ecg->locPbSize, op->m);
+  ecg->tot_t = ecg->comm_t = ecg->trsm_t = ecg->gemm_t = ecg->potrf_t = ecg->pstrf_t = 0.0;
+  ecg->lapmt_t = ecg->gesvd_t = ecg->geqrf_t = ecg->ormqr_t = ecg->copy_t = 0.0;
+  int M = ecg->globPbSize, m = ecg->locPbSize, t = ecg->enlFac, ts = pv->ts;
+  /* pointer order back to the initial one */
+  {
+    size_t panel = (size_t)(m > 0 ? m : 1) * ts;
+    double* w = ecg->work;
+    int nv = (ecg->ortho_alg == ORTHOMIN) ? 1 : 2;
+    pv->buf_v[0] = w; w += panel; if (nv == 2) { pv->buf_v[1] = w; w += panel; }
+    pv->buf_av[0] = w; w += panel; if (nv == 2) { pv->buf_av[1] = w; w += panel; }
+    pv->buf_z = w;
+  }
+  publish_pointers(ecg, pv);
+  pv->rotate = (ecg->bs_red == NO_BS_RED);
+  pa_set_desc(ecg->X, M, t, m, t, ts);
+  pa_set_desc(ecg->R, M, t, m, t, ts);
+  pa_set_desc(ecg->Z, M, t, m, t, ts);
+  if (ecg->ortho_alg == ORTHOMIN) {
+    pa_set_desc(ecg->V, M, t, m, t, ts);
+    pa_set_desc(ecg->AV, M, t, m, t, ts);
+    CPLM_MatDenseSetInfo(ecg->alpha, t, t, t, t, COL_MAJOR);
+    CPLM_MatDenseSetInfo(ecg->beta, t, t, t, t, COL_MAJOR);
+  } else {
+    pa_set_desc(ecg->V, M, 2 * t, m, 2 * t, ts);
+    pa_set_desc(ecg->AV, M, 2 * t, m, 2 * t, ts);
+    CPLM_MatDenseSetInfo(ecg->alpha, t, t, t, t, COL_MAJOR);
+    CPLM_MatDenseSetInfo(ecg->beta, 2 * t, t, 2 * t, t, COL_MAJOR);
+  }
+  pa_set_desc(ecg->P, M, t, m, t, ts);
+  pa_set_desc(ecg->AP, M, t, m, t, ts);
+  PA_CHECK(pa_rt_memset(ecg->work, 0, pv->pool_doubles * sizeof(double)));
+  /* normb and R0: column (rank % t) of every reference rank = part */
+  double nb2 = 0.0;
+  double* r0 = (double*)calloc((size_t)(m > 0 ? m : 1) * ts, sizeof(double));
+  if (!r0) return PA_FAIL("out of host memory");
+  for (int p = op->part0; p < op->part1; ++p) {
+    int base = op->rowPos[p] - op->row_off, l = op->rowPos[p + 1] - op->rowPos[p];
+    int col = p % t;
+    double s = 0.0;
+    for (int i = 0; i < l; ++i) { double v = rhs[base + i]; s += v * v; r0[(size_t)(base + i) * ts + col] = v; }
+    nb2 += s;
+  }
+  int rc = pa_rt_h2d(pv->d_R, r0, (size_t)m * ts * sizeof(double));
+  free(r0);
+  if (rc) return PA_FAIL("%s", pa_rt_error());
+  if (pa_world_size() > 1) {
+    double t0 = pa_wtime();
+    PA_CHECK(pa_rt_h2d(pv->d_res2, &nb2, sizeof(double)));
+    if (pa_allreduce(pv->d_res2, 1)) return 1;
+    PA_CHECK(pa_rt_d2h(&nb2, pv->d_res2, sizeof(double)));
+    ecg->comm_t += pa_wtime() - t0;
+  }
+  ecg->normb = sqrt(nb2);
+  ecg->res = 1.0; ecg->iter = 0; ecg->bs = t; ecg->kbs = ecg->V->info.n;
+  pv->rtr_valid = 0;
+  *rci_request = 0;
+  return 0;
+}
+
+int preAlps_ECGInitialize(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
+  const pa_operator_info_t* op = pa_operator_info();
+  if (!op) return PA_FAIL("the operator must be built before the solver");
+  /* ecg.c:178-183 with the reference's "processors" = subdomains */
+  if (op->nparts < ecg->enlFac)
+    return PA_FAIL("Enlarging factor must be lower than the number of processors"
+                   " in the MPI communicator! size: %d ; enlarging factor: %d", op->nparts, ecg->enlFac);
+  int rc = _preAlps_ECGMalloc(ecg);
+  if (rc) return rc;
+  return _preAlps_ECGReset(ecg, rhs, rci_request);
+}
+
+int _preAlps_ECGSplit(double* x, CPLM_Mat_Dense_t* XSplit, int colIndex) {
+  if (!XSplit || !XSplit->val || !x) return PA_FAIL(" wrong test 'XSplit->val != NULL && x != NULL'");
+  int m = XSplit->info.m, ts = pa_desc_stride(XSplit);
+  double* tmp = (double*)malloc((size_t)(m > 0 ? m : 1) * ts * sizeof(double));
+  if (!tmp) return PA_FAIL("out of host memory");
+  int rc = pa_rt_d2h(tmp, XSplit->val, (size_t)m * ts * sizeof(double));
+  for (int i = 0; i < m; ++i) tmp[(size_t)i * ts + colIndex] = x[i];
+  rc = rc || pa_rt_h2d(XSplit->val, tmp, (size_t)m * ts * sizeof(double));
+  free(tmp);
+  if (rc) return PA_FAIL("%s", pa_rt_error());
+  return 0;
+}
+
+/* ---------------------------------------------------------- stopping ---- */
+static int fetch_res2(preAlps_ECG_t* ecg, ecg_priv_t* pv, double* res2, int* info) {
+  double t0 = pa_wtime();
+  if (pa_allreduce(pv->d_res2, 1)) return 1;
+  ecg->comm_t += pa_wtime() - t0;
+  PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->d_res2, sizeof(double)));
+  PA_CHECK(pa_rt_d2h_async(pv->h_pin_i, pv->d_info, sizeof(int)));
+  PA_CHECK(pa_rt_sync());
+  *res2 = pv->h_pin[0];
+  *info = pv->h_pin_i[0];
+  return 0;
+}
+
+int preAlps_ECGStoppingCriterion(preAlps_ECG_t* ecg, int* stop) {
+  ecg_priv_t* pv = priv_of(ecg);
+  if (!pv) return PA_FAIL("solver not initialised");
+  if (!stop) return PA_FAIL(" wrong test 'stop != NULL'");
+  double tg = pa_wtime();
+  int T = ecg->enlFac;
+  if (!pv->rtr_valid) {
+    PA_CHECK(pa_k_colnorm2(pv->m, pv->ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
+  }
+  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2));
+  pv->rtr_valid = 0;
+  double res2 = 0.0; int info = 0;
+  if (fetch_res2(ecg, pv, &res2, &info)) return 1;
+  if (info != 0 && ecg->ortho_alg == ORTHOMIN) return PA_FAIL("ACHQR: dpotrf:\n ERROR: P^tAP is not spd!");
+  ecg->res = sqrt(res2);
+  /* !(a > b) also stops on NaN, like the reference's comparison */
+  if (ecg->res > ecg->normb * ecg->tol && ecg->iter < ecg->maxIter && ecg->bs > 0) *stop = 0;
+  else *stop = 1;
+  ecg->tot_t += pa_wtime() - tg;
+  return 0;
+}
+
+/* ------------------------------------------------------ shared pieces ---- */
+/* W = AP^T P -> all-reduce -> U^T U ; P <- P U^-1 ; AP <- AP U^-1 ;
+ * alpha = P^T R -> all-reduce   (ecg.c:311-333, :425-443) */
+static int a_orthonormalise_and_alpha(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
+  int nb = 0, m = pv->m, ts = pv->ts;
+  double t0;
+  pa_time_begin(PA_T_GRAM);
+  t0 = pa_wtime();
+  PA_CHECK(pa_k_gram(m, ts, ecg->AP->val, NULL, ecg->P->val, pv->d_partials, &nb));
+  PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, t, 0, t, pv->d_mu, t));
+  ecg->gemm_t += pa_wtime() - t0;
+  pa_time_end(PA_T_GRAM);
+  t0 = pa_wtime();
+  if (pa_allreduce(pv->d_mu, t * t)) return 1;
+  ecg->comm_t += pa_wtime() - t0;
+  pa_time_begin(PA_T_SMALL);
+  t0 = pa_wtime();
+  PA_CHECK(pa_k_potrf(pv->d_mu, t, pv->d_info));
+  ecg->potrf_t += pa_wtime() - t0;
+  pa_time_end(PA_T_SMALL);
+  pa_time_begin(PA_T_TRSM);
+  t0 = pa_wtime();
+  PA_CHECK(pa_k_trsm(m, ts, t, pv->d_mu, ecg->P->val, ecg->AP->val));
+  ecg->trsm_t += pa_wtime() - t0;
+  pa_time_end(PA_T_TRSM);
+  pa_time_begin(PA_T_GRAM);
+  t0 = pa_wtime();
+  PA_CHECK(pa_k_gram(m, ts, ecg->P->val, NULL, ecg->R->val, pv->d_partials, &nb));
+  PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, ecg->alpha->info.m, 0, ecg->alpha->info.n,
+                       pv->d_alpha, ecg->alpha->info.lda));
+  ecg->gemm_t += pa_wtime() - t0;
+  pa_time_end(PA_T_GRAM);
+  t0 = pa_wtime();
+  if (pa_allreduce(pv->d_alpha, ecg->alpha->info.lda * ecg->alpha->info.n)) return 1;
+  ecg->comm_t += pa_wtime() - t0;
+  return 0;
+}
+
+/* X += P alpha ; R -= AP alpha (ecg.c:337-338, :500-501) + residual norms */
+static int update_iterate(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
+  double t0 = pa_wtime();
+  pa_time_begin(PA_T_UPDATE);
+  PA_CHECK(pa_k_update_xr(pv->m, pv->ts, ecg->P->info.n, ecg->X->info.n, pv->d_alpha, ecg->P->val,
+                          ecg->AP->val, pv->d_X, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
+  pa_time_end(PA_T_UPDATE);
+  pv->rtr_valid = 1;
+  ecg->gemm_t += pa_wtime() - t0;
+  return 0;
+}
+
+/* The reference's "Swapping time" (ecg.c:521-523 / :358): without block-size
+ * reduction all columns are live, so the copies become pointer rotations. */
+static int shift_directions(preAlps_ECG_t* ecg, ecg_priv_t* pv, int ncopy) {
+  double t0 = pa_wtime();
+  if (ecg->ortho_alg == ORTHOMIN) {
+    if (pv->rotate) { double* p = pv->buf_v[0]; pv->buf_v[0] = pv->buf_z; pv->buf_z = p; }
+    else PA_CHECK(pa_k_copy_cols(pv->m, pv->ts, ncopy, pv->buf_z, pv->buf_v[0]));
+  } else if (pv->rotate) {
+    double* oldprev = pv->buf_v[1];
+    pv->buf_v[1] = pv->buf_v[0]; pv->buf_v[0] = pv->buf_z; pv->buf_z = oldprev;
+    double* oldaprev = pv->buf_av[1];
+    pv->buf_av[1] = pv->buf_av[0]; pv->buf_av[0] = oldaprev;
+  } else {
+    PA_CHECK(pa_k_copy_cols(pv->m, pv->ts, ncopy, pv->buf_v[0], pv->buf_v[1]));
+    PA_CHECK(pa_k_copy_cols(pv->m, pv->ts, ncopy, pv->buf_av[0], pv->buf_av[1]));
+    PA_CHECK(pa_k_copy_cols(pv->m, pv->ts, ncopy, pv->buf_z, pv->buf_v[0]));
+  }
+  publish_pointers(ecg, pv);
+  ecg->copy_t += pa_wtime() - t0;
+  return 0;
+}
+
+/* beta = AV^T Z over kbs columns of [slot 0 | slot 1] -> all-reduce ;
+ * Z -= V beta (ecg.c:510-517) */
+static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
+  int T = ecg->enlFac, nb = 0;
+  int kb = ecg->beta->info.m; /* rows of beta = columns of V in use */
+  int a_lo = kb < T ? kb : T, a_hi = kb - a_lo;
+  double t0 = pa_wtime();
+  pa_time_begin(PA_T_GRAM);
+  PA_CHECK(pa_k_gram(pv->m, pv->ts, pv->buf_av[0], a_hi > 0 ? pv->buf_av[1] : NULL, pv->buf_z,
+                     pv->d_partials, &nb));
+  PA_CHECK(pa_k_finish(pv->d_partials, nb, a_hi > 0 ? 2 : 1, pv->ts, a_lo, a_hi, ecg->beta->info.n,
+                       pv->d_beta, ecg->beta->info.lda));
+  pa_time_end(PA_T_GRAM);
+  ecg->gemm_t += pa_wtime() - t0;
+  t0 = pa_wtime();
+  if (pa_allreduce(pv->d_beta, ecg->beta->info.lda * ecg->beta->info.n)) return 1;
+  ecg->comm_t += pa_wtime() - t0;
+  t0 = pa_wtime();
+  pa_time_begin(PA_T_UPDATE);
+  int vn = ecg->V->info.n;
+  int v_lo = vn < T ? vn : T, v_hi = vn - v_lo;
+  PA_CHECK(pa_k_update_z(pv->m, pv->ts, v_lo, v_hi, ecg->Z->info.n, pv->d_beta, ecg->beta->info.lda,
+                         pv->buf_v[0], pv->buf_v[1], pv->buf_z));
+  pa_time_end(PA_T_UPDATE);
+  ecg->gemm_t += pa_wtime() - t0;
+  return 0;
+}
+
+/* ---- D-Odir: reduction of the search directions (ecg.c:445-497, :593-637) -- */
+static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z) {
+  int M = ecg->globPbSize, m = pv->m, ts = pv->ts, nrhs = ecg->enlFac;
+  int t = ecg->P->info.n, t1 = 0;
+  double tol = ecg->tol * ecg->normb / sqrt((double)nrhs), t0;
+  double* ha = pv->h_pin + 16;                 /* t x nrhs, ld t */
+  double* hq = ha + (size_t)nrhs * nrhs;       /* t x t */
+  double sig[16];
+  t0 = pa_wtime();
+  PA_CHECK(pa_rt_d2h_async(ha, pv->d_alpha, (size_t)t * nrhs * sizeof(double)));
+  PA_CHECK(pa_rt_sync());
+  ecg->copy_t += pa_wtime() - t0;
+  t0 = pa_wtime();
+  pa_sd_left_singular(t, nrhs, ha, t, hq, sig); /* hq = U, sig decreasing */
+  ecg->gesvd_t += pa_wtime() - t0;
+  for (int i = 0; i < t; ++i) { if (sig[i] > tol) t1++; else break; }
+  if (t1 > 0 && t1 < nrhs && t1 < t) {
+    t0 = pa_wtime();
+    pa_sd_qr_q(t, hq);                         /* hq <- Q of the Householder QR of U */
+    ecg->geqrf_t += pa_wtime() - t0;
+    t0 = pa_wtime();
+    pa_sd_qt_times(t, nrhs, hq, ha);           /* alpha <- Q^T alpha */
+    /* keep the first t1 rows, leading dimension t1 (mkl_dimatcopy, ecg.c:483) */
+    double* packed = hq + (size_t)nrhs * nrhs;
+    for (int j = 0; j < nrhs; ++j) for (int i = 0; i < t1; ++i) packed[i + (size_t)t1 * j] = ha[i + (size_t)t * j];
+    PA_CHECK(pa_rt_h2d(pv->d_alpha, packed, (size_t)t1 * nrhs * sizeof(double)));
+    PA_CHECK(pa_rt_h2d(pv->d_q, hq, (size_t)t * t * sizeof(double)));
+    PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->P->val));
+    PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->AP->val));
+    if (with_Z) PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->Z->val));
+    ecg->ormqr_t += pa_wtime() - t0;
+    CPLM_MatDenseSetInfo(ecg->alpha, t1, nrhs, t1, nrhs, COL_MAJOR);
+    pa_set_desc(ecg->P, M, t1, m, t1, ts);
+    pa_set_desc(ecg->AP, M, t1, m, t1, ts);
+    pa_set_desc(ecg->Z, M, t1, m, t1, ts);
+    ecg->bs = t1;
+    ecg->kbs = t + nrhs;
+  }
+  CPLM_MatDenseSetInfo(ecg->beta, ecg->kbs, t1, ecg->kbs, t1, COL_MAJOR);
+  pa_set_desc(ecg->V, M, ecg->kbs, m, ecg->kbs, ts);
+  pa_set_desc(ecg->AV, M, ecg->kbs, m, ecg->kbs, ts);
+  return 0;
+}
+
+/* ------------------------------------------------------------ Orthodir ---- */
+int _preAlps_ECGIterateOdir(preAlps_ECG_t* ecg, int* rci_request) {
+  ecg_priv_t* pv = priv_of(ecg);
+  if (!pv) return PA_FAIL("solver not initialised");
+  int t = ecg->P->info.n;
+  if (*rci_request == 0) {
+    if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
+    if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0)) return 1;
+    if (update_iterate(ecg, pv)) return 1;
+    ecg->iter++;
+    *rci_request = 1;
+  } else if (*rci_request == 1) {
+    if (orthogonalise_z(ecg, pv)) return 1;
+    if (shift_directions(ecg, pv, t)) return 1;
+    *rci_request = 0;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------ Orthomin ---- */
+int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
+  ecg_priv_t* pv = priv_of(ecg);
+  if (!pv) return PA_FAIL("solver not initialised");
+  int M = ecg->globPbSize, m = pv->m, ts = pv->ts, nrhs = ecg->enlFac;
+  int t = ecg->P->info.n;
+  if (*rci_request == 0) {
+    if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
+    if (update_iterate(ecg, pv)) return 1;
+    ecg->iter++;
+    *rci_request = 1;
+  } else if (*rci_request == 1) {
+    if (orthogonalise_z(ecg, pv)) return 1;
+    if (shift_directions(ecg, pv, nrhs)) return 1;
+    if (ecg->bs_red == ADAPT_BS) {
+      /* BF-Omin: G = P^T P -> pivoted Cholesky -> permute, P <- P U^-1 (ecg.c:361-393) */
+      int nb = 0, rank = 0;
+      double t0 = pa_wtime();
+      PA_CHECK(pa_k_gram(m, ts, ecg->P->val, NULL, ecg->P->val, pv->d_partials, &nb));
+      PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, nrhs, 0, nrhs, pv->d_mu, nrhs));
+      ecg->gemm_t += pa_wtime() - t0;
+      t0 = pa_wtime();
+      if (pa_allreduce(pv->d_mu, nrhs * nrhs)) return 1;
+      ecg->comm_t += pa_wtime() - t0;
+      double* hg = pv->h_pin + 16;
+      PA_CHECK(pa_rt_d2h_async(hg, pv->d_mu, (size_t)nrhs * nrhs * sizeof(double)));
+      PA_CHECK(pa_rt_sync());
+      t0 = pa_wtime();
+      pa_sd_pstrf_upper(nrhs, hg, nrhs, ecg->iwork, &rank, -1.0);
+      ecg->pstrf_t += pa_wtime() - t0;
+      t0 = pa_wtime();
+      for (int j = 0; j < nrhs; ++j) pv->h_pin_i[j] = ecg->iwork[j] - 1;
+      PA_CHECK(pa_rt_h2d(pv->d_piv, pv->h_pin_i, nrhs * sizeof(int)));
+      PA_CHECK(pa_k_permute_cols(m, ts, nrhs, pv->d_piv, ecg->P->val));
+      ecg->lapmt_t += pa_wtime() - t0;
+      t0 = pa_wtime();
+      /* leading rank x rank block, leading dimension rank for the kernel */
+      double* hu = hg + (size_t)nrhs * nrhs;
+      for (int j = 0; j < rank; ++j) for (int i = 0; i < rank; ++i) hu[i + (size_t)rank * j] = hg[i + (size_t)nrhs * j];
+      PA_CHECK(pa_rt_h2d(pv->d_q, hu, (size_t)rank * rank * sizeof(double)));
+      PA_CHECK(pa_k_trsm(m, ts, rank, pv->d_q, ecg->P->val, NULL));
+      ecg->trsm_t += pa_wtime() - t0;
+      t = rank;
+      pa_set_desc(ecg->P, M, t, m, t, ts);
+      pa_set_desc(ecg->AP, M, t, m, t, ts);
+      CPLM_MatDenseSetInfo(ecg->alpha, t, nrhs, t, nrhs, COL_MAJOR);
+      CPLM_MatDenseSetInfo(ecg->beta, t, nrhs, t, nrhs, COL_MAJOR);
+      ecg->bs = t;
+    }
+    *rci_request = 0;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------ fused Orthodir ---- */
+int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
+  ecg_priv_t* pv = priv_of(ecg);
+  if (!pv) return PA_FAIL("solver not initialised");
+  int m = pv->m, ts = pv->ts, nrhs = ecg->enlFac, nb = 0;
+  int t = ecg->P->info.n;
+  double t0 = pa_wtime();
+  /* the four local Gram blocks, stacked [alpha | beta | mu | RtR] (ecg.c:554-560) */
+  pa_time_begin(PA_T_GRAM);
+  PA_CHECK(pa_k_gram(m, ts, ecg->P->val, NULL, ecg->R->val, pv->d_partials, &nb));
+  PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, ecg->alpha->info.m, 0, ecg->alpha->info.n, pv->d_alpha, ecg->alpha->info.lda));
+  {
+    int kb = ecg->beta->info.m, a_lo = kb < nrhs ? kb : nrhs, a_hi = kb - a_lo;
+    PA_CHECK(pa_k_gram(m, ts, pv->buf_av[0], a_hi > 0 ? pv->buf_av[1] : NULL, pv->buf_z, pv->d_partials, &nb));
+    PA_CHECK(pa_k_finish(pv->d_partials, nb, a_hi > 0 ? 2 : 1, ts, a_lo, a_hi, ecg->beta->info.n, pv->d_beta, ecg->beta->info.lda));
+  }
+  PA_CHECK(pa_k_gram(m, ts, ecg->AP->val, NULL, ecg->P->val, pv->d_partials, &nb));
+  PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, t, 0, t, pv->d_mu, t));
+  /* R has not changed since the previous call's update: its column norms are
+   * already there, except on the first call */
+  if (!pv->rtr_valid) PA_CHECK(pa_k_colnorm2(m, ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
+  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, ts, nrhs, pv->d_rtr));
+  pa_time_end(PA_T_GRAM);
+  ecg->gemm_t += pa_wtime() - t0;
+  t0 = pa_wtime();
+  if (pa_allreduce(pv->d_F, 5 * nrhs * nrhs)) return 1; /* the single reduction (ecg.c:563) */
+  ecg->comm_t += pa_wtime() - t0;
+  PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->d_rtr, sizeof(double)));
+  PA_CHECK(pa_rt_sync());
+  ecg->res = sqrt(pv->h_pin[0]);
+  if (ecg->res < ecg->tol * ecg->normb || ecg->iter > ecg->maxIter) *rci_request = 1;
+  else *rci_request = 0;
+  t0 = pa_wtime();
+  pa_time_begin(PA_T_SMALL);
+  /* mu = U^T U ; beta <- beta U^-1 ; alpha <- U^-T alpha ; beta(0:t,0:t) <- U^-T beta */
+  PA_CHECK(pa_k_fused_small(pv->d_mu, t, nrhs, ecg->beta->info.m, ecg->beta->info.n, ecg->kbs,
+                            pv->d_alpha, pv->d_beta, pv->d_info));
+  pa_time_end(PA_T_SMALL);
+  ecg->potrf_t += pa_wtime() - t0;
+  t0 = pa_wtime();
+  pa_time_begin(PA_T_TRSM);
+  PA_CHECK(pa_k_trsm(m, ts, t, pv->d_mu, ecg->P->val, ecg->AP->val));
+  PA_CHECK(pa_k_trsm(m, ts, ecg->Z->info.n, pv->d_mu, ecg->Z->val, NULL));
+  pa_time_end(PA_T_TRSM);
+  ecg->trsm_t += pa_wtime() - t0;
+  t0 = pa_wtime();
+  pa_time_begin(PA_T_UPDATE);
+  {
+    int vn = ecg->V->info.n, v_lo = vn < nrhs ? vn : nrhs, v_hi = vn - v_lo;
+    PA_CHECK(pa_k_update_z(m, ts, v_lo, v_hi, ecg->Z->info.n, pv->d_beta, ecg->beta->info.lda,
+                           pv->buf_v[0], pv->buf_v[1], pv->buf_z));
+  }
+  pa_time_end(PA_T_UPDATE);
+  ecg->gemm_t += pa_wtime() - t0;
+  if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 1)) return 1;
+  if (update_iterate(ecg, pv)) return 1;
+  ecg->iter++;
+  return shift_directions(ecg, pv, ecg->bs);
+}
+
+int preAlps_ECGIterate(preAlps_ECG_t* ecg, int* rci_request) {
+  double t0 = pa_wtime();
+  int rc = 0;
+  if (ecg->ortho_alg == ORTHOMIN) rc = _preAlps_ECGIterateOmin(ecg, rci_request);
+  else if (ecg->ortho_alg == ORTHODIR) rc = _preAlps_ECGIterateOdir(ecg, rci_request);
+  else if (ecg->ortho_alg == ORTHODIR_FUSED) rc = _preAlps_ECGIterateOdirFused(ecg, rci_request);
+  ecg->tot_t += pa_wtime() - t0;
+  return rc;
+}
+
+/* ------------------------------------------------------------ wrap up ---- */
+int _preAlps_ECGWrapUp(preAlps_ECG_t* ecg, double* solution) {
+  ecg_priv_t* pv = priv_of(ecg);
+  if (!pv) return PA_FAIL("solver not initialised");
+  /* x = X * ones (ecg.c:674); the partial sums go through the free Z buffer */
+  double* d_sol = pv->d_partials;
+  size_t room = (size_t)pa_gram_max_blocks() * 2 * pv->ts * pv->ts;
+  double* tmp = NULL;
+  if ((size_t)pv->m > room) { tmp = (double*)pa_rt_malloc((size_t)pv->m * sizeof(double)); if (!tmp) return PA_FAIL("%s", pa_rt_error()); d_sol = tmp; }
+  int rc = pa_k_rowsum(pv->m, pv->ts, ecg->X->info.n, pv->d_X, d_sol) ||
+           pa_rt_d2h(solution, d_sol, (size_t)pv->m * sizeof(double));
+  pa_rt_free(tmp);
+  if (rc) return PA_FAIL("%s", pa_rt_error());
+  return 0;
+}
+
+void _preAlps_ECGFree(preAlps_ECG_t* ecg) {
+  ecg_priv_t* pv = priv_of(ecg);
+  if (pv) {
+    pa_rt_sync();
+    pa_rt_free(pv->d_info);
+    pa_rt_host_free(pv->h_pin);
+    pa_rt_host_free(pv->h_pin_i);
+    pv->magic = 0;
+  }
+  free(ecg->X); free(ecg->R); free(ecg->V); free(ecg->AV); free(ecg->alpha); free(ecg->beta);
+  free(ecg->Z); free(ecg->P); free(ecg->AP);
+  ecg->X = ecg->R = ecg->V = ecg->AV = ecg->alpha = ecg->beta = ecg->Z = ecg->P = ecg->AP = NULL;
+  pa_rt_free(ecg->work); ecg->work = NULL;
+  free(ecg->iwork); ecg->iwork = NULL;
+}
+
+int preAlps_ECGFinalize(preAlps_ECG_t* ecg, double* solution) {
+  int rc = _preAlps_ECGWrapUp(ecg, solution);
+  _preAlps_ECGFree(ecg);
+  return rc;
+}
+
+void preAlps_ECGPrint(preAlps_ECG_t* ecg, int verbosity) {
+  int rank = pa_world_rank();
+  printf("[%d] prints ECG_t...\n", rank);
+  printf("=== Summary ===\n");
+  printf("\titer: %d\n\tres : %e\n\tbs  : %1d\n", ecg->iter, ecg->res, ecg->bs);
+  printf("=== Timings ===\n");
+  printf("\ttot_t  : %e s\n", ecg->tot_t);
+  printf("\tcomm_t : %e s\n", ecg->comm_t);
+  printf("\ttrsm_t : %e s\n", ecg->trsm_t);
+  printf("\tgemm_t : %e s\n", ecg->gemm_t);
+  printf("\tpotrf_t: %e s\n", ecg->potrf_t);
+  printf("\tpstrf_t: %e s\n", ecg->pstrf_t);
+  printf("\tlapmt_t: %e s\n", ecg->lapmt_t);
+  printf("\tgesvd_t: %e s\n", ecg->gesvd_t);
+  printf("\tgeqrf_t: %e s\n", ecg->geqrf_t);
+  printf("\tormqr_t: %e s\n", ecg->ormqr_t);
+  printf("\tcopy_t : %e s\n", ecg->copy_t);
+  if (verbosity > 1 && ecg->X) {
+    const char* names[9] = {"X", "R", "V", "AV", "P", "AP", "Z", "alpha", "beta"};
+    CPLM_Mat_Dense_t* d[9] = {ecg->X, ecg->R, ecg->V, ecg->AV, ecg->P, ecg->AP, ecg->Z, ecg->alpha, ecg->beta};
+    printf("=== Memory consumption ===\n");
+    for (int i = 0; i < 9; ++i)
+      printf("%s\n\tM=%d N=%d m=%d n=%d lda=%d nval=%d (HBM, %s)\n", names[i], d[i]->info.M, d[i]->info.N,
+             d[i]->info.m, d[i]->info.n, d[i]->info.lda, d[i]->info.nval,
+             d[i]->info.stor_type == ROW_MAJOR ? "row-interleaved" : "column major");
+    printf("\n");
+  }
+  printf("[%d] ends printing ECG_t!\n", rank);
+}
+
+/* The driver loop of examples/test_ecg_prealps_op.c:203-223 (fused:
+ * examples/test_ecg_bench_fused.c:243-259). */
+int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_hist, int* bs_hist,
+                     int max_hist, int* n_hist) {
+  int rci = 0, stop = 0, nh = 0;
+  if (preAlps_ECGInitialize(ecg, rhs, &rci)) return 1;
+  if (preAlps_BlockJacobiApply(ecg->R, ecg->P)) return 1;
+  if (ecg->ortho_alg != ORTHODIR_FUSED) {
+    if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+    while (stop != 1) {
+      if (preAlps_ECGIterate(ecg, &rci)) return 1;
+      if (rci == 0) {
+        if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+      } else if (rci == 1) {
+        if (preAlps_ECGStoppingCriterion(ecg, &stop)) return 1;
+        if (res_hist && nh < max_hist) { res_hist[nh] = ecg->res; if (bs_hist) bs_hist[nh] = ecg->bs; }
+        ++nh;
+        if (stop == 1) break;
+        if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
+        else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+      }
+    }
+  } else {
+    while (rci != 1) {
+      if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+      if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+      if (preAlps_ECGIterate(ecg, &rci)) return 1;
+      if (res_hist && nh < max_hist) { res_hist[nh] = ecg->res; if (bs_hist) bs_hist[nh] = ecg->bs; }
+      ++nh;
+    }
+  }
+  if (n_hist) *n_hist = nh < max_hist ? nh : max_hist;
+  if (sol) return preAlps_ECGFinalize(ecg, sol);
+  return 0;
+}

@@ -1,0 +1,835 @@
+// kernels.hip -- CDNA4 (gfx950) kernels of the ECG block iteration and their
+// C launchers (pa_device.h).  All panels are row-interleaved [rows][TS] fp64,
+// all small t x t blocks column-major like the reference's work area.
+//
+// Every kernel here is HBM-bandwidth bound (SpMM: 0.67 flop/B at t = 4; the
+// tall-skinny kernels t/8..t/4 flop/B against a ridge of ~10 flop/B), so the
+// design rules are coalesced 16-B accesses, LDS staging where rows are reused,
+// 64-wide shuffle reductions, and XCD-aware block order for the SpMM gathers.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include "pa_device.h"
+
+namespace {
+
+constexpr int WG = 256;           // 4 wavefronts of 64
+constexpr int GRAM_MAX_BLOCKS = 512;
+
+inline hipStream_t cur_stream() { return (hipStream_t)pa_rt_stream(); }
+
+char g_kerr[256];
+int kfail(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  snprintf(g_kerr, sizeof(g_kerr), "%s: %s", what, hipGetErrorString(e));
+  fprintf(stderr, "[prealps_hip] kernel launch failed: %s\n", g_kerr);
+  return 1;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Load / store one panel row of TS doubles with 16-byte accesses.
+template <int TS>
+__device__ __forceinline__ void load_row(const double* __restrict__ p, size_t row, double (&r)[TS]) {
+  const double2* q = reinterpret_cast<const double2*>(p + row * TS);
+#pragma unroll
+  for (int i = 0; i < TS / 2; ++i) {
+    double2 v = q[i];
+    r[2 * i] = v.x;
+    r[2 * i + 1] = v.y;
+  }
+}
+template <int TS>
+__device__ __forceinline__ void store_row(double* __restrict__ p, size_t row, const double (&r)[TS]) {
+  double2* q = reinterpret_cast<double2*>(p + row * TS);
+#pragma unroll
+  for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(r[2 * i], r[2 * i + 1]);
+}
+
+// ---------------------------------------------------------------- SpMM ----
+// One workgroup per row block.  The block's slice of val/colind is streamed
+// into LDS with coalesced 16-B loads (the dominant HBM traffic: 12 B per
+// nonzero), the block's window of X rows is staged next to it, and each row
+// is then reduced by G lanes per panel column out of LDS; columns outside the
+// window (neighbouring parts, halo rows) are gathered from L2/HBM.
+template <int TS, int G>
+__global__ __launch_bounds__(WG) void k_spmm(
+    int m, const int* __restrict__ rowptr, const int* __restrict__ colind,
+    const double* __restrict__ val, const int* __restrict__ blk_row,
+    const int* __restrict__ blk_win, const int* __restrict__ order, int nlist, int nnz_cap,
+    int win_cap, const double* __restrict__ X, const double* __restrict__ Xh,
+    double* __restrict__ Y) {
+  extern __shared__ double smem[];
+  // XCD-aware order: consecutive logical blocks (which share X rows) run on one XCD.
+  const int cpx = (nlist + 7) >> 3;
+  const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  if (logical >= nlist) return;
+  const int b = order[logical];
+  const int r0 = blk_row[b], r1 = blk_row[b + 1];
+  const int w0 = blk_win[2 * b];
+  const int wlen = min(blk_win[2 * b + 1] - w0, win_cap);
+  const int k0 = rowptr[r0], k1 = rowptr[r1];
+  const int kv0 = k0 & ~1, kc0 = k0 & ~3;
+  double* sval = smem;                          // nnz_cap + 2
+  double* sx = smem + (nnz_cap + 2);            // win_cap * TS
+  int* scol = reinterpret_cast<int*>(sx + (size_t)win_cap * TS);  // nnz_cap + 8
+  const int tid = threadIdx.x;
+  {
+    const double2* src = reinterpret_cast<const double2*>(val + kv0);
+    const int n2 = (k1 - kv0 + 1) >> 1;
+    for (int i = tid; i < n2; i += WG) reinterpret_cast<double2*>(sval)[i] = src[i];
+    const int4* csrc = reinterpret_cast<const int4*>(colind + kc0);
+    const int n4 = (k1 - kc0 + 3) >> 2;
+    for (int i = tid; i < n4; i += WG) reinterpret_cast<int4*>(scol)[i] = csrc[i];
+    const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)w0 * TS);
+    const int nx2 = (wlen * TS) >> 1;
+    for (int i = tid; i < nx2; i += WG) reinterpret_cast<double2*>(sx)[i] = xsrc[i];
+  }
+  __syncthreads();
+  constexpr int LPR = TS * G;      // lanes per row
+  constexpr int RPP = WG / LPR;    // rows per pass
+  const int lr = tid / LPR, li = tid % LPR, g = li / TS, c = li % TS;
+  for (int rowb = r0; rowb < r1; rowb += RPP) {
+    const int row = rowb + lr;
+    double acc = 0.0;
+    if (row < r1) {
+      const int ks = rowptr[row], ke = rowptr[row + 1];
+      for (int k = ks + g; k < ke; k += G) {
+        const double v = sval[k - kv0];
+        const int col = scol[k - kc0];
+        const unsigned wi = (unsigned)(col - w0);
+        double x;
+        if (wi < (unsigned)wlen) x = sx[wi * TS + c];
+        else if (col < m) x = X[(size_t)col * TS + c];
+        else x = Xh[(size_t)(col - m) * TS + c];
+        acc = fma(v, x, acc);
+      }
+    }
+    if (G > 1) {
+#pragma unroll
+      for (int off = TS; off < LPR; off <<= 1) acc += __shfl_xor(acc, off);
+    }
+    if (row < r1 && g == 0) Y[(size_t)row * TS + c] = acc;
+  }
+}
+
+template <int TS>
+__global__ __launch_bounds__(WG) void k_pack_rows(int n, const int* __restrict__ idx,
+                                                  const double* __restrict__ X,
+                                                  double* __restrict__ out) {
+  const int i = (blockIdx.x * WG + threadIdx.x) / TS, c = threadIdx.x % TS;
+  if (i < n) out[(size_t)i * TS + c] = X[(size_t)idx[i] * TS + c];
+}
+
+// ---------------------------------------------------------------- Gram ----
+// C = [A0 | A1]^T B over the local rows.  Each lane owns a TI x TI tile of C
+// for a strided set of rows; NPAN*(TS/TI)^2 lanes cover one row.  Lanes are
+// then folded with wavefront shuffles (64 wide), waves through LDS, and each
+// workgroup writes one partial block (summed by k_finish in a fixed order, so
+// results are bitwise reproducible).
+template <int TS, int NPAN>
+__global__ __launch_bounds__(WG) void k_gram(int m, const double* __restrict__ A0,
+                                             const double* __restrict__ A1,
+                                             const double* __restrict__ B,
+                                             double* __restrict__ partials) {
+  constexpr int TI = TS < 4 ? TS : 4;
+  constexpr int TD = TS / TI;
+  constexpr int LPR = NPAN * TD * TD;
+  constexpr int LDP = NPAN * TS;
+  const int tid = threadIdx.x;
+  const int li = tid % LPR;
+  const int pan = li / (TD * TD), ti = (li / TD) % TD, tj = li % TD;
+  const double* __restrict__ A = (pan == 0) ? A0 : A1;
+  double acc[TI][TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j) acc[i][j] = 0.0;
+  const size_t rstride = (size_t)gridDim.x * WG / LPR;
+  for (size_t row = ((size_t)blockIdx.x * WG + tid) / LPR; row < (size_t)m; row += rstride) {
+    double a[TI], b[TI];
+    const double2* ap = reinterpret_cast<const double2*>(A + row * TS + ti * TI);
+    const double2* bp = reinterpret_cast<const double2*>(B + row * TS + tj * TI);
+#pragma unroll
+    for (int i = 0; i < TI / 2; ++i) {
+      double2 va = ap[i], vb = bp[i];
+      a[2 * i] = va.x; a[2 * i + 1] = va.y;
+      b[2 * i] = vb.x; b[2 * i + 1] = vb.y;
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TI; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+  }
+  // fold the 64/LPR row groups of the wave
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TI; ++j) acc[i][j] += __shfl_xor(acc[i][j], off);
+  __shared__ double red[WG / 64][LDP * TS];
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane < LPR) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TI; ++j)
+        red[wave][(pan * TS + ti * TI + i) + LDP * (tj * TI + j)] = acc[i][j];
+  }
+  __syncthreads();
+  for (int e = tid; e < LDP * TS; e += WG) {
+    double s = red[0][e];
+#pragma unroll
+    for (int w = 1; w < WG / 64; ++w) s += red[w][e];
+    partials[(size_t)blockIdx.x * (LDP * TS) + e] = s;
+  }
+}
+
+// Sum the per-workgroup partial blocks (fixed order) and scatter the active
+// sub-block into the reference's t x t layout.
+__global__ __launch_bounds__(WG) void k_finish(const double* __restrict__ partials, int nblk,
+                                               int npan, int ts, int a_lo, int a_hi, int nb,
+                                               double* __restrict__ out, int ld_out) {
+  __shared__ double red[WG];
+  const int ldp = npan * ts;
+  const int na = a_lo + a_hi;
+  const int ne = na * nb;
+  int ner = 1;
+  while (ner < ne && ner < WG) ner <<= 1;
+  const int nsl = WG / ner;
+  const int tid = threadIdx.x;
+  const int e0 = tid % ner, s = tid / ner;
+  for (int base = 0; base < ne; base += ner) {
+    const int e = base + e0;
+    double sum = 0.0;
+    int i = 0, j = 0;
+    if (e < ne) {
+      i = e % na; j = e / na;
+      const int src = (i < a_lo ? i : ts + (i - a_lo)) + ldp * j;
+      for (int b = s; b < nblk; b += nsl) sum += partials[(size_t)b * (ldp * ts) + src];
+    }
+    red[tid] = sum;
+    __syncthreads();
+    if (s == 0 && e < ne) {
+      double tot = 0.0;
+      for (int q = 0; q < nsl; ++q) tot += red[q * ner + e0];
+      out[i + ld_out * j] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+// t x t upper Cholesky, one lane (t <= 16).  LAPACK dpotf2 'U': on failure
+// the failing pivot is stored and the rest of W is left untouched.
+__global__ void k_potrf(double* __restrict__ W, int t, int* __restrict__ info) {
+  if (threadIdx.x != 0) return;
+  int fail = 0;
+  for (int j = 0; j < t; ++j) {
+    double d = W[j + t * j];
+    for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
+    if (!(d > 0.0)) { W[j + t * j] = d; fail = j + 1; break; }
+    d = sqrt(d);
+    W[j + t * j] = d;
+    for (int i = j + 1; i < t; ++i) {
+      double s = W[j + t * i];
+      for (int k = 0; k < j; ++k) s -= W[k + t * j] * W[k + t * i];
+      W[j + t * i] = s / d;
+    }
+  }
+  *info = fail;
+}
+
+
+// Small t x t work of the fused Orthodir step (ecg.c:577-587), one lane:
+// mu = U^T U ; beta <- beta U^-1 (bm x bn) ; alpha <- U^-T alpha (t x nrhs) ;
+// beta(0:t, 0:t) <- U^-T beta(0:t, 0:t).
+__global__ void k_fused_small(double* __restrict__ mu, int t, int nrhs, int bm, int bn, int ldb,
+                              double* __restrict__ alpha, double* __restrict__ beta,
+                              int* __restrict__ info) {
+  if (threadIdx.x != 0) return;
+  int fail = 0;
+  for (int j = 0; j < t; ++j) {
+    double d = mu[j + t * j];
+    for (int k = 0; k < j; ++k) d -= mu[k + t * j] * mu[k + t * j];
+    if (!(d > 0.0)) { mu[j + t * j] = d; fail = j + 1; break; }
+    d = sqrt(d);
+    mu[j + t * j] = d;
+    for (int i = j + 1; i < t; ++i) {
+      double s = mu[j + t * i];
+      for (int k = 0; k < j; ++k) s -= mu[k + t * j] * mu[k + t * i];
+      mu[j + t * i] = s / d;
+    }
+  }
+  *info = fail;
+  for (int j = 0; j < bn && j < t; ++j) {      // beta <- beta U^-1
+    for (int k = 0; k < j; ++k) {
+      const double u = mu[k + t * j];
+      for (int i = 0; i < bm; ++i) beta[i + ldb * j] -= beta[i + ldb * k] * u;
+    }
+    const double d = 1.0 / mu[j + t * j];
+    for (int i = 0; i < bm; ++i) beta[i + ldb * j] *= d;
+  }
+  for (int c = 0; c < nrhs; ++c)                 // alpha <- U^-T alpha
+    for (int i = 0; i < t; ++i) {
+      double s = alpha[i + t * c];
+      for (int k = 0; k < i; ++k) s -= mu[k + t * i] * alpha[k + t * c];
+      alpha[i + t * c] = s / mu[i + t * i];
+    }
+  for (int c = 0; c < t; ++c)                    // beta(0:t,0:t) <- U^-T beta(0:t,0:t)
+    for (int i = 0; i < t; ++i) {
+      double s = beta[i + ldb * c];
+      for (int k = 0; k < i; ++k) s -= mu[k + t * i] * beta[k + ldb * c];
+      beta[i + ldb * c] = s / mu[i + t * i];
+    }
+}
+
+// -------------------------------------------------------------- updates ----
+// P <- P U^-1 (and AP) by forward substitution along each row, one row/lane.
+template <int TS>
+__global__ __launch_bounds__(WG) void k_trsm(int m, int t, const double* __restrict__ U,
+                                             double* __restrict__ P, double* __restrict__ AP) {
+  __shared__ double su[TS * TS];
+  __shared__ double sd[TS];
+  for (int e = threadIdx.x; e < t * t; e += WG) su[e] = U[e];
+  __syncthreads();
+  if (threadIdx.x < t) sd[threadIdx.x] = 1.0 / su[threadIdx.x + t * threadIdx.x];
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double p[TS];
+    load_row<TS>(P, row, p);
+#pragma unroll
+    for (int j = 0; j < TS; ++j) {
+      if (j < t) {
+        double s = p[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = fma(-p[k], su[k + t * j], s);
+        p[j] = s * sd[j];
+      }
+    }
+    store_row<TS>(P, row, p);
+    if (AP) {
+      load_row<TS>(AP, row, p);
+#pragma unroll
+      for (int j = 0; j < TS; ++j) {
+        if (j < t) {
+          double s = p[j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) s = fma(-p[k], su[k + t * j], s);
+          p[j] = s * sd[j];
+        }
+      }
+      store_row<TS>(AP, row, p);
+    }
+  }
+}
+
+template <int TS>
+__device__ __forceinline__ void block_sum_cols(double (&v)[TS], double* __restrict__ out) {
+  __shared__ double red[WG / 64][TS];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+#pragma unroll
+    for (int c = 0; c < TS; ++c) v[c] += __shfl_xor(v[c], off);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < TS; ++c) red[wave][c] = v[c];
+  __syncthreads();
+  if (threadIdx.x < TS) {
+    double s = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < WG / 64; ++w) s += red[w][threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+
+// X += P alpha, R -= AP alpha, plus per-workgroup sums of R(:,c)^2.
+template <int TS>
+__global__ __launch_bounds__(WG) void k_update_xr(int m, int t, int nc,
+                                                  const double* __restrict__ alpha,
+                                                  const double* __restrict__ P,
+                                                  const double* __restrict__ AP,
+                                                  double* __restrict__ X, double* __restrict__ R,
+                                                  double* __restrict__ rtr) {
+  __shared__ double sa[TS * TS];
+  for (int e = threadIdx.x; e < t * nc; e += WG) sa[e] = alpha[e];
+  __syncthreads();
+  double rr[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) rr[c] = 0.0;
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double p[TS], ap[TS], x[TS], r[TS];
+    load_row<TS>(P, row, p);
+    load_row<TS>(AP, row, ap);
+    load_row<TS>(X, row, x);
+    load_row<TS>(R, row, r);
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      if (c < nc) {
+        double sx = 0.0, sr = 0.0;
+#pragma unroll
+        for (int k = 0; k < TS; ++k) {
+          if (k < t) {
+            const double a = sa[k + t * c];
+            sx = fma(p[k], a, sx);
+            sr = fma(ap[k], a, sr);
+          }
+        }
+        x[c] += sx;
+        r[c] -= sr;
+        rr[c] = fma(r[c], r[c], rr[c]);
+      }
+    }
+    store_row<TS>(X, row, x);
+    store_row<TS>(R, row, r);
+  }
+  block_sum_cols<TS>(rr, rtr + (size_t)blockIdx.x * TS);
+}
+
+template <int TS>
+__global__ __launch_bounds__(WG) void k_colnorm2(int m, const double* __restrict__ R,
+                                                 double* __restrict__ rtr) {
+  double rr[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) rr[c] = 0.0;
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double r[TS];
+    load_row<TS>(R, row, r);
+#pragma unroll
+    for (int c = 0; c < TS; ++c) rr[c] = fma(r[c], r[c], rr[c]);
+  }
+  block_sum_cols<TS>(rr, rtr + (size_t)blockIdx.x * TS);
+}
+
+__global__ __launch_bounds__(WG) void k_trace_finish(const double* __restrict__ rtr, int nblk,
+                                                     int ts, int nc, double* __restrict__ res2) {
+  __shared__ double red[WG];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += WG)
+    for (int c = 0; c < nc; ++c) s += rtr[(size_t)b * ts + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = WG / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) res2[0] = red[0];
+}
+
+// Z(:, :nc) -= [V0(:, :a_lo) | V1(:, :a_hi)] beta
+template <int TS>
+__global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int nc,
+                                                 const double* __restrict__ beta, int ldb,
+                                                 const double* __restrict__ V0,
+                                                 const double* __restrict__ V1,
+                                                 double* __restrict__ Z) {
+  __shared__ double sb[2 * TS * TS];
+  const int na = a_lo + a_hi;
+  for (int e = threadIdx.x; e < na * nc; e += WG) sb[e] = beta[(e % na) + ldb * (e / na)];
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double z[TS], v0[TS], v1[TS];
+    load_row<TS>(Z, row, z);
+    load_row<TS>(V0, row, v0);
+    if (a_hi > 0) load_row<TS>(V1, row, v1);
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      if (c < nc) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < TS; ++k)
+          if (k < a_lo) s = fma(v0[k], sb[k + na * c], s);
+        if (a_hi > 0) {
+#pragma unroll
+          for (int k = 0; k < TS; ++k)
+            if (k < a_hi) s = fma(v1[k], sb[a_lo + k + na * c], s);
+        }
+        z[c] -= s;
+      }
+    }
+    store_row<TS>(Z, row, z);
+  }
+}
+
+template <int TS>
+__global__ __launch_bounds__(WG) void k_copy_cols(int m, int nc, const double* __restrict__ src,
+                                                  double* __restrict__ dst) {
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double s[TS], d[TS];
+    load_row<TS>(src, row, s);
+    load_row<TS>(dst, row, d);
+#pragma unroll
+    for (int c = 0; c < TS; ++c) if (c < nc) d[c] = s[c];
+    store_row<TS>(dst, row, d);
+  }
+}
+
+template <int TS>
+__global__ __launch_bounds__(WG) void k_right_mult(int m, int t, const double* __restrict__ Q,
+                                                   double* __restrict__ A) {
+  __shared__ double sq[TS * TS];
+  for (int e = threadIdx.x; e < t * t; e += WG) sq[e] = Q[e];
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double a[TS], o[TS];
+    load_row<TS>(A, row, a);
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      o[c] = a[c];
+      if (c < t) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < TS; ++k) if (k < t) s = fma(a[k], sq[k + t * c], s);
+        o[c] = s;
+      }
+    }
+    store_row<TS>(A, row, o);
+  }
+}
+
+template <int TS>
+__global__ __launch_bounds__(WG) void k_permute_cols(int m, int n, const int* __restrict__ piv,
+                                                     double* __restrict__ A) {
+  __shared__ int sp[TS];
+  if (threadIdx.x < n) sp[threadIdx.x] = piv[threadIdx.x];
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double a[TS], o[TS];
+    load_row<TS>(A, row, a);
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      o[c] = a[c];
+      if (c < n) {
+        const int s = sp[c];
+        double v = a[0];
+#pragma unroll
+        for (int k = 1; k < TS; ++k) v = (s == k) ? a[k] : v;
+        o[c] = v;
+      }
+    }
+    store_row<TS>(A, row, o);
+  }
+}
+
+template <int TS>
+__global__ __launch_bounds__(WG) void k_rowsum(int m, int nc, const double* __restrict__ X,
+                                               double* __restrict__ sol) {
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double x[TS];
+    load_row<TS>(X, row, x);
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < TS; ++c) if (c < nc) s += x[c];
+    sol[row] = s;
+  }
+}
+
+// -------------------------------------------------------- block-Jacobi ----
+// Exact solve with one SPD diagonal block per wavefront: banded Cholesky
+// factor (RCM order, factored at setup) applied as two systolic sweeps.  The
+// W = 64*R rows in flight live in registers, row (j mod W) in lane (j mod 64)
+// of register set (j/64 mod R); at step j the pivot y_j is broadcast with
+// v_readlane and every lane updates the rows j+1..j+w it holds with one
+// coalesced read of column j of the band.  Four blocks per workgroup (one per
+// wave), no LDS, no inter-wave traffic.
+template <int TS, int R>
+__device__ __forceinline__ void bj_sweep(int b, int w, const double* __restrict__ F,
+                                         const double* __restrict__ invd,
+                                         const int* __restrict__ iomap, size_t rowbase,
+                                         const double* __restrict__ src,
+                                         double* __restrict__ dst, int lane) {
+  constexpr int W = 64 * R;
+  double acc[R][TS];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int j = k * 64 + lane;
+    if (j < b) load_row<TS>(src, rowbase + iomap[j], acc[k]);
+    else
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
+  }
+  for (int jb = 0; jb < b; jb += W) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int j0 = jb + k * 64;
+      if (j0 < b) {
+        double nxt[TS];
+        const int jn = j0 + W + lane;
+        if (jn < b) load_row<TS>(src, rowbase + iomap[jn], nxt);
+        else
+#pragma unroll
+          for (int c = 0; c < TS; ++c) nxt[c] = 0.0;
+        const int lim = (b - j0) < 64 ? (b - j0) : 64;
+        for (int l = 0; l < lim; ++l) {
+          const int j = j0 + l;
+          const double idg = invd[j];
+          double y[TS];
+#pragma unroll
+          for (int c = 0; c < TS; ++c) y[c] = readlane_f64(acc[k][c], l) * idg;
+          if (lane == 0) store_row<TS>(dst, rowbase + iomap[j], y);
+          const double* __restrict__ col = F + (size_t)j * w - 1;
+#pragma unroll
+          for (int k2 = 0; k2 < R; ++k2) {
+            int d = (k2 - k) * 64 + lane - l;
+            d = d < 0 ? d + W : d;
+            if (d >= 1 && d <= w) {
+              const double lv = col[d];
+#pragma unroll
+              for (int c = 0; c < TS; ++c) acc[k2][c] = fma(-lv, y[c], acc[k2][c]);
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < TS; ++c) acc[k][c] = nxt[c];
+      }
+    }
+  }
+}
+
+template <int TS, int R>
+__global__ __launch_bounds__(WG) void k_bj_apply(
+    const int* __restrict__ list, int count, const int* __restrict__ row0,
+    const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off,
+    const int* __restrict__ map_f, const int* __restrict__ map_b, const double* __restrict__ Lf,
+    const double* __restrict__ Lb, const double* __restrict__ invd_f,
+    const double* __restrict__ invd_b, const double* __restrict__ in, double* __restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pi = blockIdx.x * (WG / 64) + wave;
+  if (pi >= count) return;
+  const int p = list[pi];
+  const int r0 = row0[p], b = nrows[p], w = bw[p];
+  const size_t o = (size_t)off[p];
+  // forward: L y = x (y goes to `out`), backward: L^T z = y in place
+  bj_sweep<TS, R>(b, w, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in, out, lane);
+  __threadfence_block();
+  bj_sweep<TS, R>(b, w, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, lane);
+}
+
+inline int grid_rows(int m, int per_thread_rows = 1) {
+  long long blocks = ((long long)m + (long long)WG * per_thread_rows - 1) / ((long long)WG * per_thread_rows);
+  if (blocks < 1) blocks = 1;
+  const long long cap = 2048;
+  return (int)(blocks < cap ? blocks : cap);
+}
+
+}  // namespace
+
+#define TS_DISPATCH(ts, CALL)                      \
+  switch (ts) {                                    \
+    case 2: { constexpr int TS_ = 2; CALL; } break;   \
+    case 4: { constexpr int TS_ = 4; CALL; } break;   \
+    case 8: { constexpr int TS_ = 8; CALL; } break;   \
+    case 16: { constexpr int TS_ = 16; CALL; } break; \
+    default: snprintf(g_kerr, sizeof(g_kerr), "unsupported panel stride %d", ts); return 1; \
+  }
+
+template <int TS, int G>
+static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, const double* X,
+                       const double* Xh, double* Y) {
+  if (nlist <= 0) return 0;
+  // the X window shares the 160 KiB LDS with the matrix slice: at most 32 KiB of rows
+  int win_cap = pl->win_cap;
+  if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
+  const size_t lds = (size_t)(pl->nnz_cap + 2) * 8 + (size_t)win_cap * TS * 8 +
+                     (size_t)(pl->nnz_cap + 8) * 4;
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm<TS, G>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return kfail("hipFuncSetAttribute(k_spmm)");
+    configured = lds;
+  }
+  const int cpx = (nlist + 7) / 8;
+  hipLaunchKernelGGL((k_spmm<TS, G>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m,
+                     pl->rowptr, pl->colind, pl->val, pl->blk_row, pl->blk_win, order, nlist,
+                     pl->nnz_cap, win_cap, X, Xh, Y);
+  return kfail("k_spmm");
+}
+
+template <int TS>
+static int spmm_g(const pa_spmm_plan_t* pl, const int* order, int nlist, const double* X,
+                  const double* Xh, double* Y) {
+  int lg = pl->lanes_per_row_log2;
+  while ((TS << lg) > 64) --lg;
+  switch (lg) {
+    case 0: return launch_spmm<TS, 1>(pl, order, nlist, X, Xh, Y);
+    case 1: return launch_spmm<TS, 2>(pl, order, nlist, X, Xh, Y);
+    case 2: return launch_spmm<TS, 4>(pl, order, nlist, X, Xh, Y);
+    case 3: return launch_spmm<TS, 8>(pl, order, nlist, X, Xh, Y);
+    default: return launch_spmm<TS, 16>(pl, order, nlist, X, Xh, Y);
+  }
+}
+
+template <int TS>
+static int bj_launch(const pa_bj_plan_t* pl, int R, const int* list, int count, const double* in,
+                     double* out) {
+  const int blocks = (count + WG / 64 - 1) / (WG / 64);
+#define BJ_CASE(RR)                                                                              \
+  case RR:                                                                                       \
+    hipLaunchKernelGGL((k_bj_apply<TS, RR>), dim3(blocks), dim3(WG), 0, cur_stream(), list,      \
+                       count, pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b,        \
+                       pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, in, out);                         \
+    break;
+  switch (R) {
+    BJ_CASE(1) BJ_CASE(2) BJ_CASE(3) BJ_CASE(4) BJ_CASE(5) BJ_CASE(6) BJ_CASE(7) BJ_CASE(8)
+    default:
+      snprintf(g_kerr, sizeof(g_kerr), "block-Jacobi bandwidth class R=%d unsupported", R);
+      return 1;
+  }
+#undef BJ_CASE
+  return kfail("k_bj_apply");
+}
+
+extern "C" {
+
+int pa_bj_max_R(void) { return 8; }
+int pa_gram_max_blocks(void) { return GRAM_MAX_BLOCKS; }
+
+int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo, double* Y,
+              int phase) {
+  const int* order = pl->order;
+  int n = pl->nblk;
+  if (phase == 0) n = pl->n_interior;
+  else if (phase == 1) { order += pl->n_interior; n = pl->nblk - pl->n_interior; }
+  const double* Xh = Xhalo ? Xhalo : X;
+  TS_DISPATCH(ts, return spmm_g<TS_>(pl, order, n, X, Xh, Y));
+  return 0;
+}
+
+int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendbuf) {
+  if (n <= 0) return 0;
+  const int blocks = (int)(((long long)n * ts + WG - 1) / WG);
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_pack_rows<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), n,
+                                     idx, X, sendbuf));
+  return kfail("k_pack_rows");
+}
+
+int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B, double* partials,
+              int* nblk) {
+  int blocks = grid_rows(m, 4);
+  if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
+  *nblk = blocks;
+  if (A1) {
+    TS_DISPATCH(ts, hipLaunchKernelGGL((k_gram<TS_, 2>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+                                       A0, A1, B, partials));
+  } else {
+    TS_DISPATCH(ts, hipLaunchKernelGGL((k_gram<TS_, 1>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+                                       A0, A1, B, partials));
+  }
+  return kfail("k_gram");
+}
+
+int pa_k_finish(const double* partials, int nblk, int npan, int ts, int a_lo, int a_hi, int nb,
+                double* out, int ld_out) {
+  if ((a_lo + a_hi) * nb <= 0) return 0;
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(WG), 0, cur_stream(), partials, nblk, npan, ts, a_lo,
+                     a_hi, nb, out, ld_out);
+  return kfail("k_finish");
+}
+
+int pa_k_potrf(double* W, int t, int* info) {
+  hipLaunchKernelGGL(k_potrf, dim3(1), dim3(64), 0, cur_stream(), W, t, info);
+  return kfail("k_potrf");
+}
+
+int pa_k_fused_small(double* mu, int t, int nrhs, int bm, int bn, int ldb, double* alpha,
+                     double* beta, int* info) {
+  hipLaunchKernelGGL(k_fused_small, dim3(1), dim3(64), 0, cur_stream(), mu, t, nrhs, bm, bn, ldb,
+                     alpha, beta, info);
+  return kfail("k_fused_small");
+}
+
+int pa_k_trsm(int m, int ts, int t, const double* U, double* P, double* AP) {
+  if (t <= 0) return 0;
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_trsm<TS_>), dim3(grid_rows(m)), dim3(WG), 0, cur_stream(),
+                                     m, t, U, P, AP));
+  return kfail("k_trsm");
+}
+
+int pa_k_update_xr(int m, int ts, int t, int nc, const double* alpha, const double* P,
+                   const double* AP, double* X, double* R, double* rtr_partials, int* nblk) {
+  int blocks = grid_rows(m, 2);
+  if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
+  *nblk = blocks;
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_update_xr<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+                                     t, nc, alpha, P, AP, X, R, rtr_partials));
+  return kfail("k_update_xr");
+}
+
+int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk) {
+  int blocks = grid_rows(m, 4);
+  if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
+  *nblk = blocks;
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_colnorm2<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+                                     R, rtr_partials));
+  return kfail("k_colnorm2");
+}
+
+int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2) {
+  hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, nblk, ts, nc,
+                     res2);
+  return kfail("k_trace_finish");
+}
+
+int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
+                  const double* V0, const double* V1, double* Z) {
+  if (nc <= 0) return 0;
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+                                     cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z));
+  return kfail("k_update_z");
+}
+
+int pa_k_copy_cols(int m, int ts, int nc, const double* src, double* dst) {
+  if (nc <= 0) return 0;
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_copy_cols<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+                                     cur_stream(), m, nc, src, dst));
+  return kfail("k_copy_cols");
+}
+
+int pa_k_right_mult(int m, int ts, int t, const double* Q, double* A) {
+  if (t <= 0) return 0;
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_right_mult<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+                                     cur_stream(), m, t, Q, A));
+  return kfail("k_right_mult");
+}
+
+int pa_k_permute_cols(int m, int ts, int n, const int* piv, double* A) {
+  if (n <= 0) return 0;
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_permute_cols<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+                                     cur_stream(), m, n, piv, A));
+  return kfail("k_permute_cols");
+}
+
+int pa_k_rowsum(int m, int ts, int nc, const double* X, double* sol) {
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_rowsum<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+                                     cur_stream(), m, nc, X, sol));
+  return kfail("k_rowsum");
+}
+
+int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out) {
+  for (int c = 0; c < pl->nclass; ++c) {
+    if (pl->class_count[c] <= 0) continue;
+    int rc = 1;
+    TS_DISPATCH(ts, rc = bj_launch<TS_>(pl, pl->class_R[c], pl->class_list[c], pl->class_count[c],
+                                        in, out));
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

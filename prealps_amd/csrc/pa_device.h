@@ -1,0 +1,125 @@
+/*
+ * pa_device.h -- the thin C-ABI shim between the C host code (ecg.c,
+ * operator.c, block_jacobi.c) and the HIP side (runtime.hip, kernels.hip).
+ * Host code never includes a HIP header; device code never sees a preAlps
+ * struct.  Panels are row-interleaved: element (i, j) at p[i * ts + j].
+ */
+#ifndef PA_DEVICE_H
+#define PA_DEVICE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime (runtime.hip) --------------------------------------------- */
+int pa_rt_init(int device);
+void pa_rt_shutdown(void);
+int pa_rt_ready(void);
+void pa_rt_set_stream(void* s);
+void* pa_rt_stream(void);
+int pa_rt_sync(void);
+const char* pa_rt_error(void);
+void* pa_rt_malloc(size_t bytes);
+void pa_rt_free(void* d);
+void* pa_rt_host_alloc(size_t bytes);
+void pa_rt_host_free(void* h);
+int pa_rt_memset(void* d, int v, size_t bytes);
+int pa_rt_h2d(void* d, const void* h, size_t bytes);
+int pa_rt_d2h(void* h, const void* d, size_t bytes);
+int pa_rt_d2d(void* dst, const void* src, size_t bytes);
+int pa_rt_d2h_async(void* pinned, const void* d, size_t bytes);
+void* pa_rt_event_create(void);
+void pa_rt_event_destroy(void* e);
+int pa_rt_event_record(void* e);
+double pa_rt_event_elapsed_s(void* a, void* b);
+int pa_rt_num_cus(void);
+
+/* ---- SpMM (utils/cplm_v0/cplm_v0_matmult_v2.c:108-343, K1) ------------- */
+typedef struct {
+  int m;                 /* local rows */
+  const int* rowptr;     /* m+1, device */
+  const int* colind;     /* local column: < m own row, >= m halo slot; device, padded by 4 */
+  const double* val;     /* device, padded by 2 */
+  int nblk;              /* row blocks */
+  const int* blk_row;    /* nblk+1: first row of each block */
+  const int* blk_win;    /* 2*nblk: [w0, w1) local columns staged in LDS */
+  const int* order;      /* block ids: interior blocks first, then blocks that read halo */
+  int n_interior;        /* how many of `order` need no halo row */
+  int nnz_cap, win_cap;  /* LDS budget the blocks were cut for */
+  int lanes_per_row_log2;/* log2(G): lanes that share one row's nonzeros */
+} pa_spmm_plan_t;
+/* phase 0: interior blocks, 1: halo-reading blocks, 2: all */
+int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo,
+              double* Y, int phase);
+/* sendbuf[i*ts + c] = X[idx[i]*ts + c] */
+int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendbuf);
+
+/* ---- tall-skinny kernels (ecg.c:250,311,330,347,425,438,510 K2; K3; K4) -- */
+/* Partial Gram blocks C = [A0 | A1]^T B over the local rows, one (npan*ts) x ts
+ * column-major block per workgroup into `partials`; returns the number of
+ * workgroups through nblk.  A1 may be NULL (npan = 1). */
+int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B,
+              double* partials, int* nblk);
+int pa_gram_max_blocks(void);
+/* out[i + ld_out*j] = sum over blocks, for rows i < a_lo (panel 0) and
+ * a_lo <= i < a_lo + a_hi (panel 1, column i - a_lo), j < nb. */
+int pa_k_finish(const double* partials, int nblk, int npan, int ts, int a_lo, int a_hi,
+                int nb, double* out, int ld_out);
+/* In-place upper Cholesky of the t x t column-major W (LAPACKE_dpotrf 'U',
+ * ecg.c:318,431,577); *info (device int) = 0 or failing column + 1. */
+int pa_k_potrf(double* W, int t, int* info);
+/* The t x t part of one fused Orthodir step (ecg.c:577-587): Cholesky of mu,
+ * beta <- beta U^-1, alpha <- U^-T alpha, beta(0:t,0:t) <- U^-T beta(0:t,0:t). */
+int pa_k_fused_small(double* mu, int t, int nrhs, int bm, int bn, int ldb, double* alpha,
+                     double* beta, int* info);
+/* P <- P U^-1 and AP <- AP U^-1 on the first t columns (cblas_dtrsm Right,
+ * Upper, ecg.c:324-327,434-435).  AP may be NULL. */
+int pa_k_trsm(int m, int ts, int t, const double* U, double* P, double* AP);
+/* X += P alpha, R -= AP alpha (ecg.c:337-338,500-501), alpha is t x nc with
+ * leading dimension t; also the per-workgroup sums of R(:,c)^2 for the
+ * stopping test (ecg.c:250) into rtr_partials[blk*ts + c]. */
+int pa_k_update_xr(int m, int ts, int t, int nc, const double* alpha, const double* P,
+                   const double* AP, double* X, double* R, double* rtr_partials, int* nblk);
+/* Standalone sums of R(:,c)^2 (same layout as above). */
+int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk);
+/* res2[0] = sum over blocks and columns c < nc. */
+int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2);
+/* Z(:, :nc) -= [V0(:, :a_lo) | V1(:, :a_hi)] beta, beta is (a_lo+a_hi) x nc,
+ * leading dimension ldb (ecg.c:354,517). */
+int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
+                  const double* V0, const double* V1, double* Z);
+/* dst(:, :nc) = src(:, :nc) (mkl_domatcopy, ecg.c:358,521-523). */
+int pa_k_copy_cols(int m, int ts, int nc, const double* src, double* dst);
+/* A(:, :t) <- A(:, :t) Q, Q is t x t column-major (the effect of LAPACKE_dormqr
+ * 'R','N' at ecg.c:476-479 with Q formed explicitly). */
+int pa_k_right_mult(int m, int ts, int t, const double* Q, double* A);
+/* A(:, j) <- A(:, piv[j]) for j < n (LAPACKE_dlapmt forward, ecg.c:380); piv 0-based, device. */
+int pa_k_permute_cols(int m, int ts, int n, const int* piv, double* A);
+/* sol[i] = sum_j X[i][j], j < nc (ecg.c:674). */
+int pa_k_rowsum(int m, int ts, int nc, const double* X, double* sol);
+
+/* ---- block-Jacobi apply (block_jacobi.c:93-109, K8) --------------------- */
+typedef struct {
+  int nparts;              /* blocks owned by this process */
+  const int* row0;         /* nparts: first local row of each block */
+  const int* nrows;        /* nparts */
+  const int* bw;           /* nparts: bandwidth w of the block's factor */
+  const long long* off;    /* nparts: offset (doubles) of the block in Lf / Lb */
+  const int* map_f;        /* local row visited at forward step j (m entries) */
+  const int* map_b;        /* local row visited at backward step j */
+  const double* Lf;        /* forward band: Lf[off + j*w + d-1] = L(j+d, j) */
+  const double* Lb;        /* backward band: Lb[off + j*w + d-1] = L(b-1-j, b-1-j-d) */
+  const double* invd_f;    /* 1 / L(j,j) in forward order (m entries) */
+  const double* invd_b;
+  int nclass;              /* parts grouped by register sets R = ceil((w+64)/64) */
+  const int* class_R;      /* host array, nclass */
+  const int* class_count;  /* host array */
+  const int* const* class_list; /* host array of device pointers to part ids */
+} pa_bj_plan_t;
+int pa_bj_max_R(void);
+int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,64 @@
+/*
+ * pa_host.h -- internal declarations shared by the C host sources of
+ * libprealps_hip.so (context.c, operator.c, block_jacobi.c, ecg.c).
+ */
+#ifndef PA_HOST_H
+#define PA_HOST_H
+
+#include <stddef.h>
+#include "preAlps_hip.h"
+#include "pa_device.h"
+
+/* ---- errors (CPLM_Abort / CPLM_ASSERT, utils/cplm_core/cplm_utils.h:31-37) */
+int pa_fail_at(const char* func, const char* fmt, ...);
+#define PA_FAIL(...) pa_fail_at(__func__, __VA_ARGS__)
+#define PA_CHECK(call)                                                       \
+  do {                                                                       \
+    if ((call) != 0) return PA_FAIL("%s failed: %s", #call, pa_rt_error());  \
+  } while (0)
+#define PA_REQUIRE_GPU()                                                     \
+  do {                                                                       \
+    if (!pa_rt_ready() && preAlps_hip_init(pa_default_device()) != 0)        \
+      return PA_FAIL("HIP device unavailable: %s", pa_rt_error());           \
+  } while (0)
+
+int pa_default_device(void);
+double pa_wtime(void);
+
+/* ---- process group ------------------------------------------------------ */
+int pa_world_rank(void);
+int pa_world_size(void);
+/* sum a device buffer over the processes (no-op for one process) */
+int pa_allreduce(double* dev_buf, int count);
+int pa_exchange(const double* dev_send, const int* send_counts, double* dev_recv,
+                const int* recv_counts, const int* peers, int npeers);
+
+/* ---- phase timing ------------------------------------------------------- */
+enum { PA_T_OPERATOR, PA_T_PRECOND, PA_T_GRAM, PA_T_TRSM, PA_T_UPDATE, PA_T_SMALL, PA_T_COMM, PA_T_COUNT };
+void pa_time_begin(int key);
+void pa_time_end(int key);
+
+/* ---- operator state shared with block_jacobi.c / ecg.c ------------------ */
+typedef struct {
+  int built;
+  int N;            /* global rows */
+  int nparts;       /* subdomains (the reference's ranks) */
+  int part0, part1; /* parts owned by this process: [part0, part1) */
+  int row_off;      /* first global row owned */
+  int m;            /* local rows */
+  int* rowPos;      /* nparts + 1, global */
+  int* perm;        /* N: perm[new] = old */
+  CPLM_Mat_CSR_t A; /* local row panel, global column ids (host) */
+  int halo;         /* halo rows */
+} pa_operator_info_t;
+const pa_operator_info_t* pa_operator_info(void);
+
+int pa_panel_stride(int enlFac);
+static inline int pa_desc_stride(const CPLM_Mat_Dense_t* A) { return A->info.lda; }
+void pa_set_desc(CPLM_Mat_Dense_t* A, int M, int N, int m, int n, int ts);
+
+double pa_bj_factor_bytes(void);
+int pa_bj_max_bandwidth(void);
+int pa_bj_nparts(void);
+
+#endif

@@ -1,0 +1,133 @@
+// runtime.hip -- HIP runtime calls behind the C shim of pa_device.h.
+// gfx950 only; no fallback: every failure is reported to the C host code,
+// which aborts like the reference's CPLM_Abort.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "pa_device.h"
+
+namespace {
+hipStream_t g_own = nullptr;
+hipStream_t g_cur = nullptr;
+bool g_ready = false;
+int g_cus = 0;
+char g_err[512] = "";
+
+int fail(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return 1;
+}
+}  // namespace
+
+#define RT(call)                                        \
+  do {                                                  \
+    hipError_t e_ = (call);                             \
+    if (e_ != hipSuccess) return fail(e_, #call);       \
+  } while (0)
+
+extern "C" {
+
+const char* pa_rt_error(void) { return g_err; }
+int pa_rt_ready(void) { return g_ready ? 1 : 0; }
+int pa_rt_num_cus(void) { return g_cus; }
+
+int pa_rt_init(int device) {
+  if (g_ready) return 0;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    snprintf(g_err, sizeof(g_err), "no HIP device available (%s); this library has no CPU path",
+             e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return 1;
+  }
+  RT(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  RT(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    snprintf(g_err, sizeof(g_err), "device %d is %s; kernels are built for gfx950 only", device,
+             prop.gcnArchName);
+    return 1;
+  }
+  g_cus = prop.multiProcessorCount;
+  RT(hipStreamCreateWithFlags(&g_own, hipStreamNonBlocking));
+  g_cur = g_own;
+  g_ready = true;
+  return 0;
+}
+
+void pa_rt_shutdown(void) {
+  if (!g_ready) return;
+  (void)hipStreamSynchronize(g_cur);
+  (void)hipStreamDestroy(g_own);
+  g_own = g_cur = nullptr;
+  g_ready = false;
+}
+
+void pa_rt_set_stream(void* s) { g_cur = s ? (hipStream_t)s : g_own; }
+void* pa_rt_stream(void) { return (void*)g_cur; }
+
+int pa_rt_sync(void) {
+  RT(hipStreamSynchronize(g_cur));
+  return 0;
+}
+
+void* pa_rt_malloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) { fail(e, "hipMalloc"); return nullptr; }
+  return p;
+}
+void pa_rt_free(void* d) { if (d) (void)hipFree(d); }
+
+void* pa_rt_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+  if (e != hipSuccess) { fail(e, "hipHostMalloc"); return nullptr; }
+  return p;
+}
+void pa_rt_host_free(void* h) { if (h) (void)hipHostFree(h); }
+
+int pa_rt_memset(void* d, int v, size_t bytes) {
+  if (bytes) RT(hipMemsetAsync(d, v, bytes, g_cur));
+  return 0;
+}
+int pa_rt_h2d(void* d, const void* h, size_t bytes) {
+  if (!bytes) return 0;
+  RT(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, g_cur));
+  RT(hipStreamSynchronize(g_cur));
+  return 0;
+}
+int pa_rt_d2h(void* h, const void* d, size_t bytes) {
+  if (!bytes) return 0;
+  RT(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_cur));
+  RT(hipStreamSynchronize(g_cur));
+  return 0;
+}
+int pa_rt_d2d(void* dst, const void* src, size_t bytes) {
+  if (bytes) RT(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_cur));
+  return 0;
+}
+int pa_rt_d2h_async(void* pinned, const void* d, size_t bytes) {
+  if (bytes) RT(hipMemcpyAsync(pinned, d, bytes, hipMemcpyDeviceToHost, g_cur));
+  return 0;
+}
+
+void* pa_rt_event_create(void) {
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return (void*)e;
+}
+void pa_rt_event_destroy(void* e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+int pa_rt_event_record(void* e) {
+  RT(hipEventRecord((hipEvent_t)e, g_cur));
+  return 0;
+}
+double pa_rt_event_elapsed_s(void* a, void* b) {
+  float ms = 0.f;
+  if (hipEventSynchronize((hipEvent_t)b) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.0;
+  return 1e-3 * (double)ms;
+}
+
+}  // extern "C"

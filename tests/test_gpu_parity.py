@@ -1,0 +1,181 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the
+reference's recorded outputs.  fp64 throughout; the reference itself sums in
+message-arrival order, so parity is by tolerance:
+  single kernels (SpMM, block solve)   1e-12 relative to the operand norms
+  residual histories / iterates        1e-8  (MKL vs oracle differ by 1e-11)
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL_HIST = 1e-8
+
+
+def _problem(A, P, part=None, **kw):
+    import prealps_amd
+    from oracle import oracle as O
+    part = O.contiguous_partition(A.shape[0], P) if part is None else part
+    rp, ci, v = O.as_csr(A)
+    prob = prealps_amd.EcgProblem(rp, ci, v, P, part, scale=True, device=0, **kw)
+    B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, P)
+    return prob, B, rowpos
+
+
+@pytest.fixture(scope="module")
+def poisson24():
+    from oracle import oracle as O
+    prob, B, rowpos = _problem(O.poisson3d(24), 8)
+    yield prob, B, rowpos
+    prob.close()
+
+
+def _random_spd(n, density, seed):
+    rng = np.random.default_rng(seed)
+    M = sp.random(n, n, density=density, random_state=rng, format="csr")
+    A = M + M.T
+    A = A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0)
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    return A
+
+
+def test_operator_matches_reference_setup(poisson24):
+    prob, B, rowpos = poisson24
+    assert np.array_equal(prob.rowpos, rowpos)
+    rp, ci, v = prob.local_csr()
+    assert np.array_equal(rp, B.indptr) and np.array_equal(ci, B.indices)
+    np.testing.assert_allclose(v, B.data, rtol=1e-15)
+    from oracle import oracle as O
+    np.testing.assert_array_equal(prob.reference_rhs(), O.reference_rhs(rowpos))
+
+
+@pytest.mark.parametrize("t", [1, 2, 4, 8, 16])
+def test_spmm_parity(poisson24, t):
+    from oracle import oracle as O
+    prob, B, rowpos = poisson24
+    X = np.random.default_rng(t).standard_normal((B.shape[0], t))
+    got = prob.block_operator(X, t)
+    ref = O.spmm(B, X)
+    np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("t", [1, 4, 8, 16])
+def test_block_jacobi_parity(poisson24, t):
+    from oracle import oracle as O
+    prob, B, rowpos = poisson24
+    X = np.random.default_rng(10 + t).standard_normal((B.shape[0], t))
+    got = prob.block_jacobi_apply(X, t)
+    ref = O.BlockJacobi(B, rowpos).apply(X)
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-11 * np.abs(ref).max())
+
+
+def test_spmm_and_block_solve_on_ragged_rows():
+    """Random pattern: rows of very different lengths, an empty-ish row, tiny parts."""
+    from oracle import oracle as O
+    A = _random_spd(1537, 0.01, 7)
+    P = 37
+    prob, B, rowpos = _problem(A, P)
+    try:
+        for t in (4, 8):
+            X = np.random.default_rng(t).standard_normal((B.shape[0], t))
+            np.testing.assert_allclose(prob.block_operator(X, t), O.spmm(B, X), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(prob.block_jacobi_apply(X, t), O.BlockJacobi(B, rowpos).apply(X),
+                                       rtol=1e-10, atol=1e-11)
+    finally:
+        prob.close()
+
+
+def test_ecg_odir_history_vs_recorded_reference(poisson24, golden):
+    prob, B, rowpos = poisson24
+    g = golden["poisson24_np8_t4"]
+    got = prob.solve(prob.reference_rhs(), 4)
+    assert got.iters == g["odir"]["iters"]
+    assert abs(got.normb - g["normb"]) < 1e-13
+    np.testing.assert_allclose(got.res, g["odir"]["res"], rtol=RTOL_HIST)
+
+
+@pytest.mark.parametrize("alg", ["odir", "omin", "fused"])
+@pytest.mark.parametrize("t", [1, 2, 4, 8])
+def test_ecg_parity_with_oracle(poisson24, alg, t):
+    import prealps_amd as pa
+    from oracle import oracle as O
+    prob, B, rowpos = poisson24
+    algs = {"odir": (pa.ORTHODIR, O.ORTHODIR), "omin": (pa.ORTHOMIN, O.ORTHOMIN),
+            "fused": (pa.ORTHODIR_FUSED, O.ORTHODIR_FUSED)}[alg]
+    rhs = prob.reference_rhs()
+    got = prob.solve(rhs, t, ortho_alg=algs[0])
+    ref = O.ECG(B, rowpos, t, algs[1], O.NO_BS_RED).solve(rhs)
+    assert got.iters == ref["iters"]
+    np.testing.assert_allclose(got.res, ref["res"], rtol=RTOL_HIST)
+    np.testing.assert_allclose(got.x, ref["x"], rtol=1e-7, atol=1e-9 * np.abs(ref["x"]).max())
+    assert np.all(got.bs == t)
+
+
+@pytest.mark.parametrize("alg,t", [("odir", 4), ("odir", 8), ("omin", 4), ("fused", 4)])
+def test_ecg_block_size_reduction_parity(poisson24, golden, alg, t):
+    import prealps_amd as pa
+    from oracle import oracle as O
+    prob, B, rowpos = poisson24
+    algs = {"odir": (pa.ORTHODIR, O.ORTHODIR), "omin": (pa.ORTHOMIN, O.ORTHOMIN),
+            "fused": (pa.ORTHODIR_FUSED, O.ORTHODIR_FUSED)}[alg]
+    rhs = prob.reference_rhs()
+    got = prob.solve(rhs, t, ortho_alg=algs[0], bs_red=pa.ADAPT_BS)
+    ref = O.ECG(B, rowpos, t, algs[1], O.ADAPT_BS).solve(rhs)
+    assert got.iters == ref["iters"]
+    assert list(got.bs) == list(ref["bs"])
+    np.testing.assert_allclose(got.res, ref["res"], rtol=1e-7)
+    if (alg, t) == ("odir", 4):
+        g = golden["poisson24_np8_t4"]["dodir"]
+        np.testing.assert_allclose(got.res, [x[0] for x in g["res_bs"]], rtol=1e-7)
+        assert list(got.bs) == [x[1] for x in g["res_bs"]]
+
+
+def test_lfat5_from_matrixmarket_file(golden):
+    import prealps_amd
+    prob = prealps_amd.EcgProblem.from_mtx(os.path.join(GOLD, "LFAT5.mtx"), nparts=2)
+    try:
+        got = prob.solve(prob.reference_rhs(), 2)
+        g = golden["lfat5"]["np2_t2_odir"]
+        assert got.iters == g["iters"]
+        assert abs(got.normb - g["normb"]) < 1e-13
+        np.testing.assert_allclose(got.res[:4], g["res"][:4], rtol=1e-10)
+        assert got.res[4] < 1e-11
+    finally:
+        prob.close()
+
+
+def test_enlarging_factor_larger_than_parts_is_refused():
+    import prealps_amd
+    prob = prealps_amd.EcgProblem.from_mtx(os.path.join(GOLD, "LFAT5.mtx"), nparts=2)
+    try:
+        with pytest.raises(prealps_amd.PreAlpsError, match="Enlarging factor"):
+            prob.solve(prob.reference_rhs(), 4)
+    finally:
+        prob.close()
+
+
+def test_geometric_partition_many_small_blocks():
+    """64 sub-cubes of 6^3 on a 24^3 grid: the shape the benchmark uses."""
+    import prealps_amd as pa
+    from oracle import oracle as O
+    n, s = 24, 6
+    idx = np.arange(n ** 3)
+    i, j, k = idx // (n * n), (idx // n) % n, idx % n
+    part = ((i // s) * (n // s) + (j // s)) * (n // s) + (k // s)
+    prob, B, rowpos = _problem(O.poisson3d(n), (n // s) ** 3, part.astype(np.int32))
+    try:
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, 4)
+        ref = O.ECG(B, rowpos, 4).solve(rhs)
+        assert got.iters == ref["iters"]
+        np.testing.assert_allclose(got.res, ref["res"], rtol=RTOL_HIST)
+        # size-independent property: the iterate solves the scaled, permuted system
+        r = B @ got.x - rhs
+        assert np.linalg.norm(r) <= 2.0001 * got.final_res
+    finally:
+        prob.close()
