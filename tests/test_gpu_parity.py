@@ -26,8 +26,10 @@ def _problem(A, P, part=None, **kw):
     return prob, B, rowpos
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def poisson24():
+    # operator and preconditioner are process-global in the library (as in the
+    # reference), so every test builds its own
     from oracle import oracle as O
     prob, B, rowpos = _problem(O.poisson3d(24), 8)
     yield prob, B, rowpos
