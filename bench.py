@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- ECG iterations/s on MI355X (+ SpMM roofline, + CPU baseline).
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under
+torch.distributed.run, one rank per GPU) prints ONE JSON line on rank 0.
+
+A step = one full ECG iteration of the reference driver loop
+(examples/test_ecg_prealps_op.c:208-221): Iterate(rci 0) -> stopping test ->
+block-Jacobi apply -> Iterate(rci 1) -> SpMM, through the C ABI of
+libprealps_hip.so.  Workload at N=1: BASELINE.json configs[1], synthetic 7-pt
+3-D Poisson n = 100^3, t = 4, block-Jacobi, fp64, inputs resident in HBM
+before the timed region.  If the solve converges inside the timed region it
+is restarted from the same rhs (the restart is inside the timing).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=100, help="grid points per side")
+    ap.add_argument("--t", type=int, default=4, help="enlarging factor")
+    ap.add_argument("--box", type=str, default="10,10,10", help="subdomain box (nodes)")
+    ap.add_argument("--alg", type=str, default="odir", choices=["odir", "omin", "fused"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--spmm-reps", type=int, default=50)
+    return ap.parse_args()
+
+
+def run_iterations(prob, e, rhs, L, nsteps, state):
+    """Advance the reference driver loop by nsteps full iterations."""
+    import prealps_amd.lib as pl
+    from prealps_amd.lib import check
+    rci, stop = state["rci"], C.c_int(0)
+    done = 0
+    while done < nsteps:
+        check(L.preAlps_ECGIterate(C.byref(e), C.byref(rci)), "ECGIterate")
+        if rci.value == 0:
+            check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
+            done += 1
+        else:
+            check(L.preAlps_ECGStoppingCriterion(C.byref(e), C.byref(stop)), "StoppingCriterion")
+            if stop.value == 1:
+                # converged: start again from the same rhs (counted in the timing)
+                state["restarts"] += 1
+                state["last_iters"] = e.iter
+                state["last_res"] = e.res
+                check(L._preAlps_ECGReset(C.byref(e), rhs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(rci)), "ECGReset")
+                check(L.preAlps_BlockJacobiApply(e.R, e.P), "BlockJacobiApply")
+                check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
+                done += 1
+                continue
+            src = e.R if e.ortho_alg == pl.ORTHOMIN else e.AP
+            check(L.preAlps_BlockJacobiApply(src, e.Z), "BlockJacobiApply")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import prealps_amd
+    import prealps_amd.lib as pl
+    from prealps_amd import gen
+    from prealps_amd.lib import check
+
+    box = tuple(int(x) for x in a.box.split(","))
+    rowptr, colind, val = gen.poisson3d_csr(a.n)
+    part, nparts = gen.box_partition(a.n, box)
+    N, nnz = a.n ** 3, len(val)
+    t_setup = time.perf_counter()
+    prob = prealps_amd.EcgProblem(rowptr, colind, val, nparts, part, scale=True, device=local_rank,
+                                  distributed=distributed)
+    L = prob.L
+    L._preAlps_ECGReset.argtypes = [C.POINTER(pl.preAlps_ECG_t), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    prob.create_block_jacobi()
+    t_setup = time.perf_counter() - t_setup
+    rhs = prob.reference_rhs()
+    alg = {"odir": pl.ORTHODIR, "omin": pl.ORTHOMIN, "fused": pl.ORTHODIR_FUSED}[a.alg]
+    if alg == pl.ORTHODIR_FUSED:
+        raise SystemExit("bench.py times the two-phase RCI loop; use --alg odir|omin")
+    e = prob.new_ecg(a.t, alg, pl.NO_BS_RED, 1e-5, 100000)
+    rci = C.c_int(0)
+    check(L.preAlps_ECGInitialize(C.byref(e), rhs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(rci)), "ECGInitialize")
+    check(L.preAlps_BlockJacobiApply(e.R, e.P), "BlockJacobiApply")
+    check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
+    state = {"rci": rci, "restarts": 0, "last_iters": 0, "last_res": float("nan")}
+
+    def barrier():
+        prob.sync()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run_iterations(prob, e, rhs, L, a.warmup, state)
+    barrier()
+    t0 = time.perf_counter()
+    run_iterations(prob, e, rhs, L, a.steps, state)
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    its = a.steps / dt
+
+    # ---- dominant kernel (SpMM) against the HBM roofline: HIP events on the library stream
+    ts = L.preAlps_hip_panel_stride(a.t)
+    m_loc, nnz_loc = int(prob.stat("rows_local")), int(prob.stat("nnz_local"))
+    halo = int(prob.stat("halo_rows"))
+    sec = C.c_double()
+    for _ in range(5):
+        check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
+    check(L.preAlps_hip_timer_start(), "timer_start")
+    for _ in range(a.spmm_reps):
+        check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
+    check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
+    spmm_s = sec.value / a.spmm_reps
+    # 12 B per nonzero + 4 B per row pointer + read X + write AX (8*t B per row each)
+    spmm_bytes = 12.0 * nnz_loc + 4.0 * (m_loc + 1) + 8.0 * (m_loc + halo) * a.t + 8.0 * m_loc * a.t
+    spmm_gbs = spmm_bytes / spmm_s / 1e9
+    # block-Jacobi apply, same stopwatch
+    check(L.preAlps_hip_timer_start(), "timer_start")
+    for _ in range(a.spmm_reps):
+        check(L.preAlps_BlockJacobiApply(e.AP, e.Z), "BlockJacobiApply")
+    check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
+    bj_s = sec.value / a.spmm_reps
+    bj_bytes = prob.stat("bj_factor_bytes") + 16.0 * m_loc * a.t + 8.0 * m_loc
+    traffic = None
+    tf = os.environ.get("PREALPS_SPMM_TRAFFIC_BYTES")
+    if tf:
+        traffic = float(tf)
+
+    out = {
+        "metric": "ECG iters/sec + SpMM HBM GB/s (% roofline), 3D-elasticity n~1M t=4",
+        "value": its, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: synthetic 7-pt 3-D Poisson SPD CSR %d^3 (N=%d, nnz=%d), "
+                               "ECG %s + block-Jacobi, t=%d, tol 1e-5" % (a.n, N, nnz, a.alg, a.t),
+                   "nparts": int(nparts), "subdomain_box": list(box), "parallelism": "rows x%d" % world,
+                   "restarts_in_timed_region": state["restarts"],
+                   "iterations_to_converge": state["last_iters"], "setup_seconds": t_setup,
+                   "bj_max_bandwidth": int(prob.stat("bj_max_bandwidth")),
+                   "spmm_blocks": int(prob.stat("spmm_blocks"))},
+        "roofline": {"kernel": "k_spmm", "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": spmm_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s},
+        "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "factor_bytes": prob.stat("bj_factor_bytes"),
+                         "achieved_GBs": bj_bytes / bj_s / 1e9},
+    }
+
+    # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, rank 0, N=1
+    if rank == 0 and world == 1 and not a.no_cpu:
+        from oracle import oracle as O
+        import scipy.sparse as sp
+        A = sp.csr_matrix((val, colind, rowptr), shape=(N, N))
+        B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, nparts)
+        tf0 = time.perf_counter()
+        ecg = O.ECG(B, rowpos, a.t, O.ORTHODIR if a.alg == "odir" else O.ORTHOMIN, O.NO_BS_RED, 1e-5, a.cpu_iters)
+        tfac = time.perf_counter() - tf0
+        r = ecg.solve(O.reference_rhs(rowpos))
+        out["cpu_baseline"] = {"value": r["iters"] / r["t_total"], "unit": "iterations/s",
+                               "cores": O.lib().orc_num_threads(), "kind": "port",
+                               "sample": "%d ECG iterations of the same workload (same matrix, scaling, partition, rhs) "
+                                         "by oracle/ecg_oracle.c with OpenMP; operator %.3fs precond %.3fs of %.3fs; "
+                                         "factorisation %.1fs outside the rate" % (r["iters"], r["t_op"], r["t_prec"], r["t_total"], tfac),
+                               "host_cores_online": os.cpu_count()}
+    if rank == 0:
+        print(json.dumps(out))
+    prob.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,11 @@ int preAlps_hip_panel_from_host(CPLM_Mat_Dense_t* A, int enlFac, const double* h
  * "nnz_local", "rows_local", "halo_rows", "spmm_blocks", "bj_factor_bytes",
  * "bj_max_bandwidth", "bj_parts_local".  Returns non-zero for unknown keys. */
 int preAlps_hip_get_stat(const char* key, double* value);
+/* A stopwatch made of two hipEvents on the library stream: start records the
+ * first, stop records the second, waits for it and returns the device time
+ * between them (what bench.py uses to time a batch of launches). */
+int preAlps_hip_timer_start(void);
+int preAlps_hip_timer_stop(double* seconds);
 /* Per-phase device time in seconds accumulated since the last reset, from
  * hipEvents on the library stream when timing is enabled (it adds a stream
  * sync per call, so it is off by default).  Keys: "operator", "precond",

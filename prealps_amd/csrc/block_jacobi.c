@@ -202,8 +202,6 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     for (int j = 0; j < b; ++j) {
       map_f[r0 + j] = order[j];
       map_b[r0 + j] = order[b - 1 - j];
-      invd_f[r0 + j] = 1.0 / band[(size_t)j * ld];
-      invd_b[r0 + j] = 1.0 / band[(size_t)(b - 1 - j) * ld];
     }
     free(xadj); free(adj); free(deg); free(order); free(pos); free(queue); free(level);
   }
@@ -212,33 +210,42 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   /* pass 2: sweep layouts */
   off[0] = 0;
   int maxw = 0;
-  for (int q = 0; q < np; ++q) { off[q + 1] = off[q] + (long long)nrows[q] * bw[q]; if (bw[q] > maxw) maxw = bw[q]; }
+  /* one record of wr doubles per step: [1/L(j,j) | row id | 0 | L(j+1..j+w, j) | 0], wr even */
+  for (int q = 0; q < np; ++q) { off[q + 1] = off[q] + (long long)nrows[q] * ((bw[q] + 5) & ~1); if (bw[q] > maxw) maxw = bw[q]; }
   s->max_bw = maxw;
   int maxR = pa_bj_max_R();
   if (!rc && (maxw + 127) / 64 > maxR)
     rc = PA_FAIL("block-Jacobi: a diagonal block has bandwidth %d after RCM; the wavefront-resident solve "
                  "supports up to %d -- use more (smaller) subdomains", maxw, 64 * maxR - 64);
   size_t tot = (size_t)off[np];
+  const size_t pad = 256; /* the last LDS-DMA piece of a chunk may read up to 1 KiB past it */
   double* Lf = NULL; double* Lb = NULL;
   if (!rc) {
-    Lf = (double*)malloc((tot ? tot : 1) * sizeof(double));
-    Lb = (double*)malloc((tot ? tot : 1) * sizeof(double));
+    Lf = (double*)calloc(tot + pad, sizeof(double));
+    Lb = (double*)calloc(tot + pad, sizeof(double));
     if (!Lf || !Lb) rc = PA_FAIL("out of host memory for %zu factor entries", tot);
   }
   if (!rc) {
 #pragma omp parallel for schedule(dynamic, 1)
     for (int q = 0; q < np; ++q) {
-      int b = nrows[q], w = bw[q];
-      size_t ld = (size_t)w + 1;
+      int b = nrows[q], w = bw[q], r0 = row0[q];
+      size_t ld = (size_t)w + 1, wr = (size_t)((w + 5) & ~1);
       const double* band = bands[q];
       double* f = Lf + off[q];
       double* g = Lb + off[q];
-      for (int j = 0; j < b; ++j)
+      for (int j = 0; j < b; ++j) {
+        int jr = b - 1 - j;
+        long long idf = map_f[r0 + j], idb = map_b[r0 + j];
+        f[(size_t)j * wr] = invd_f[r0 + j] = 1.0 / band[(size_t)j * ld];
+        g[(size_t)j * wr] = invd_b[r0 + j] = 1.0 / band[(size_t)jr * ld];
+        memcpy(&f[(size_t)j * wr + 1], &idf, sizeof(double));
+        memcpy(&g[(size_t)j * wr + 1], &idb, sizeof(double));
         for (int dd = 1; dd <= w; ++dd) {
-          f[(size_t)j * w + dd - 1] = (j + dd < b) ? band[(size_t)(j + dd) * ld + dd] : 0.0;
-          int jr = b - 1 - j;
-          g[(size_t)j * w + dd - 1] = (jr - dd >= 0) ? band[(size_t)jr * ld + dd] : 0.0;
+          /* pre-divided by the pivot of the step (see kernels.hip: bj_block) */
+          f[(size_t)j * wr + 2 + dd] = (j + dd < b) ? band[(size_t)(j + dd) * ld + dd] * invd_f[r0 + j] : 0.0;
+          g[(size_t)j * wr + 2 + dd] = (jr - dd >= 0) ? band[(size_t)jr * ld + dd] * invd_b[r0 + j] : 0.0;
         }
+      }
     }
   }
   for (int q = 0; q < np; ++q) free(bands[q]);
@@ -274,21 +281,21 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     s->d_map_b = (int*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(int));
     s->d_invd_f = (double*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(double));
     s->d_invd_b = (double*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(double));
-    s->d_Lf = (double*)pa_rt_malloc((tot ? tot : 1) * sizeof(double));
-    s->d_Lb = (double*)pa_rt_malloc((tot ? tot : 1) * sizeof(double));
+    s->d_Lf = (double*)pa_rt_malloc((tot + pad) * sizeof(double));
+    s->d_Lb = (double*)pa_rt_malloc((tot + pad) * sizeof(double));
     int bad = !s->d_row0 || !s->d_nrows || !s->d_bw || !s->d_off || !s->d_map_f || !s->d_map_b ||
-              !s->d_invd_f || !s->d_invd_b || !s->d_Lf || !s->d_Lb;
+              !s->d_Lf || !s->d_Lb || !s->d_invd_f || !s->d_invd_b;
     bad = bad || pa_rt_h2d(s->d_row0, row0, np * sizeof(int)) || pa_rt_h2d(s->d_nrows, nrows, np * sizeof(int)) ||
           pa_rt_h2d(s->d_bw, bw, np * sizeof(int)) || pa_rt_h2d(s->d_off, off, (np + 1) * sizeof(long long)) ||
           pa_rt_h2d(s->d_map_f, map_f, (size_t)m * sizeof(int)) || pa_rt_h2d(s->d_map_b, map_b, (size_t)m * sizeof(int)) ||
           pa_rt_h2d(s->d_invd_f, invd_f, (size_t)m * sizeof(double)) || pa_rt_h2d(s->d_invd_b, invd_b, (size_t)m * sizeof(double)) ||
-          pa_rt_h2d(s->d_Lf, Lf, tot * sizeof(double)) || pa_rt_h2d(s->d_Lb, Lb, tot * sizeof(double));
+          pa_rt_h2d(s->d_Lf, Lf, (tot + pad) * sizeof(double)) || pa_rt_h2d(s->d_Lb, Lb, (tot + pad) * sizeof(double));
     if (bad) rc = PA_FAIL("uploading the block factors failed: %s", pa_rt_error());
   }
   free(Lf); free(Lb);
   free(row0); free(nrows); free(bw); free(off); free(map_f); free(map_b); free(invd_f); free(invd_b);
   if (rc) { preAlps_BlockJacobiFree(); return rc; }
-  s->factor_bytes = 2.0 * 8.0 * (double)tot + 2.0 * 8.0 * (double)m;
+  s->factor_bytes = 2.0 * 8.0 * (double)tot;
   pa_bj_plan_t* pl = &s->plan;
   pl->nparts = np; pl->row0 = s->d_row0; pl->nrows = s->d_nrows; pl->bw = s->d_bw; pl->off = s->d_off;
   pl->map_f = s->d_map_f; pl->map_b = s->d_map_b; pl->Lf = s->d_Lf; pl->Lb = s->d_Lb;

@@ -166,6 +166,23 @@ void pa_time_end(int key) {
     if (s > 0) g_times[key] += s;
   }
 }
+static void* g_sw0 = NULL;
+static void* g_sw1 = NULL;
+int preAlps_hip_timer_start(void) {
+  PA_REQUIRE_GPU();
+  if (!g_sw0) { g_sw0 = pa_rt_event_create(); g_sw1 = pa_rt_event_create(); }
+  if (!g_sw0 || !g_sw1) return PA_FAIL("hipEventCreate failed");
+  PA_CHECK(pa_rt_event_record(g_sw0));
+  return 0;
+}
+int preAlps_hip_timer_stop(double* seconds) {
+  if (!g_sw0) return PA_FAIL("timer not started");
+  PA_CHECK(pa_rt_event_record(g_sw1));
+  *seconds = pa_rt_event_elapsed_s(g_sw0, g_sw1);
+  if (*seconds < 0) return PA_FAIL("hipEventElapsedTime failed");
+  return 0;
+}
+
 int preAlps_hip_get_time(const char* key, double* seconds) {
   for (int i = 0; i < PA_T_COUNT; ++i)
     if (strcmp(key, k_time_keys[i]) == 0) { *seconds = g_times[i]; return 0; }

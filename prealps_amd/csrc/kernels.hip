@@ -194,16 +194,16 @@ __global__ __launch_bounds__(WG) void k_gram(int m, const double* __restrict__ A
 
 // Sum the per-workgroup partial blocks (fixed order) and scatter the active
 // sub-block into the reference's t x t layout.
-__global__ __launch_bounds__(WG) void k_finish(const double* __restrict__ partials, int nblk,
+__global__ __launch_bounds__(1024) void k_finish(const double* __restrict__ partials, int nblk,
                                                int npan, int ts, int a_lo, int a_hi, int nb,
                                                double* __restrict__ out, int ld_out) {
-  __shared__ double red[WG];
+  __shared__ double red[1024];
   const int ldp = npan * ts;
   const int na = a_lo + a_hi;
   const int ne = na * nb;
   int ner = 1;
-  while (ner < ne && ner < WG) ner <<= 1;
-  const int nsl = WG / ner;
+  while (ner < ne && ner < 1024) ner <<= 1;
+  const int nsl = 1024 / ner;
   const int tid = threadIdx.x;
   const int e0 = tid % ner, s = tid / ner;
   for (int base = 0; base < ne; base += ner) {
@@ -228,24 +228,29 @@ __global__ __launch_bounds__(WG) void k_finish(const double* __restrict__ partia
 
 // t x t upper Cholesky, one lane (t <= 16).  LAPACK dpotf2 'U': on failure
 // the failing pivot is stored and the rest of W is left untouched.
-__global__ void k_potrf(double* __restrict__ W, int t, int* __restrict__ info) {
-  if (threadIdx.x != 0) return;
-  int fail = 0;
-  for (int j = 0; j < t; ++j) {
-    double d = W[j + t * j];
-    for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
-    if (!(d > 0.0)) { W[j + t * j] = d; fail = j + 1; break; }
-    d = sqrt(d);
-    W[j + t * j] = d;
-    for (int i = j + 1; i < t; ++i) {
-      double s = W[j + t * i];
-      for (int k = 0; k < j; ++k) s -= W[k + t * j] * W[k + t * i];
-      W[j + t * i] = s / d;
+__global__ void k_potrf(double* __restrict__ Wg, int t, int* __restrict__ info) {
+  __shared__ double W[16 * 16];
+  for (int e = threadIdx.x; e < t * t; e += 64) W[e] = Wg[e];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int fail = 0;
+    for (int j = 0; j < t; ++j) {
+      double d = W[j + t * j];
+      for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
+      if (!(d > 0.0)) { W[j + t * j] = d; fail = j + 1; break; }
+      d = sqrt(d);
+      W[j + t * j] = d;
+      for (int i = j + 1; i < t; ++i) {
+        double s = W[j + t * i];
+        for (int k = 0; k < j; ++k) s -= W[k + t * j] * W[k + t * i];
+        W[j + t * i] = s / d;
+      }
     }
+    *info = fail;
   }
-  *info = fail;
+  __syncthreads();
+  for (int e = threadIdx.x; e < t * t; e += 64) Wg[e] = W[e];
 }
-
 
 // Small t x t work of the fused Orthodir step (ecg.c:577-587), one lane:
 // mu = U^T U ; beta <- beta U^-1 (bm x bn) ; alpha <- U^-T alpha (t x nrhs) ;
@@ -544,80 +549,178 @@ __global__ __launch_bounds__(WG) void k_rowsum(int m, int nc, const double* __re
 // factor (RCM order, factored at setup) applied as two systolic sweeps.  The
 // W = 64*R rows in flight live in registers, row (j mod W) in lane (j mod 64)
 // of register set (j/64 mod R); at step j the pivot y_j is broadcast with
-// v_readlane and every lane updates the rows j+1..j+w it holds with one
-// coalesced read of column j of the band.  Four blocks per workgroup (one per
-// wave), no LDS, no inter-wave traffic.
-template <int TS, int R>
-__device__ __forceinline__ void bj_sweep(int b, int w, const double* __restrict__ F,
-                                         const double* __restrict__ invd,
-                                         const int* __restrict__ iomap, size_t rowbase,
-                                         const double* __restrict__ src,
-                                         double* __restrict__ dst, int lane) {
-  constexpr int W = 64 * R;
-  double acc[R][TS];
+// v_readlane and every lane updates the rows j+1..j+w it holds.
+//
+// The band is the only large operand and it is read exactly once per sweep:
+// step j needs the record [1/L(j,j) | row id | L(j+1..j+w, j)] (wr doubles).
+// Records are streamed HBM -> LDS in chunks of CH steps with LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPRs), double
+// buffered per wave so chunk c+1 is in flight while chunk c is consumed.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+template <int CH>
+__device__ __forceinline__ void bj_issue_chunk(const double* __restrict__ rec, int wr, int chunk,
+                                               double* lbuf, int lane) {
+  const int nbytes = CH * wr * 8;
+  const char* g = reinterpret_cast<const char*>(rec) + (size_t)chunk * nbytes + lane * 16;
+  char* l = reinterpret_cast<char*>(lbuf);
+  for (int o = 0; o < nbytes; o += 1024)
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)(g + o), (lds_void_ptr)(l + o), 16, 0, 0);
+}
+
+// Record of step j (wr = (w+5)&~1 doubles):
+//   r[0] = 1/L(j,j)   r[1] = row id (both unused by the kernel)   r[2] = 0
+//   r[2+d] = L(j+d, j) / L(j, j), d = 1..w   r[w+3] = 0
+// The band is pre-divided by its pivot, so a step is a_i -= (L_ij / L_jj) a_j
+// with a_j read straight from its lane (no multiply on the critical path);
+// y_j = a_j / L_jj is formed once per row when its block of 64 is stored.
+// A lane that holds row j+d reads r[2 + min(d, w+1)] (d taken as unsigned): rows
+// outside the band, the pivot row itself (d = 0) and rows already solved
+// (d < 0) all land on a zero, so the update needs no branch.  A solved row is
+// never touched again, so the block's 64 results stay in their lanes and are
+// scaled and stored together when the block is done.
+template <int R>
+struct bj_vals {
+  double lv[R];
+};
+
+template <int R, int K>
+__device__ __forceinline__ void bj_load_step(const double* __restrict__ r, int l, int w, int lane,
+                                             bj_vals<R>& v) {
 #pragma unroll
-  for (int k = 0; k < R; ++k) {
-    const int j = k * 64 + lane;
-    if (j < b) load_row<TS>(src, rowbase + iomap[j], acc[k]);
-    else
-#pragma unroll
-      for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
+  for (int k2 = 0; k2 < R; ++k2) {
+    const int rel = (k2 - K + R) % R;
+    v.lv[k2] = 0.0;
+    if (rel == 0 || l >= rel * 64 - w) {       // wave-uniform: does set k2 touch the band at all?
+      const unsigned d = (unsigned)(rel * 64 + lane - l);
+      const unsigned idx = min(d, (unsigned)(w + 1));
+      v.lv[k2] = r[2 + idx];
+    }
   }
-  for (int jb = 0; jb < b; jb += W) {
+}
+
+template <int TS, int R, int CH, int K>
+__device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chunk, int b, int w, int wr,
+                                         const double* __restrict__ rec, double* lds0, double* lds1,
+                                         int lane) {
+  for (int lc = 0; lc < lim; lc += CH, ++chunk) {
+    // chunk `chunk` has landed once every outstanding VMEM op of this wave is done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const double* cur = (chunk & 1) ? lds1 : lds0;
+    if ((chunk + 1) * CH < b) bj_issue_chunk<CH>(rec, wr, chunk + 1, (chunk & 1) ? lds0 : lds1, lane);
+    const int send = (lim - lc) < CH ? (lim - lc) : CH;
+    bj_vals<R> nv;
+    bj_load_step<R, K>(cur, lc, w, lane, nv);
+    for (int s = 0; s < send; ++s) {
+      const int l = lc + s;
+      const bj_vals<R> cv = nv;
+      if (s + 1 < send) bj_load_step<R, K>(cur + (s + 1) * wr, l + 1, w, lane, nv);
+      double y[TS];
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const int j0 = jb + k * 64;
-      if (j0 < b) {
-        double nxt[TS];
-        const int jn = j0 + W + lane;
-        if (jn < b) load_row<TS>(src, rowbase + iomap[jn], nxt);
-        else
+      for (int c = 0; c < TS; ++c) y[c] = readlane_f64(acc[K][c], l);
 #pragma unroll
-          for (int c = 0; c < TS; ++c) nxt[c] = 0.0;
-        const int lim = (b - j0) < 64 ? (b - j0) : 64;
-        for (int l = 0; l < lim; ++l) {
-          const int j = j0 + l;
-          const double idg = invd[j];
-          double y[TS];
+      for (int k2 = 0; k2 < R; ++k2) {
+        const int rel = (k2 - K + R) % R;
+        if (rel == 0 || l >= rel * 64 - w) {
 #pragma unroll
-          for (int c = 0; c < TS; ++c) y[c] = readlane_f64(acc[k][c], l) * idg;
-          if (lane == 0) store_row<TS>(dst, rowbase + iomap[j], y);
-          const double* __restrict__ col = F + (size_t)j * w - 1;
-#pragma unroll
-          for (int k2 = 0; k2 < R; ++k2) {
-            int d = (k2 - k) * 64 + lane - l;
-            d = d < 0 ? d + W : d;
-            if (d >= 1 && d <= w) {
-              const double lv = col[d];
-#pragma unroll
-              for (int c = 0; c < TS; ++c) acc[k2][c] = fma(-lv, y[c], acc[k2][c]);
-            }
-          }
+          for (int c = 0; c < TS; ++c) acc[k2][c] = fma(-cv.lv[k2], y[c], acc[k2][c]);
         }
-#pragma unroll
-        for (int c = 0; c < TS; ++c) acc[k][c] = nxt[c];
       }
     }
   }
 }
 
-template <int TS, int R>
-__global__ __launch_bounds__(WG) void k_bj_apply(
+template <int TS, int R, int CH, int K>
+__device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R], int jb, int& chunk, int b,
+                                          int w, int wr, const double* __restrict__ rec,
+                                          const double* __restrict__ invd,
+                                          const int* __restrict__ iomap, size_t rowbase,
+                                          const double* __restrict__ src, double* __restrict__ dst,
+                                          double* lds0, double* lds1, int lane) {
+  if constexpr (K < R) {
+    constexpr int W = 64 * R;
+    const int j0 = jb + K * 64;
+    if (j0 < b) {
+      double nxt[TS];
+      double idl = 0.0;
+      int nrow = 0;
+      const int jn = j0 + W + lane;
+      if (j0 + lane < b) idl = invd[j0 + lane];
+      if (jn < b) { nrow = iomap[jn]; load_row<TS>(src, rowbase + nrow, nxt); }
+      else
+#pragma unroll
+        for (int c = 0; c < TS; ++c) nxt[c] = 0.0;
+      const int lim = (b - j0) < 64 ? (b - j0) : 64;
+      bj_block<TS, R, CH, K>(acc, lim, chunk, b, w, wr, rec, lds0, lds1, lane);
+      if (lane < lim) {
+        double y[TS];
+#pragma unroll
+        for (int c = 0; c < TS; ++c) y[c] = acc[K][c] * idl;
+        store_row<TS>(dst, rowbase + rowid[K], y);
+      }
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[K][c] = nxt[c];
+      rowid[K] = nrow;
+    }
+    bj_blocks<TS, R, CH, K + 1>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0,
+                                lds1, lane);
+  }
+}
+
+template <int TS, int R, int CH>
+__device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __restrict__ rec,
+                                         const double* __restrict__ invd,
+                                         const int* __restrict__ iomap, size_t rowbase,
+                                         const double* __restrict__ src, double* __restrict__ dst,
+                                         double* lds0, double* lds1, int lane) {
+  constexpr int W = 64 * R;
+  double acc[R][TS];
+  int rowid[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int j = k * 64 + lane;
+    rowid[k] = 0;
+    if (j < b) { rowid[k] = iomap[j]; load_row<TS>(src, rowbase + rowid[k], acc[k]); }
+    else
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
+  }
+  bj_issue_chunk<CH>(rec, wr, 0, lds0, lane);
+  int chunk = 0;
+  for (int jb = 0; jb < b; jb += W)
+    bj_blocks<TS, R, CH, 0>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lds1,
+                            lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int TS, int R, int CH>
+__global__ void k_bj_apply(
     const int* __restrict__ list, int count, const int* __restrict__ row0,
     const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off,
     const int* __restrict__ map_f, const int* __restrict__ map_b, const double* __restrict__ Lf,
     const double* __restrict__ Lb, const double* __restrict__ invd_f,
-    const double* __restrict__ invd_b, const double* __restrict__ in, double* __restrict__ out) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int pi = blockIdx.x * (WG / 64) + wave;
+    const double* __restrict__ invd_b, int lds_per_wave, const double* __restrict__ in,
+    double* __restrict__ out) {
+  extern __shared__ double smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int pi = blockIdx.x * (blockDim.x >> 6) + wave;
   if (pi >= count) return;
-  const int p = list[pi];
-  const int r0 = row0[p], b = nrows[p], w = bw[p];
-  const size_t o = (size_t)off[p];
+  // everything that steers the sweep is wave-uniform: keep it in SGPRs
+  const int p = __builtin_amdgcn_readfirstlane(list[pi]);
+  const int r0 = __builtin_amdgcn_readfirstlane(row0[p]);
+  const int b = __builtin_amdgcn_readfirstlane(nrows[p]);
+  const int w = __builtin_amdgcn_readfirstlane(bw[p]);
+  const int wr = (w + 5) & ~1;
+  const long long o64 = off[p];
+  const size_t o = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(o64 >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)o64);
+  double* lds0 = smem + (size_t)wave * lds_per_wave;
+  double* lds1 = lds0 + (lds_per_wave >> 1);
   // forward: L y = x (y goes to `out`), backward: L^T z = y in place
-  bj_sweep<TS, R>(b, w, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in, out, lane);
+  bj_sweep<TS, R, CH>(b, w, wr, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in, out, lds0, lds1, lane);
   __threadfence_block();
-  bj_sweep<TS, R>(b, w, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, lane);
+  bj_sweep<TS, R, CH>(b, w, wr, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, lds0, lds1, lane);
 }
 
 inline int grid_rows(int m, int per_thread_rows = 1) {
@@ -675,16 +778,33 @@ static int spmm_g(const pa_spmm_plan_t* pl, const int* order, int nlist, const d
   }
 }
 
+constexpr int BJ_CH = 16;
+
 template <int TS>
 static int bj_launch(const pa_bj_plan_t* pl, int R, const int* list, int count, const double* in,
                      double* out) {
-  const int blocks = (count + WG / 64 - 1) / (WG / 64);
-#define BJ_CASE(RR)                                                                              \
-  case RR:                                                                                       \
-    hipLaunchKernelGGL((k_bj_apply<TS, RR>), dim3(blocks), dim3(WG), 0, cur_stream(), list,      \
-                       count, pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b,        \
-                       pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, in, out);                         \
-    break;
+  // LDS per wave: two chunk buffers of CH records of the widest band in this class
+  const int wmax = 64 * R - 64;
+  const int wr = (wmax + 5) & ~1;
+  int per_wave = 2 * ((BJ_CH * wr + 127) & ~127);  // doubles, each buffer a multiple of 1 KiB
+  int waves = (160 * 1024) / (per_wave * 8);
+  if (waves > 4) waves = 4;
+  if (waves < 1) { snprintf(g_kerr, sizeof(g_kerr), "block-Jacobi band too wide for LDS (R=%d)", R); return 1; }
+  const size_t lds = (size_t)waves * per_wave * 8;
+  const int blocks = (count + waves - 1) / waves;
+#define BJ_CASE(RR)                                                                               \
+  case RR: {                                                                                      \
+    static size_t configured = 0;                                                                 \
+    if (lds > 64 * 1024 && lds > configured) {                                                    \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply<TS, RR, BJ_CH>),          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return kfail("hipFuncSetAttribute(k_bj_apply)");                                          \
+      configured = lds;                                                                           \
+    }                                                                                             \
+    hipLaunchKernelGGL((k_bj_apply<TS, RR, BJ_CH>), dim3(blocks), dim3(64 * waves), lds,          \
+                       cur_stream(), list, count, pl->row0, pl->nrows, pl->bw, pl->off,           \
+                       pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, per_wave, in, out);                  \
+  } break;
   switch (R) {
     BJ_CASE(1) BJ_CASE(2) BJ_CASE(3) BJ_CASE(4) BJ_CASE(5) BJ_CASE(6) BJ_CASE(7) BJ_CASE(8)
     default:
@@ -737,7 +857,7 @@ int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B
 int pa_k_finish(const double* partials, int nblk, int npan, int ts, int a_lo, int a_hi, int nb,
                 double* out, int ld_out) {
   if ((a_lo + a_hi) * nb <= 0) return 0;
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(WG), 0, cur_stream(), partials, nblk, npan, ts, a_lo,
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, cur_stream(), partials, nblk, npan, ts, a_lo,
                      a_hi, nb, out, ld_out);
   return kfail("k_finish");
 }

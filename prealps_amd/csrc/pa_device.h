@@ -104,13 +104,18 @@ typedef struct {
   const int* row0;         /* nparts: first local row of each block */
   const int* nrows;        /* nparts */
   const int* bw;           /* nparts: bandwidth w of the block's factor */
-  const long long* off;    /* nparts: offset (doubles) of the block in Lf / Lb */
+  const long long* off;    /* nparts: offset (doubles, even) of the block in Lf / Lb */
   const int* map_f;        /* local row visited at forward step j (m entries) */
   const int* map_b;        /* local row visited at backward step j */
-  const double* Lf;        /* forward band: Lf[off + j*w + d-1] = L(j+d, j) */
-  const double* Lb;        /* backward band: Lb[off + j*w + d-1] = L(b-1-j, b-1-j-d) */
-  const double* invd_f;    /* 1 / L(j,j) in forward order (m entries) */
-  const double* invd_b;
+  /* One record of wr = (w+5)&~1 doubles per step, [1/L(j,j) | row id | 0 | band | 0]:
+   * forward  Lf[off + j*wr + 2 + d] = L(j+d, j),            d = 1..w
+   * backward Lb[off + j*wr + 2 + d] = L(b-1-j, b-1-j-d);  the row id (local row
+   * visited at the step, as an int in the low word) rides along so a step
+   * needs nothing but its record.  Arrays are padded by 2 KiB at the end. */
+  const double* Lf;
+  const double* Lb;
+  const double* invd_f;    /* 1 / L(j,j) in forward step order (m entries) */
+  const double* invd_b;    /* ... in backward step order */
   int nclass;              /* parts grouped by register sets R = ceil((w+64)/64) */
   const int* class_R;      /* host array, nclass */
   const int* class_count;  /* host array */

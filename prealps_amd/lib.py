@@ -72,6 +72,7 @@ EXPORTS = [
     "preAlps_OperatorGetPermPtr", "preAlps_hip_nparts", "preAlps_hip_reference_rhs", "preAlps_ECGSolve",
     "preAlps_hip_panel_alloc", "preAlps_hip_panel_free", "preAlps_hip_panel_to_host",
     "preAlps_hip_panel_from_host", "preAlps_hip_get_stat", "preAlps_hip_timing",
+    "preAlps_hip_timer_start", "preAlps_hip_timer_stop",
     "preAlps_hip_timing_reset", "preAlps_hip_get_time",
 ]
 
@@ -124,6 +125,7 @@ def load():
     L.preAlps_hip_panel_from_host.argtypes = [_PD, C.c_int, pd, C.c_int]
     L.preAlps_hip_get_stat.argtypes = [C.c_char_p, pd]
     L.preAlps_hip_get_time.argtypes = [C.c_char_p, pd]
+    L.preAlps_hip_timer_stop.argtypes = [pd]
     L.preAlps_hip_timing.restype = None
     L.preAlps_hip_timing_reset.restype = None
     L.preAlps_hip_shutdown.restype = None
