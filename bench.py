@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=100, help="grid points per side")
     ap.add_argument("--t", type=int, default=4, help="enlarging factor")
-    ap.add_argument("--box", type=str, default="10,10,10", help="subdomain box (nodes)")
+    ap.add_argument("--box", type=str, default="5,5,20", help="subdomain box (nodes)")
     ap.add_argument("--alg", type=str, default="odir", choices=["odir", "omin", "fused"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=8)
@@ -132,13 +132,23 @@ def main():
     m_loc, nnz_loc = int(prob.stat("rows_local")), int(prob.stat("nnz_local"))
     halo = int(prob.stat("halo_rows"))
     sec = C.c_double()
-    for _ in range(5):
+    # (a) in context: between two SpMM launches of the solver lies a whole iteration that streams the
+    #     block-Jacobi factors and seven panels through the 256 MiB Infinity Cache, so each timed launch
+    #     here is preceded by one (untimed) preconditioner apply; one event pair per launch.
+    tot = 0.0
+    for _ in range(a.spmm_reps):
+        check(L.preAlps_BlockJacobiApply(e.AP, e.Z), "BlockJacobiApply")
+        check(L.preAlps_hip_timer_start(), "timer_start")
         check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
+        check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
+        tot += sec.value
+    spmm_s = tot / a.spmm_reps
+    # (b) back to back (matrix partly resident in the Infinity Cache): reported for comparison only
     check(L.preAlps_hip_timer_start(), "timer_start")
     for _ in range(a.spmm_reps):
         check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
     check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
-    spmm_s = sec.value / a.spmm_reps
+    spmm_b2b_s = sec.value / a.spmm_reps
     # 12 B per nonzero + 4 B per row pointer + read X + write AX (8*t B per row each)
     spmm_bytes = 12.0 * nnz_loc + 4.0 * (m_loc + 1) + 8.0 * (m_loc + halo) * a.t + 8.0 * m_loc * a.t
     spmm_gbs = spmm_bytes / spmm_s / 1e9
@@ -168,7 +178,9 @@ def main():
                    "spmm_blocks": int(prob.stat("spmm_blocks"))},
         "roofline": {"kernel": "k_spmm", "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": spmm_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s},
+                     "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s,
+                     "back_to_back_launch_us": 1e6 * spmm_b2b_s,
+                     "note": "each timed launch follows one preconditioner apply (cache state of the solver loop)"},
         "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "factor_bytes": prob.stat("bj_factor_bytes"),
                          "achieved_GBs": bj_bytes / bj_s / 1e9},
     }

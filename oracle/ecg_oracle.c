@@ -202,18 +202,19 @@ static int potrf_upper(int n, double* W, int ld) {
   return 0;
 }
 
-/* B <- B U^-1, B is m x n (cblas_dtrsm Right,Upper,NoTrans,NonUnit). */
+/* B <- B U^-1, B is m x n (cblas_dtrsm Right,Upper,NoTrans,NonUnit).  Rows are
+ * independent: each thread substitutes along its own rows. */
 static void trsm_right_upper(int m, int n, const double* U, int ldu, double* B,
                              int ldb) {
-  for (int j = 0; j < n; ++j) {
-    double* bj = B + (size_t)ldb * j;
-    for (int k = 0; k < j; ++k) {
-      double u = U[k + (size_t)ldu * j];
-      const double* bk = B + (size_t)ldb * k;
-      for (int i = 0; i < m; ++i) bj[i] -= bk[i] * u;
+  double rd[128];
+  for (int j = 0; j < n; ++j) rd[j] = 1.0 / U[j + (size_t)ldu * j];
+#pragma omp parallel for schedule(static) if (m > 4096)
+  for (int i = 0; i < m; ++i) {
+    for (int j = 0; j < n; ++j) {
+      double s = B[i + (size_t)ldb * j];
+      for (int k = 0; k < j; ++k) s -= B[i + (size_t)ldb * k] * U[k + (size_t)ldu * j];
+      B[i + (size_t)ldb * j] = s * rd[j];
     }
-    double d = 1.0 / U[j + (size_t)ldu * j];
-    for (int i = 0; i < m; ++i) bj[i] *= d;
   }
 }
 
@@ -509,13 +510,11 @@ static void gram(orc_ecg_t* e, const double* A, int lda, int a, const double* B,
   for (int p = 0; p < e->P; ++p) {
     double* g = e->gpart + (size_t)p * ab;
     int r0 = e->rowpos[p], r1 = e->rowpos[p + 1];
-    for (int j = 0; j < b; ++j)
-      for (int i = 0; i < a; ++i) {
-        const double* x = A + (size_t)lda * i;
-        const double* y = B + (size_t)ldb * j;
-        double s = 0.0;
-        for (int r = r0; r < r1; ++r) s += x[r] * y[r];
-        g[i + a * j] = s;
+    for (int q = 0; q < ab; ++q) g[q] = 0.0;
+    for (int r = r0; r < r1; ++r)       /* one pass over the rows of the rank */
+      for (int j = 0; j < b; ++j) {
+        const double y = B[r + (size_t)ldb * j];
+        for (int i = 0; i < a; ++i) g[i + a * j] += A[r + (size_t)lda * i] * y;
       }
   }
   for (int j = 0; j < b; ++j)
@@ -539,7 +538,10 @@ static void panel_update(int N, const double* A, int lda, int a, const double* S
 }
 
 static void copy_cols(int N, int ncol, const double* src, double* dst) {
-  if (ncol > 0) memmove(dst, src, (size_t)N * ncol * sizeof(double));
+  if (ncol <= 0 || src == dst) return;
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < ncol; ++j)
+    memmove(dst + (size_t)N * j, src + (size_t)N * j, (size_t)N * sizeof(double));
 }
 
 /* ecg.c:98-171 + :201-221.  rhs is the concatenation of the per-rank rhs. */

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include "pa_device.h"
 
 namespace {
@@ -53,69 +54,69 @@ __device__ __forceinline__ void store_row(double* __restrict__ p, size_t row, co
 }
 
 // ---------------------------------------------------------------- SpMM ----
-// One workgroup per row block.  The block's slice of val/colind is streamed
-// into LDS with coalesced 16-B loads (the dominant HBM traffic: 12 B per
-// nonzero), the block's window of X rows is staged next to it, and each row
-// is then reduced by G lanes per panel column out of LDS; columns outside the
-// window (neighbouring parts, halo rows) are gathered from L2/HBM.
-template <int TS, int G>
+// SELL-64 SpMM.  One workgroup per block of slices of one subdomain; the
+// subdomain's own X rows (where ~90 % of the nonzeros of a box partition
+// point) are staged once into LDS with coalesced 16-B loads, every wavefront
+// then walks whole slices: lane r owns row r of the slice, keeps its TS sums
+// in registers and reads val/col of entry k at [off + k*64 + r] -- one fully
+// coalesced 512-B / 256-B load per wave instruction for the 12 B/nonzero
+// stream.  Columns outside the window (neighbour subdomains, halo rows) are
+// gathered as whole 8*TS-byte rows from L2.
+template <int TS>
+__device__ __forceinline__ void spmm_fma_row(double (&acc)[TS], double v, const double* __restrict__ xr) {
+  const double2* q = reinterpret_cast<const double2*>(xr);
+#pragma unroll
+  for (int i = 0; i < TS / 2; ++i) {
+    const double2 x = q[i];
+    acc[2 * i] = fma(v, x.x, acc[2 * i]);
+    acc[2 * i + 1] = fma(v, x.y, acc[2 * i + 1]);
+  }
+}
+
+template <int TS, bool NT>
 __global__ __launch_bounds__(WG) void k_spmm(
-    int m, const int* __restrict__ rowptr, const int* __restrict__ colind,
-    const double* __restrict__ val, const int* __restrict__ blk_row,
-    const int* __restrict__ blk_win, const int* __restrict__ order, int nlist, int nnz_cap,
-    int win_cap, const double* __restrict__ X, const double* __restrict__ Xh,
-    double* __restrict__ Y) {
-  extern __shared__ double smem[];
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const int* __restrict__ col, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
+    const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y) {
+  extern __shared__ double sx[];
   // XCD-aware order: consecutive logical blocks (which share X rows) run on one XCD.
   const int cpx = (nlist + 7) >> 3;
   const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
   if (logical >= nlist) return;
   const int b = order[logical];
-  const int r0 = blk_row[b], r1 = blk_row[b + 1];
+  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
   const int w0 = blk_win[2 * b];
   const int wlen = min(blk_win[2 * b + 1] - w0, win_cap);
-  const int k0 = rowptr[r0], k1 = rowptr[r1];
-  const int kv0 = k0 & ~1, kc0 = k0 & ~3;
-  double* sval = smem;                          // nnz_cap + 2
-  double* sx = smem + (nnz_cap + 2);            // win_cap * TS
-  int* scol = reinterpret_cast<int*>(sx + (size_t)win_cap * TS);  // nnz_cap + 8
   const int tid = threadIdx.x;
   {
-    const double2* src = reinterpret_cast<const double2*>(val + kv0);
-    const int n2 = (k1 - kv0 + 1) >> 1;
-    for (int i = tid; i < n2; i += WG) reinterpret_cast<double2*>(sval)[i] = src[i];
-    const int4* csrc = reinterpret_cast<const int4*>(colind + kc0);
-    const int n4 = (k1 - kc0 + 3) >> 2;
-    for (int i = tid; i < n4; i += WG) reinterpret_cast<int4*>(scol)[i] = csrc[i];
     const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)w0 * TS);
     const int nx2 = (wlen * TS) >> 1;
     for (int i = tid; i < nx2; i += WG) reinterpret_cast<double2*>(sx)[i] = xsrc[i];
   }
   __syncthreads();
-  constexpr int LPR = TS * G;      // lanes per row
-  constexpr int RPP = WG / LPR;    // rows per pass
-  const int lr = tid / LPR, li = tid % LPR, g = li / TS, c = li % TS;
-  for (int rowb = r0; rowb < r1; rowb += RPP) {
-    const int row = rowb + lr;
-    double acc = 0.0;
-    if (row < r1) {
-      const int ks = rowptr[row], ke = rowptr[row + 1];
-      for (int k = ks + g; k < ke; k += G) {
-        const double v = sval[k - kv0];
-        const int col = scol[k - kc0];
-        const unsigned wi = (unsigned)(col - w0);
-        double x;
-        if (wi < (unsigned)wlen) x = sx[wi * TS + c];
-        else if (col < m) x = X[(size_t)col * TS + c];
-        else x = Xh[(size_t)(col - m) * TS + c];
-        acc = fma(v, x, acc);
-      }
-    }
-    if (G > 1) {
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int s = s0 + wave; s < s1; s += WG / 64) {
+    const long long off = sl_off[s];
+    const int len = sl_len[s];
+    const int* __restrict__ cp = col + off + lane;
+    const double* __restrict__ vp = val + off + lane;
+    double acc[TS];
 #pragma unroll
-      for (int off = TS; off < LPR; off <<= 1) acc += __shfl_xor(acc, off);
+    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < len; ++k) {
+      // the matrix is streamed once: keep it out of the way of the X rows in L2
+      const double v = NT ? __builtin_nontemporal_load(vp + (size_t)k * 64) : vp[(size_t)k * 64];
+      const int cidx = NT ? __builtin_nontemporal_load(cp + (size_t)k * 64) : cp[(size_t)k * 64];
+      const unsigned wi = (unsigned)(cidx - w0);
+      if (wi < (unsigned)wlen) spmm_fma_row<TS>(acc, v, sx + (size_t)wi * TS);
+      else if (cidx < m) spmm_fma_row<TS>(acc, v, X + (size_t)cidx * TS);
+      else spmm_fma_row<TS>(acc, v, Xh + (size_t)(cidx - m) * TS);
     }
-    if (row < r1 && g == 0) Y[(size_t)row * TS + c] = acc;
+    if (lane < sl_nrows[s]) store_row<TS>(Y, (size_t)(sl_row0[s] + lane), acc);
   }
 }
 
@@ -741,41 +742,26 @@ inline int grid_rows(int m, int per_thread_rows = 1) {
     default: snprintf(g_kerr, sizeof(g_kerr), "unsupported panel stride %d", ts); return 1; \
   }
 
-template <int TS, int G>
+template <int TS>
 static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, const double* X,
                        const double* Xh, double* Y) {
   if (nlist <= 0) return 0;
-  // the X window shares the 160 KiB LDS with the matrix slice: at most 32 KiB of rows
+  // the X window shares the 160 KiB LDS of a CU with other workgroups: at most 32 KiB of rows
   int win_cap = pl->win_cap;
   if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
-  const size_t lds = (size_t)(pl->nnz_cap + 2) * 8 + (size_t)win_cap * TS * 8 +
-                     (size_t)(pl->nnz_cap + 8) * 4;
-  static size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm<TS, G>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return kfail("hipFuncSetAttribute(k_spmm)");
-    configured = lds;
-  }
+  const size_t lds = (size_t)win_cap * TS * 8;
   const int cpx = (nlist + 7) / 8;
-  hipLaunchKernelGGL((k_spmm<TS, G>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m,
-                     pl->rowptr, pl->colind, pl->val, pl->blk_row, pl->blk_win, order, nlist,
-                     pl->nnz_cap, win_cap, X, Xh, Y);
+  static int nt = -1;
+  if (nt < 0) { const char* e = getenv("PREALPS_SPMM_NT"); nt = e ? atoi(e) : 0; }
+  if (nt)
+    hipLaunchKernelGGL((k_spmm<TS, true>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
+                       pl->blk_win, order, nlist, win_cap, X, Xh, Y);
+  else
+    hipLaunchKernelGGL((k_spmm<TS, false>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
+                       pl->blk_win, order, nlist, win_cap, X, Xh, Y);
   return kfail("k_spmm");
-}
-
-template <int TS>
-static int spmm_g(const pa_spmm_plan_t* pl, const int* order, int nlist, const double* X,
-                  const double* Xh, double* Y) {
-  int lg = pl->lanes_per_row_log2;
-  while ((TS << lg) > 64) --lg;
-  switch (lg) {
-    case 0: return launch_spmm<TS, 1>(pl, order, nlist, X, Xh, Y);
-    case 1: return launch_spmm<TS, 2>(pl, order, nlist, X, Xh, Y);
-    case 2: return launch_spmm<TS, 4>(pl, order, nlist, X, Xh, Y);
-    case 3: return launch_spmm<TS, 8>(pl, order, nlist, X, Xh, Y);
-    default: return launch_spmm<TS, 16>(pl, order, nlist, X, Xh, Y);
-  }
 }
 
 constexpr int BJ_CH = 16;
@@ -827,7 +813,7 @@ int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* X
   if (phase == 0) n = pl->n_interior;
   else if (phase == 1) { order += pl->n_interior; n = pl->nblk - pl->n_interior; }
   const double* Xh = Xhalo ? Xhalo : X;
-  TS_DISPATCH(ts, return spmm_g<TS_>(pl, order, n, X, Xh, Y));
+  TS_DISPATCH(ts, return launch_spmm<TS_>(pl, order, n, X, Xh, Y));
   return 0;
 }
 

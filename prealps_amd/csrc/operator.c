@@ -30,12 +30,14 @@
 
 typedef struct {
   pa_operator_info_t info;
-  /* device CSR (local column ids) */
-  int* d_rowptr; int* d_colind; double* d_val;
+  /* device matrix: SELL-64 slices with local column ids */
+  long long* d_sl_off; int* d_sl_len; int* d_sl_row0; int* d_sl_nrows;
+  int* d_col; double* d_val;
   int lnnz;
+  double sell_entries;   /* stored entries including padding */
   /* SpMM plan */
   pa_spmm_plan_t plan;
-  int* d_blk_row; int* d_blk_win; int* d_order;
+  int* d_blk_slice; int* d_blk_win; int* d_order;
   /* halo exchange */
   int npeers;
   int* peers;        /* process ids */
@@ -88,8 +90,9 @@ void preAlps_OperatorFree(void) {
   pa_operator_t* o = &g_op;
   free(o->info.rowPos); free(o->info.perm);
   free(o->info.A.rowPtr); free(o->info.A.colInd); free(o->info.A.val);
-  pa_rt_free(o->d_rowptr); pa_rt_free(o->d_colind); pa_rt_free(o->d_val);
-  pa_rt_free(o->d_blk_row); pa_rt_free(o->d_blk_win); pa_rt_free(o->d_order);
+  pa_rt_free(o->d_sl_off); pa_rt_free(o->d_sl_len); pa_rt_free(o->d_sl_row0); pa_rt_free(o->d_sl_nrows);
+  pa_rt_free(o->d_col); pa_rt_free(o->d_val);
+  pa_rt_free(o->d_blk_slice); pa_rt_free(o->d_blk_win); pa_rt_free(o->d_order);
   free(o->peers); free(o->send_rows); free(o->recv_rows); free(o->send_cnt); free(o->recv_cnt);
   pa_rt_free(o->d_send_idx); pa_rt_free(o->d_sendbuf); pa_rt_free(o->d_halo);
   free(o->colPos_dummy);
@@ -97,87 +100,116 @@ void preAlps_OperatorFree(void) {
 }
 
 /* ------------------------------------------------------------ the plan ---- */
-/* Cut every part into row blocks of at most nnz_cap nonzeros / row_cap rows
- * and give each block the window of local X rows it stages in LDS. */
-static int build_plan(pa_operator_t* o, const int* rowptr, const int* colind) {
+/* Local CSR (local column ids) -> SELL-64 slices + workgroup blocks.  A block
+ * is a run of slices of one subdomain (at most PREALPS_SPMM_BLOCK_ROWS rows);
+ * its LDS window is the subdomain's own row range, or the PREALPS_SPMM_WIN_CAP
+ * rows around the block when the subdomain is larger than that. */
+static int build_plan(pa_operator_t* o, const int* rowptr, const int* colind, const double* val) {
   const pa_operator_info_t* in = &o->info;
   int m = in->m;
-  int nnz_cap = env_int("PREALPS_SPMM_NNZ_CAP", 2048) & ~1;
-  int win_cap = env_int("PREALPS_SPMM_WIN_CAP", 1024);
-  int row_cap = env_int("PREALPS_SPMM_ROW_CAP", 512);
-  if (nnz_cap < 64) nnz_cap = 64;
-  int maxrow = 0;
-  for (int i = 0; i < m; ++i) {
-    int l = rowptr[i + 1] - rowptr[i];
-    if (l > maxrow) maxrow = l;
-  }
-  if (maxrow > nnz_cap) nnz_cap = (maxrow + 1) & ~1;
-  /* LDS budget: val + col + window at the widest stride we may meet (16) is
-   * checked at launch; keep the static part below 64 KiB here */
-  if ((size_t)nnz_cap * 12 > 60 * 1024)
-    return PA_FAIL("a row with %d nonzeros does not fit the SpMM staging buffer", maxrow);
-  int cap_blocks = 16, nblk = 0;
-  int* blk_row = (int*)malloc((cap_blocks + 1) * sizeof(int));
-  int* blk_win = (int*)malloc(2 * cap_blocks * sizeof(int));
-  char* needs_halo = (char*)malloc(cap_blocks);
+  int win_cap = env_int("PREALPS_SPMM_WIN_CAP", 256);
+  int blk_rows = env_int("PREALPS_SPMM_BLOCK_ROWS", 256);
+  if (blk_rows < 64) blk_rows = 64;
+  blk_rows &= ~63;
+  int nslices = 0;
+  for (int p = in->part0; p < in->part1; ++p) nslices += (in->rowPos[p + 1] - in->rowPos[p] + 63) / 64;
+  long long* sl_off = (long long*)malloc(((size_t)nslices + 1) * sizeof(long long));
+  int* sl_len = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
+  int* sl_row0 = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
+  int* sl_nrows = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
+  int* sl_part = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
+  int s = 0;
+  sl_off[0] = 0;
   for (int p = in->part0; p < in->part1; ++p) {
     int pr0 = in->rowPos[p] - in->row_off, pr1 = in->rowPos[p + 1] - in->row_off;
-    int r = pr0;
-    while (r < pr1) {
-      int r1 = r, nn = 0;
-      while (r1 < pr1 && r1 - r < row_cap && nn + (rowptr[r1 + 1] - rowptr[r1]) <= nnz_cap) {
-        nn += rowptr[r1 + 1] - rowptr[r1];
-        ++r1;
-      }
-      if (r1 == r) ++r1; /* cannot happen: nnz_cap >= maxrow */
-      if (nblk == cap_blocks) {
-        cap_blocks *= 2;
-        blk_row = (int*)realloc(blk_row, (cap_blocks + 1) * sizeof(int));
-        blk_win = (int*)realloc(blk_win, 2 * cap_blocks * sizeof(int));
-        needs_halo = (char*)realloc(needs_halo, cap_blocks);
-      }
-      int w0, w1;
-      if (win_cap <= 0) { w0 = w1 = r; }
-      else if (pr1 - pr0 <= win_cap) { w0 = pr0; w1 = pr1; }
-      else {
-        int c = (r + r1) / 2;
-        w0 = c - win_cap / 2;
-        if (w0 < pr0) w0 = pr0;
-        w1 = w0 + win_cap;
-        if (w1 > pr1) { w1 = pr1; w0 = w1 - win_cap; }
-      }
-      char h = 0;
-      for (int k = rowptr[r]; k < rowptr[r1] && !h; ++k) h = colind[k] >= m;
-      blk_row[nblk] = r; blk_win[2 * nblk] = w0; blk_win[2 * nblk + 1] = w1; needs_halo[nblk] = h;
-      ++nblk;
-      r = r1;
+    for (int r = pr0; r < pr1; r += 64, ++s) {
+      int nr = pr1 - r < 64 ? pr1 - r : 64, len = 0;
+      for (int i = 0; i < nr; ++i) { int l = rowptr[r + i + 1] - rowptr[r + i]; if (l > len) len = l; }
+      sl_len[s] = len; sl_row0[s] = r; sl_nrows[s] = nr; sl_part[s] = p;
+      sl_off[s + 1] = sl_off[s] + (long long)len * 64;
     }
   }
-  blk_row[nblk] = m;
+  size_t tot = (size_t)sl_off[nslices];
+  o->sell_entries = (double)tot;
+  int* scol = (int*)malloc((tot + 64) * sizeof(int));
+  double* sval = (double*)calloc(tot + 64, sizeof(double));
+  if (!scol || !sval) return PA_FAIL("out of host memory for %zu SELL entries", tot);
+  for (int q = 0; q < nslices; ++q) {
+    int r = sl_row0[q], nr = sl_nrows[q], len = sl_len[q];
+    int* c = scol + sl_off[q];
+    double* v = sval + sl_off[q];
+    for (int i = 0; i < 64; ++i) {
+      int row = i < nr ? r + i : r;          /* unused lanes mirror the first row */
+      int l = i < nr ? rowptr[row + 1] - rowptr[row] : 0;
+      for (int k = 0; k < len; ++k) {
+        if (k < l) { c[(size_t)k * 64 + i] = colind[rowptr[row] + k]; v[(size_t)k * 64 + i] = val[rowptr[row] + k]; }
+        else { c[(size_t)k * 64 + i] = row; v[(size_t)k * 64 + i] = 0.0; } /* padding: 0 * x[row] */
+      }
+    }
+  }
+  for (size_t k = tot; k < tot + 64; ++k) scol[k] = 0;
+  /* blocks */
+  int cap_blocks = nslices > 0 ? nslices : 1, nblk = 0;
+  int* blk_slice = (int*)malloc(((size_t)cap_blocks + 1) * sizeof(int));
+  int* blk_win = (int*)malloc((size_t)2 * cap_blocks * sizeof(int));
+  char* needs_halo = (char*)malloc(cap_blocks);
+  int q = 0, max_win = 0;
+  while (q < nslices) {
+    int p = sl_part[q], q1 = q, rows = 0;
+    while (q1 < nslices && sl_part[q1] == p && rows + 64 <= blk_rows) { rows += 64; ++q1; }
+    int pr0 = in->rowPos[p] - in->row_off, pr1 = in->rowPos[p + 1] - in->row_off;
+    int r0 = sl_row0[q], r1 = sl_row0[q1 - 1] + sl_nrows[q1 - 1];
+    int w0, w1;
+    if (win_cap <= 0) { w0 = w1 = r0; }
+    else if (pr1 - pr0 <= win_cap) { w0 = pr0; w1 = pr1; }
+    else {
+      int c = (r0 + r1) / 2;
+      w0 = c - win_cap / 2;
+      if (w0 < pr0) w0 = pr0;
+      w1 = w0 + win_cap;
+      if (w1 > pr1) { w1 = pr1; w0 = w1 - win_cap; }
+    }
+    if (w1 - w0 > max_win) max_win = w1 - w0;
+    char h = 0;
+    for (int k = rowptr[r0]; k < rowptr[r1] && !h; ++k) h = colind[k] >= m;
+    blk_slice[nblk] = q; blk_win[2 * nblk] = w0; blk_win[2 * nblk + 1] = w1; needs_halo[nblk] = h;
+    ++nblk;
+    q = q1;
+  }
+  blk_slice[nblk] = nslices;
   int* order = (int*)malloc((nblk > 0 ? nblk : 1) * sizeof(int));
   int ni = 0;
   for (int b = 0; b < nblk; ++b) if (!needs_halo[b]) order[ni++] = b;
-  int k = ni;
-  for (int b = 0; b < nblk; ++b) if (needs_halo[b]) order[k++] = b;
-  o->d_blk_row = (int*)pa_rt_malloc((nblk + 1) * sizeof(int));
+  int k2 = ni;
+  for (int b = 0; b < nblk; ++b) if (needs_halo[b]) order[k2++] = b;
+  o->d_sl_off = (long long*)pa_rt_malloc(((size_t)nslices + 1) * sizeof(long long));
+  o->d_sl_len = (int*)pa_rt_malloc((nslices ? nslices : 1) * sizeof(int));
+  o->d_sl_row0 = (int*)pa_rt_malloc((nslices ? nslices : 1) * sizeof(int));
+  o->d_sl_nrows = (int*)pa_rt_malloc((nslices ? nslices : 1) * sizeof(int));
+  o->d_col = (int*)pa_rt_malloc((tot + 64) * sizeof(int));
+  o->d_val = (double*)pa_rt_malloc((tot + 64) * sizeof(double));
+  o->d_blk_slice = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
   o->d_blk_win = (int*)pa_rt_malloc((size_t)2 * (nblk > 0 ? nblk : 1) * sizeof(int));
   o->d_order = (int*)pa_rt_malloc((nblk > 0 ? nblk : 1) * sizeof(int));
-  int rc = (!o->d_blk_row || !o->d_blk_win || !o->d_order);
-  rc = rc || pa_rt_h2d(o->d_blk_row, blk_row, (nblk + 1) * sizeof(int));
+  int rc = (!o->d_sl_off || !o->d_sl_len || !o->d_sl_row0 || !o->d_sl_nrows || !o->d_col || !o->d_val ||
+            !o->d_blk_slice || !o->d_blk_win || !o->d_order);
+  rc = rc || pa_rt_h2d(o->d_sl_off, sl_off, ((size_t)nslices + 1) * sizeof(long long));
+  rc = rc || pa_rt_h2d(o->d_sl_len, sl_len, nslices * sizeof(int));
+  rc = rc || pa_rt_h2d(o->d_sl_row0, sl_row0, nslices * sizeof(int));
+  rc = rc || pa_rt_h2d(o->d_sl_nrows, sl_nrows, nslices * sizeof(int));
+  rc = rc || pa_rt_h2d(o->d_col, scol, (tot + 64) * sizeof(int));
+  rc = rc || pa_rt_h2d(o->d_val, sval, (tot + 64) * sizeof(double));
+  rc = rc || pa_rt_h2d(o->d_blk_slice, blk_slice, ((size_t)nblk + 1) * sizeof(int));
   rc = rc || pa_rt_h2d(o->d_blk_win, blk_win, (size_t)2 * nblk * sizeof(int));
   rc = rc || pa_rt_h2d(o->d_order, order, nblk * sizeof(int));
-  free(blk_row); free(blk_win); free(needs_halo); free(order);
+  free(sl_off); free(sl_len); free(sl_row0); free(sl_nrows); free(sl_part); free(scol); free(sval);
+  free(blk_slice); free(blk_win); free(needs_halo); free(order);
   if (rc) return PA_FAIL("uploading the SpMM plan failed: %s", pa_rt_error());
-  /* lanes that share a row: enough to keep a wave busy on long rows */
-  double avg = m > 0 ? (double)rowptr[m] / m : 0.0;
-  int lg = 0;
-  while (lg < 4 && (16 << lg) < avg) ++lg; /* ~16+ nonzeros per lane group */
-  lg = env_int("PREALPS_SPMM_LPR_LOG2", lg);
   pa_spmm_plan_t* pl = &o->plan;
-  pl->m = m; pl->rowptr = o->d_rowptr; pl->colind = o->d_colind; pl->val = o->d_val;
-  pl->nblk = nblk; pl->blk_row = o->d_blk_row; pl->blk_win = o->d_blk_win; pl->order = o->d_order;
-  pl->n_interior = ni; pl->nnz_cap = nnz_cap; pl->win_cap = win_cap > 0 ? win_cap : 0;
-  pl->lanes_per_row_log2 = lg;
+  pl->m = m; pl->nslices = nslices; pl->sl_off = o->d_sl_off; pl->sl_len = o->d_sl_len;
+  pl->sl_row0 = o->d_sl_row0; pl->sl_nrows = o->d_sl_nrows; pl->col = o->d_col; pl->val = o->d_val;
+  pl->nblk = nblk; pl->blk_slice = o->d_blk_slice; pl->blk_win = o->d_blk_win; pl->order = o->d_order;
+  pl->n_interior = ni; pl->win_cap = max_win;
   return 0;
 }
 
@@ -317,21 +349,14 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   for (size_t k = 0; k < lnnz; ++k) { int c = A->colInd[k]; lcol[k] = (c >= lo && c < hi) ? c - lo : m + mark[c] - 1; }
   for (size_t k = lnnz; k < lnnz + 8; ++k) lcol[k] = 0;
   free(mark); free(halo_cols);
-  o->d_rowptr = (int*)pa_rt_malloc((size_t)(m + 1) * sizeof(int));
-  o->d_colind = (int*)pa_rt_malloc((lnnz + 8) * sizeof(int));
-  o->d_val = (double*)pa_rt_malloc((lnnz + 4) * sizeof(double));
-  int rc = (!o->d_rowptr || !o->d_colind || !o->d_val);
-  rc = rc || pa_rt_h2d(o->d_rowptr, A->rowPtr, (size_t)(m + 1) * sizeof(int));
-  rc = rc || pa_rt_h2d(o->d_colind, lcol, (lnnz + 8) * sizeof(int));
-  rc = rc || pa_rt_memset(o->d_val, 0, (lnnz + 4) * sizeof(double));
-  rc = rc || pa_rt_h2d(o->d_val, A->val, lnnz * sizeof(double));
-  if (!rc && o->nsend > 0) {
+  int rc = 0;
+  if (o->nsend > 0) {
     o->d_send_idx = (int*)pa_rt_malloc((size_t)o->nsend * sizeof(int));
     rc = !o->d_send_idx || pa_rt_h2d(o->d_send_idx, send_idx, (size_t)o->nsend * sizeof(int));
   }
   free(send_idx);
   if (rc) { free(lcol); return PA_FAIL("uploading the operator failed: %s", pa_rt_error()); }
-  rc = build_plan(o, A->rowPtr, lcol);
+  rc = build_plan(o, A->rowPtr, lcol, A->val);
   free(lcol);
   if (rc) return rc;
   in->built = 1;
@@ -513,6 +538,8 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "halo_rows")) *value = o->info.halo;
   else if (!strcmp(key, "send_rows")) *value = o->nsend;
   else if (!strcmp(key, "spmm_blocks")) *value = o->plan.nblk;
+  else if (!strcmp(key, "spmm_slices")) *value = o->plan.nslices;
+  else if (!strcmp(key, "spmm_stored_entries")) *value = o->sell_entries;
   else if (!strcmp(key, "spmm_interior_blocks")) *value = o->plan.n_interior;
   else if (!strcmp(key, "bj_factor_bytes")) *value = pa_bj_factor_bytes();
   else if (!strcmp(key, "bj_max_bandwidth")) *value = pa_bj_max_bandwidth();

@@ -35,18 +35,26 @@ double pa_rt_event_elapsed_s(void* a, void* b);
 int pa_rt_num_cus(void);
 
 /* ---- SpMM (utils/cplm_v0/cplm_v0_matmult_v2.c:108-343, K1) ------------- */
+/* The local row panel in sliced-ELL form (SELL-64): rows are cut into slices
+ * of 64 consecutive rows (slices never cross a subdomain), each slice padded to
+ * its longest row and stored entry-major, so lane r of a wavefront reads
+ * val[off + k*64 + r]: every load of the 12 B/nonzero stream is coalesced.
+ * Padding entries carry value 0 and the row's own (diagonal) column. */
 typedef struct {
-  int m;                 /* local rows */
-  const int* rowptr;     /* m+1, device */
-  const int* colind;     /* local column: < m own row, >= m halo slot; device, padded by 4 */
-  const double* val;     /* device, padded by 2 */
-  int nblk;              /* row blocks */
-  const int* blk_row;    /* nblk+1: first row of each block */
-  const int* blk_win;    /* 2*nblk: [w0, w1) local columns staged in LDS */
-  const int* order;      /* block ids: interior blocks first, then blocks that read halo */
-  int n_interior;        /* how many of `order` need no halo row */
-  int nnz_cap, win_cap;  /* LDS budget the blocks were cut for */
-  int lanes_per_row_log2;/* log2(G): lanes that share one row's nonzeros */
+  int m;                    /* local rows */
+  int nslices;
+  const long long* sl_off;  /* nslices+1: offset of the slice in val / col */
+  const int* sl_len;        /* nslices: padded row length */
+  const int* sl_row0;       /* nslices: first local row */
+  const int* sl_nrows;      /* nslices: rows in the slice (<= 64) */
+  const int* col;           /* local column: < m own row, >= m halo slot */
+  const double* val;
+  int nblk;                 /* workgroup blocks: consecutive slices of one subdomain */
+  const int* blk_slice;     /* nblk+1: first slice of each block */
+  const int* blk_win;       /* 2*nblk: [w0, w1) local X rows staged in LDS */
+  const int* order;         /* block ids: interior blocks first, then blocks that read halo rows */
+  int n_interior;
+  int win_cap;              /* rows of the largest window */
 } pa_spmm_plan_t;
 /* phase 0: interior blocks, 1: halo-reading blocks, 2: all */
 int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo,
