@@ -76,10 +76,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    # rehearsal knobs for a one-GPU box: PREALPS_BENCH_BACKEND=gloo PREALPS_BENCH_ONE_DEVICE=1
+    backend = os.environ.get("PREALPS_BENCH_BACKEND", "nccl")
+    if os.environ.get("PREALPS_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import prealps_amd
     import prealps_amd.lib as pl

@@ -62,6 +62,14 @@ int preAlps_hip_set_comm(preAlps_allreduce_fn allreduce,
 int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd,
                                  const double* val, int nparts, const int* part,
                                  int scale);
+/* Plan-only mode: build the sharding and halo lists on the host without a GPU
+ * (used by the multi-process CPU tests); preAlps_BlockOperator is refused. */
+void preAlps_hip_plan_only(int on);
+/* The halo plan of this process (library-owned arrays): peers[i] gets
+ * send_rows[i] of our rows (local row ids in send_idx, peer after peer) and
+ * owns recv_rows[i] of our halo slots (their global rows in halo_cols). */
+int preAlps_OperatorGetHaloPlan(int* npeers, int** peers, int** send_rows, int** recv_rows,
+                                int** send_idx, int* nsend, int** halo_cols, int* nhalo);
 /* perm[new] = old, of the whole problem (library-owned, N ints). */
 int preAlps_OperatorGetPermPtr(int** perm, int* n);
 int preAlps_hip_nparts(void);

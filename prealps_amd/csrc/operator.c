@@ -46,6 +46,8 @@ typedef struct {
   int* send_cnt;     /* scratch: elements for the current stride */
   int* recv_cnt;
   int nsend;         /* total rows packed */
+  int* send_idx;     /* local rows packed for the peers, peer after peer */
+  int* halo_cols;    /* global row of every halo slot, ascending */
   int* d_send_idx;
   double* d_sendbuf; double* d_halo;
   int buf_ts;        /* stride the buffers are sized for */
@@ -94,6 +96,7 @@ void preAlps_OperatorFree(void) {
   pa_rt_free(o->d_col); pa_rt_free(o->d_val);
   pa_rt_free(o->d_blk_slice); pa_rt_free(o->d_blk_win); pa_rt_free(o->d_order);
   free(o->peers); free(o->send_rows); free(o->recv_rows); free(o->send_cnt); free(o->recv_cnt);
+  free(o->send_idx); free(o->halo_cols);
   pa_rt_free(o->d_send_idx); pa_rt_free(o->d_sendbuf); pa_rt_free(o->d_halo);
   free(o->colPos_dummy);
   memset(o, 0, sizeof(*o));
@@ -214,9 +217,14 @@ static int build_plan(pa_operator_t* o, const int* rowptr, const int* colind, co
 }
 
 /* -------------------------------------------------------------- build ---- */
+static int g_plan_only = 0;
+/* Host-side planning without touching the GPU (sharding, halo lists): what the
+ * multi-process CPU tests exercise.  BlockOperator is unavailable in this mode. */
+void preAlps_hip_plan_only(int on) { g_plan_only = on ? 1 : 0; }
+
 int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, const double* val,
                                  int nparts, const int* part, int scale) {
-  PA_REQUIRE_GPU();
+  if (!g_plan_only) PA_REQUIRE_GPU();
   if (g_op.info.built) preAlps_OperatorFree();
   pa_operator_t* o = &g_op;
   pa_operator_info_t* in = &o->info;
@@ -348,13 +356,15 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   int* lcol = (int*)malloc((lnnz + 8) * sizeof(int));
   for (size_t k = 0; k < lnnz; ++k) { int c = A->colInd[k]; lcol[k] = (c >= lo && c < hi) ? c - lo : m + mark[c] - 1; }
   for (size_t k = lnnz; k < lnnz + 8; ++k) lcol[k] = 0;
-  free(mark); free(halo_cols);
+  free(mark);
+  o->halo_cols = halo_cols;
+  o->send_idx = send_idx;
+  if (g_plan_only) { free(lcol); in->built = 1; return 0; }
   int rc = 0;
   if (o->nsend > 0) {
     o->d_send_idx = (int*)pa_rt_malloc((size_t)o->nsend * sizeof(int));
     rc = !o->d_send_idx || pa_rt_h2d(o->d_send_idx, send_idx, (size_t)o->nsend * sizeof(int));
   }
-  free(send_idx);
   if (rc) { free(lcol); return PA_FAIL("uploading the operator failed: %s", pa_rt_error()); }
   rc = build_plan(o, A->rowPtr, lcol, A->val);
   free(lcol);
@@ -476,6 +486,16 @@ int preAlps_OperatorGetDepPtr(int** dep, int* sizeDep) {
   *dep = g_op.peers; *sizeDep = g_op.npeers;
   return 0;
 }
+/* The halo plan of this process: peers[i] receives send_rows[i] of our rows
+ * (local indices in send_idx, peer after peer) and owns recv_rows[i] of our
+ * halo slots (global rows in halo_cols, ascending, peer after peer). */
+int preAlps_OperatorGetHaloPlan(int* npeers, int** peers, int** send_rows, int** recv_rows,
+                                int** send_idx, int* nsend, int** halo_cols, int* nhalo) {
+  if (!g_op.info.built) return PA_FAIL("operator not built");
+  *npeers = g_op.npeers; *peers = g_op.peers; *send_rows = g_op.send_rows; *recv_rows = g_op.recv_rows;
+  *send_idx = g_op.send_idx; *nsend = g_op.nsend; *halo_cols = g_op.halo_cols; *nhalo = g_op.info.halo;
+  return 0;
+}
 int preAlps_OperatorGetPermPtr(int** perm, int* n) {
   if (!g_op.info.built) return PA_FAIL("operator not built");
   *perm = g_op.info.perm; *n = g_op.info.N;
@@ -508,6 +528,7 @@ static int ensure_halo_buffers(pa_operator_t* o, int ts) {
 int preAlps_BlockOperator(CPLM_Mat_Dense_t* X, CPLM_Mat_Dense_t* AX) {
   pa_operator_t* o = &g_op;
   if (!o->info.built) return PA_FAIL("operator not built");
+  if (g_plan_only) return PA_FAIL("the operator was built in plan-only mode (no GPU)");
   if (!X || !AX || !X->val || !AX->val) return PA_FAIL(" wrong test 'X->val != NULL && AX->val != NULL'");
   int ts = pa_desc_stride(X);
   if (pa_desc_stride(AX) != ts || X->info.m != o->info.m)

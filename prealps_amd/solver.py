@@ -48,28 +48,34 @@ class DistributedHooks:
         self.torch, self.dist, self.L = torch, dist, L
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
         self.staged = dist.get_backend() != "nccl"
+        # everything the hooks do is queued on the library's own stream, so it is ordered
+        # after the kernels that produced the buffers and before the ones that consume them
+        self.stream = torch.cuda.ExternalStream(int(L.preAlps_hip_get_stream()))
         self._ar = _l.ALLREDUCE_FN(self._allreduce)
         self._ex = _l.EXCHANGE_FN(self._exchange)
         check(L.preAlps_hip_set_world(self.rank, self.size), "preAlps_hip_set_world")
         check(L.preAlps_hip_set_comm(self._ar, self._ex, None), "preAlps_hip_set_comm")
 
     def _wrap(self, ptr, count):
-        class _Buf:
-            pass
-        b = _Buf()
-        b.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False),
-                                      "version": 2, "strides": None}
-        return self.torch.as_tensor(b, device="cuda")
+        """Zero-copy float64 view of `count` doubles of device memory owned by the library."""
+        torch = self.torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        st = torch._C._construct_storage_from_data_pointer(int(ptr), dev, 8 * int(count))
+        t = torch.empty(0, dtype=torch.float64, device=dev).set_(st, 0, (int(count),), (1,))
+        if t.data_ptr() != int(ptr):
+            raise RuntimeError("could not alias library memory as a torch tensor")
+        return t
 
     def _allreduce(self, ctx, ptr, count):
         try:
-            t = self._wrap(ptr, count)
-            if self.staged:
-                h = t.cpu()
-                self.dist.all_reduce(h)
-                t.copy_(h)
-            else:
-                self.dist.all_reduce(t)
+            with self.torch.cuda.stream(self.stream):
+                t = self._wrap(ptr, count)
+                if self.staged:
+                    h = t.cpu()
+                    self.dist.all_reduce(h)
+                    t.copy_(h)
+                else:
+                    self.dist.all_reduce(t)
             return 0
         except Exception as e:  # pragma: no cover - surfaced through the C error path
             print("all-reduce hook failed:", e)
@@ -80,25 +86,26 @@ class DistributedHooks:
             dist, torch = self.dist, self.torch
             ns = sum(send_counts[i] for i in range(npeers))
             nr = sum(recv_counts[i] for i in range(npeers))
-            ts_ = self._wrap(send, max(ns, 1))
-            tr_ = self._wrap(recv, max(nr, 1))
-            if self.staged:
-                hs, hr = ts_.cpu(), torch.empty(max(nr, 1), dtype=torch.float64)
-            else:
-                hs, hr = ts_, tr_
-            ops, so, ro = [], 0, 0
-            for i in range(npeers):
-                p, sc, rc = peers[i], send_counts[i], recv_counts[i]
-                if sc:
-                    ops.append(dist.P2POp(dist.isend, hs[so:so + sc], p))
-                if rc:
-                    ops.append(dist.P2POp(dist.irecv, hr[ro:ro + rc], p))
-                so += sc
-                ro += rc
-            for w in dist.batch_isend_irecv(ops) if ops else []:
-                w.wait()
-            if self.staged and nr:
-                tr_[:nr].copy_(hr[:nr])
+            with torch.cuda.stream(self.stream):
+                ts_ = self._wrap(send, max(ns, 1))
+                tr_ = self._wrap(recv, max(nr, 1))
+                if self.staged:
+                    hs, hr = ts_.cpu(), torch.empty(max(nr, 1), dtype=torch.float64)
+                else:
+                    hs, hr = ts_, tr_
+                ops, so, ro = [], 0, 0
+                for i in range(npeers):
+                    p, sc, rc = peers[i], send_counts[i], recv_counts[i]
+                    if sc:
+                        ops.append(dist.P2POp(dist.isend, hs[so:so + sc], p))
+                    if rc:
+                        ops.append(dist.P2POp(dist.irecv, hr[ro:ro + rc], p))
+                    so += sc
+                    ro += rc
+                for w in dist.batch_isend_irecv(ops) if ops else []:
+                    w.wait()
+                if self.staged and nr:
+                    tr_[:nr].copy_(hr[:nr])
             return 0
         except Exception as e:  # pragma: no cover
             print("halo-exchange hook failed:", e)
@@ -120,7 +127,6 @@ class EcgProblem:
             import torch
             torch.cuda.set_device(dev)
             self.hooks = DistributedHooks(L)
-            use_torch_stream = True
         if use_torch_stream:
             import torch
             check(L.preAlps_hip_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)),

@@ -1,0 +1,125 @@
+"""World-size-2 (and 3) checks of the multi-process path on CPU with gloo: every
+rank plans its shard with the C library (plan-only mode, no GPU), the ranks
+exchange exactly the rows the plan lists, and the distributed product equals
+the global one; the t x t Gram blocks summed with all_reduce equal the global
+Gram.  This is the communication pattern of utils/cplm_v0/cplm_v0_matmult_v2.c
+:184-275 and src/solvers/ecg.c:427,441,513 with boundary rows only."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nparts, n, box, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import prealps_amd
+        from prealps_amd import gen
+        from prealps_amd.lib import check
+        from oracle import oracle as O
+        L = prealps_amd.load()
+        L.preAlps_hip_plan_only(1)
+        check(L.preAlps_hip_set_world(rank, world), "set_world")
+        rp, ci, v = gen.poisson3d_csr(n)
+        part, npz = gen.box_partition(n, box)
+        assert npz == nparts
+        pi, pd = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        check(L.preAlps_OperatorBuildFromCSR(n ** 3, rp.ctypes.data_as(pi), ci.ctypes.data_as(pi),
+                                             v.ctypes.data_as(pd), nparts, part.ctypes.data_as(pi), 1), "build")
+        M, m = C.c_int(), C.c_int()
+        check(L.preAlps_OperatorGetSizes(C.byref(M), C.byref(m)), "sizes")
+        m = m.value
+        A = prealps_amd.CPLM_Mat_CSR_t()
+        check(L.preAlps_OperatorGetA(C.byref(A)), "getA")
+        lrp = np.ctypeslib.as_array(A.rowPtr, shape=(m + 1,)).copy()
+        lci = np.ctypeslib.as_array(A.colInd, shape=(A.info.lnnz,)).copy()
+        lv = np.ctypeslib.as_array(A.val, shape=(A.info.lnnz,)).copy()
+        npeers, nsend, nhalo = C.c_int(), C.c_int(), C.c_int()
+        peers, srows, rrows, sidx, hcols = pi(), pi(), pi(), pi(), pi()
+        check(L.preAlps_OperatorGetHaloPlan(C.byref(npeers), C.byref(peers), C.byref(srows), C.byref(rrows),
+                                            C.byref(sidx), C.byref(nsend), C.byref(hcols), C.byref(nhalo)), "halo")
+        npeers, nsend, nhalo = npeers.value, nsend.value, nhalo.value
+        peers = [peers[i] for i in range(npeers)]
+        srows = [srows[i] for i in range(npeers)]
+        rrows = [rrows[i] for i in range(npeers)]
+        sidx = np.array([sidx[i] for i in range(nsend)], dtype=np.int64)
+        hcols = np.array([hcols[i] for i in range(nhalo)], dtype=np.int64)
+        # the global reference, identical on every rank
+        import scipy.sparse as sp
+        Ag = sp.csr_matrix((v, ci, rp), shape=(n ** 3, n ** 3))
+        B, perm, rowpos = O.permute_by_part(O.symrac_scale(Ag), part, nparts)
+        p0, p1 = rank * nparts // world, (rank + 1) * nparts // world
+        lo, hi = int(rowpos[p0]), int(rowpos[p1])
+        assert m == hi - lo
+        t = 4
+        Xg = np.random.default_rng(5).standard_normal((n ** 3, t))
+        Xl = Xg[lo:hi]
+        # halo exchange of boundary rows only, as the plan prescribes
+        send = torch.from_numpy(np.ascontiguousarray(Xl[sidx])) if nsend else torch.empty((0, t), dtype=torch.float64)
+        recv = torch.empty((nhalo, t), dtype=torch.float64)
+        ops, so, ro = [], 0, 0
+        for pr, sc, rc in zip(peers, srows, rrows):
+            if sc:
+                ops.append(dist.P2POp(dist.isend, send[so:so + sc], pr))
+            if rc:
+                ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], pr))
+            so += sc
+            ro += rc
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        halo = recv.numpy()
+        np.testing.assert_array_equal(halo, Xg[hcols])          # the right rows arrived, in order
+        # local product with [own rows | halo rows]
+        slot = {int(c): k for k, c in enumerate(hcols)}
+        lcol = np.array([c - lo if lo <= c < hi else m + slot[int(c)] for c in lci], dtype=np.int64)
+        Al = sp.csr_matrix((lv, lcol, lrp), shape=(m, m + nhalo))
+        Yl = Al @ np.vstack([Xl, halo])
+        np.testing.assert_allclose(Yl, (B @ Xg)[lo:hi], rtol=1e-13, atol=1e-13)
+        # Gram block summed over ranks
+        G = torch.from_numpy(Yl.T @ Xl)
+        dist.all_reduce(G)
+        np.testing.assert_allclose(G.numpy(), (B @ Xg).T @ Xg, rtol=1e-11, atol=1e-11)
+        rhs = np.zeros(m)
+        check(L.preAlps_hip_reference_rhs(rhs.ctypes.data_as(pd)), "rhs")
+        np.testing.assert_array_equal(rhs, O.reference_rhs(rowpos)[lo:hi])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", npeers, nhalo))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc()), 0, 0))
+
+
+@pytest.mark.parametrize("world,box,nparts", [(2, (4, 4, 4), 27), (3, (6, 6, 3), 16)])
+def test_sharded_spmm_and_gram_match_global(world, box, nparts):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nparts, 12, box, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r
+    assert sum(r[3] for r in res) > 0      # some halo rows really moved

@@ -1,0 +1,77 @@
+"""Two ranks sharing the one GPU of the test box, talking through gloo (host
+staging): the whole multi-process path -- sharded operator, halo exchange of
+boundary rows inside preAlps_BlockOperator, all-reduced t x t blocks inside
+preAlps_ECGIterate -- must reproduce the single-process oracle solve."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, alg, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["LOCAL_RANK"] = "0"
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import prealps_amd as pa
+        from prealps_amd import gen
+        from oracle import oracle as O
+        n, box, t = 16, (4, 4, 8), 4
+        rp, ci, v = gen.poisson3d_csr(n)
+        part, nparts = gen.box_partition(n, box)
+        prob = pa.EcgProblem(rp, ci, v, nparts, part, scale=True, device=0, distributed=True)
+        rhs = prob.reference_rhs()
+        algs = {"odir": (pa.ORTHODIR, O.ORTHODIR), "omin": (pa.ORTHOMIN, O.ORTHOMIN),
+                "fused": (pa.ORTHODIR_FUSED, O.ORTHODIR_FUSED)}[alg]
+        got = prob.solve(rhs, t, ortho_alg=algs[0])
+        import scipy.sparse as sp
+        A = sp.csr_matrix((v, ci, rp), shape=(n ** 3, n ** 3))
+        B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, nparts)
+        ref = O.ECG(B, rowpos, t, algs[1], O.NO_BS_RED).solve(O.reference_rhs(rowpos))
+        p0, p1 = rank * nparts // world, (rank + 1) * nparts // world
+        lo, hi = int(rowpos[p0]), int(rowpos[p1])
+        assert prob.stat("halo_rows") > 0
+        assert got.iters == ref["iters"], (got.iters, ref["iters"])
+        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-8)
+        np.testing.assert_allclose(got.x, ref["x"][lo:hi], rtol=1e-7, atol=1e-9 * np.abs(ref["x"]).max())
+        np.testing.assert_array_equal(rhs, O.reference_rhs(rowpos)[lo:hi])
+        prob.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc())))
+
+
+@pytest.mark.parametrize("alg", ["odir", "omin", "fused"])
+def test_two_ranks_one_gpu_match_oracle(alg):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, alg, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r
