@@ -181,3 +181,20 @@ def test_geometric_partition_many_small_blocks():
         assert np.linalg.norm(r) <= 2.0001 * got.final_res
     finally:
         prob.close()
+
+
+def test_c_driver_end_to_end(tmp_path, golden):
+    """examples/ecg_driver.c (the reference driver's call sequence in C) on LFAT5."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ecg_driver")
+    subprocess.check_call(["gcc", "-std=gnu11", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "ecg_driver.c"), "-L" + os.path.join(root, "prealps_amd"),
+                           "-lprealps_hip", "-Wl,-rpath," + os.path.join(root, "prealps_amd"), "-lm", "-o", exe])
+    r = subprocess.run([exe, "-m", os.path.join(GOLD, "LFAT5.mtx"), "-e", "2", "-o", "0", "-r", "0"],
+                       capture_output=True, text=True, env=dict(os.environ, PREALPS_NPARTS="2"), timeout=120)
+    assert r.returncode == 0, r.stderr
+    it = int(re.search(r"iter: (\d+)", r.stdout).group(1))
+    res = float(re.search(r"res : (\S+)", r.stdout).group(1))
+    assert it == golden["lfat5"]["np2_t2_odir"]["iters"] and res < 1e-11

@@ -72,3 +72,33 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+REF_DRIVER = "/root/reference/examples/test_ecg_prealps_op.c"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="the reference tree is not on this machine")
+def test_reference_driver_links_unchanged(tmp_path):
+    """The drop-in claim: the reference's own driver compiles against include/ and links
+    against libprealps_hip.so without a single edit (it is read where it lies, never copied)."""
+    import subprocess
+    prealps_amd.load()
+    exe = str(tmp_path / "ref_driver")
+    subprocess.check_call(["gcc", "-std=gnu99", "-w", "-I" + os.path.join(ROOT, "include", "compat"),
+                           "-I" + os.path.join(ROOT, "include"), REF_DRIVER,
+                           "-L" + os.path.join(ROOT, "prealps_amd"), "-lprealps_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "prealps_amd"), "-lm", "-o", exe])
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "-m", os.path.join(ROOT, "tests", "golden", "LFAT5.mtx"), "-e", "2"],
+                           capture_output=True, text=True, env=dict(os.environ, PREALPS_NPARTS="2"))
+        assert r.returncode != 0 and "ABORTING from" in r.stderr      # CPLM_Abort-style banner, no fallback
+
+
+def test_own_c_driver_compiles(tmp_path):
+    import subprocess
+    prealps_amd.load()
+    subprocess.check_call(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "ecg_driver.c"), "-L" + os.path.join(ROOT, "prealps_amd"),
+                           "-lprealps_hip", "-Wl,-rpath," + os.path.join(ROOT, "prealps_amd"), "-lm",
+                           "-o", str(tmp_path / "ecg_driver")])
