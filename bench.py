@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=100, help="grid points per side")
     ap.add_argument("--t", type=int, default=4, help="enlarging factor")
-    ap.add_argument("--box", type=str, default="5,5,20", help="subdomain box (nodes)")
+    ap.add_argument("--box", type=str, default="5,5,10", help="subdomain box (nodes)")
     ap.add_argument("--alg", type=str, default="odir", choices=["odir", "omin", "fused"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=8)

@@ -35,7 +35,7 @@ typedef struct {
   int* d_map_f; int* d_map_b;
   double* d_Lf; double* d_Lb; double* d_invd_f; double* d_invd_b;
   /* classes by register sets */
-  int nclass; int class_R[16]; int class_count[16]; int* class_list[16];
+  int nclass; int class_R[16]; int class_count[16]; int class_wmax[16]; int* class_list[16];
   const int* class_list_c[16];
   pa_bj_plan_t plan;
   double factor_bytes; int max_bw;
@@ -257,8 +257,9 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     for (int q = 0; q < np; ++q) {
       int R = (bw[q] + 127) / 64, c;
       for (c = 0; c < s->nclass; ++c) if (s->class_R[c] == R) break;
-      if (c == s->nclass) { s->class_R[c] = R; s->class_count[c] = 0; s->nclass++; }
+      if (c == s->nclass) { s->class_R[c] = R; s->class_count[c] = 0; s->class_wmax[c] = 0; s->nclass++; }
       cls[q] = c; s->class_count[c]++;
+      if (bw[q] > s->class_wmax[c]) s->class_wmax[c] = bw[q];
     }
     for (int c = 0; c < s->nclass && !rc; ++c) {
       int* list = (int*)malloc(s->class_count[c] * sizeof(int));
@@ -301,6 +302,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   pl->map_f = s->d_map_f; pl->map_b = s->d_map_b; pl->Lf = s->d_Lf; pl->Lb = s->d_Lb;
   pl->invd_f = s->d_invd_f; pl->invd_b = s->d_invd_b;
   pl->nclass = s->nclass; pl->class_R = s->class_R; pl->class_count = s->class_count;
+  pl->class_wmax = s->class_wmax;
   pl->class_list = s->class_list_c;
   s->created = 1;
   return 0;

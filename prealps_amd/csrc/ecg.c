@@ -49,6 +49,7 @@ typedef struct {
   double* h_pin;      /* pinned: [0] res2, [1..] scratch */
   int* h_pin_i;
   int rotate;         /* NO_BS_RED: rotate pointers instead of copying */
+  int fuse;           /* NO_BS_RED: two-pass first half (PREALPS_ECG_FUSE=0 keeps the four-pass one) */
 } ecg_priv_t;
 
 static ecg_priv_t* priv_of(preAlps_ECG_t* ecg) {
@@ -148,6 +149,7 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
   }
   publish_pointers(ecg, pv);
   pv->rotate = (ecg->bs_red == NO_BS_RED);
+  { const char* f = getenv("PREALPS_ECG_FUSE"); pv->fuse = f ? atoi(f) : 1; }
   pa_set_desc(ecg->X, M, t, m, t, ts);
   pa_set_desc(ecg->R, M, t, m, t, ts);
   pa_set_desc(ecg->Z, M, t, m, t, ts);
@@ -291,6 +293,38 @@ static int a_orthonormalise_and_alpha(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t)
   return 0;
 }
 
+/* The rci == 0 half without block-size reduction, in two passes over the panels
+ * instead of four: [W ; G^T] = [AP | R]^T P (one Gram kernel, one all-reduce),
+ * then U = chol(W), alpha = U^-T G on one wave, then P U^-1, AP U^-1, X += P alpha,
+ * R -= AP alpha and the residual column norms in a single kernel.  Algebraically
+ * ecg.c:425-443 + :500-501; alpha is formed from the Gram of the un-normalised P. */
+static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
+  int nb = 0, m = pv->m, ts = pv->ts, T = ecg->enlFac;
+  double* buf = pv->d_q; /* (t+T) x t */
+  double t0 = pa_wtime();
+  pa_time_begin(PA_T_GRAM);
+  PA_CHECK(pa_k_gram(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, &nb));
+  PA_CHECK(pa_k_finish(pv->d_partials, nb, 2, ts, t, T, t, buf, t + T));
+  pa_time_end(PA_T_GRAM);
+  ecg->gemm_t += pa_wtime() - t0;
+  t0 = pa_wtime();
+  if (pa_allreduce(buf, (t + T) * t)) return 1;
+  ecg->comm_t += pa_wtime() - t0;
+  t0 = pa_wtime();
+  pa_time_begin(PA_T_SMALL);
+  PA_CHECK(pa_k_potrf_alpha(buf, t, T, pv->d_mu, pv->d_alpha, pv->d_info));
+  pa_time_end(PA_T_SMALL);
+  ecg->potrf_t += pa_wtime() - t0;
+  t0 = pa_wtime();
+  pa_time_begin(PA_T_UPDATE);
+  PA_CHECK(pa_k_trsm_update(m, ts, t, ecg->X->info.n, pv->d_mu, pv->d_alpha, ecg->P->val, ecg->AP->val,
+                            pv->d_X, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
+  pa_time_end(PA_T_UPDATE);
+  pv->rtr_valid = 1;
+  ecg->trsm_t += pa_wtime() - t0;
+  return 0;
+}
+
 /* X += P alpha ; R -= AP alpha (ecg.c:337-338, :500-501) + residual norms */
 static int update_iterate(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   double t0 = pa_wtime();
@@ -403,9 +437,13 @@ int _preAlps_ECGIterateOdir(preAlps_ECG_t* ecg, int* rci_request) {
   if (!pv) return PA_FAIL("solver not initialised");
   int t = ecg->P->info.n;
   if (*rci_request == 0) {
-    if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
-    if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0)) return 1;
-    if (update_iterate(ecg, pv)) return 1;
+    if (ecg->bs_red == NO_BS_RED && pv->fuse) {
+      if (fused_first_half(ecg, pv, t)) return 1;
+    } else {
+      if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
+      if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0)) return 1;
+      if (update_iterate(ecg, pv)) return 1;
+    }
     ecg->iter++;
     *rci_request = 1;
   } else if (*rci_request == 1) {
@@ -423,8 +461,12 @@ int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
   int M = ecg->globPbSize, m = pv->m, ts = pv->ts, nrhs = ecg->enlFac;
   int t = ecg->P->info.n;
   if (*rci_request == 0) {
-    if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
-    if (update_iterate(ecg, pv)) return 1;
+    if (ecg->bs_red == NO_BS_RED && pv->fuse) {
+      if (fused_first_half(ecg, pv, t)) return 1;
+    } else {
+      if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
+      if (update_iterate(ecg, pv)) return 1;
+    }
     ecg->iter++;
     *rci_request = 1;
   } else if (*rci_request == 1) {

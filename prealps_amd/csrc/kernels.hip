@@ -401,6 +401,108 @@ __global__ __launch_bounds__(WG) void k_update_xr(int m, int t, int nc,
   block_sum_cols<TS>(rr, rtr + (size_t)blockIdx.x * TS);
 }
 
+// [W ; G^T] ((t+T) x t, ld t+T) -> mu = chol(W) (t x t, ld t), alpha = U^-T G (t x T, ld t).
+// One wave, everything in LDS.  (ecg.c:431 + :438 with the Gram of the
+// un-normalised P: (P U^-1)^T R = U^-T (P^T R).)
+__global__ void k_potrf_alpha(const double* __restrict__ buf, int t, int T, double* __restrict__ mu,
+                              double* __restrict__ alpha, int* __restrict__ info) {
+  __shared__ double W[16 * 16];
+  __shared__ double G[16 * 16];
+  const int ld = t + T;
+  for (int e = threadIdx.x; e < t * t; e += 64) W[e] = buf[(e % t) + ld * (e / t)];
+  for (int e = threadIdx.x; e < t * T; e += 64) { const int i = e % t, c = e / t; G[e] = buf[(t + c) + ld * i]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int fail = 0;
+    for (int j = 0; j < t; ++j) {
+      double d = W[j + t * j];
+      for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
+      if (!(d > 0.0)) { W[j + t * j] = d; fail = j + 1; break; }
+      d = sqrt(d);
+      W[j + t * j] = d;
+      for (int i = j + 1; i < t; ++i) {
+        double s = W[j + t * i];
+        for (int k = 0; k < j; ++k) s -= W[k + t * j] * W[k + t * i];
+        W[j + t * i] = s / d;
+      }
+    }
+    *info = fail;
+  }
+  __syncthreads();
+  if (threadIdx.x < T) {            // one column of alpha per lane: forward substitution with U^T
+    const int c = threadIdx.x;
+    for (int i = 0; i < t; ++i) {
+      double s = G[i + t * c];
+      for (int k = 0; k < i; ++k) s -= W[k + t * i] * G[k + t * c];
+      G[i + t * c] = s / W[i + t * i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < t * t; e += 64) mu[e] = W[e];
+  for (int e = threadIdx.x; e < t * T; e += 64) alpha[e] = G[e];
+}
+
+// P <- P U^-1, AP <- AP U^-1, X += P alpha, R -= AP alpha and the column sums of
+// R^2 in one pass over the four panels (ecg.c:434-435 + :500-501 + :250).
+template <int TS>
+__global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, const double* __restrict__ U,
+                                                    const double* __restrict__ alpha,
+                                                    double* __restrict__ P, double* __restrict__ AP,
+                                                    double* __restrict__ X, double* __restrict__ R,
+                                                    double* __restrict__ rtr) {
+  __shared__ double su[TS * TS];
+  __shared__ double sd[TS];
+  __shared__ double sa[TS * TS];
+  for (int e = threadIdx.x; e < t * t; e += WG) su[e] = U[e];
+  for (int e = threadIdx.x; e < t * nc; e += WG) sa[e] = alpha[e];
+  __syncthreads();
+  if (threadIdx.x < t) sd[threadIdx.x] = 1.0 / su[threadIdx.x + t * threadIdx.x];
+  __syncthreads();
+  double rr[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) rr[c] = 0.0;
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double p[TS], ap[TS], x[TS], r[TS];
+    load_row<TS>(P, row, p);
+    load_row<TS>(AP, row, ap);
+    load_row<TS>(X, row, x);
+    load_row<TS>(R, row, r);
+#pragma unroll
+    for (int j = 0; j < TS; ++j) {
+      if (j < t) {
+        double s1 = p[j], s2 = ap[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) { const double u = su[k + t * j]; s1 = fma(-p[k], u, s1); s2 = fma(-ap[k], u, s2); }
+        p[j] = s1 * sd[j];
+        ap[j] = s2 * sd[j];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      if (c < nc) {
+        double sx = 0.0, sr = 0.0;
+#pragma unroll
+        for (int k = 0; k < TS; ++k) {
+          if (k < t) {
+            const double a = sa[k + t * c];
+            sx = fma(p[k], a, sx);
+            sr = fma(ap[k], a, sr);
+          }
+        }
+        x[c] += sx;
+        r[c] -= sr;
+        rr[c] = fma(r[c], r[c], rr[c]);
+      }
+    }
+    store_row<TS>(P, row, p);
+    store_row<TS>(AP, row, ap);
+    store_row<TS>(X, row, x);
+    store_row<TS>(R, row, r);
+  }
+  block_sum_cols<TS>(rr, rtr + (size_t)blockIdx.x * TS);
+}
+
 template <int TS>
 __global__ __launch_bounds__(WG) void k_colnorm2(int m, const double* __restrict__ R,
                                                  double* __restrict__ rtr) {
@@ -767,10 +869,9 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
 constexpr int BJ_CH = 16;
 
 template <int TS>
-static int bj_launch(const pa_bj_plan_t* pl, int R, const int* list, int count, const double* in,
-                     double* out) {
+static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, int count,
+                     const double* in, double* out) {
   // LDS per wave: two chunk buffers of CH records of the widest band in this class
-  const int wmax = 64 * R - 64;
   const int wr = (wmax + 5) & ~1;
   int per_wave = 2 * ((BJ_CH * wr + 127) & ~127);  // doubles, each buffer a multiple of 1 KiB
   int waves = (160 * 1024) / (per_wave * 8);
@@ -877,6 +978,21 @@ int pa_k_update_xr(int m, int ts, int t, int nc, const double* alpha, const doub
   return kfail("k_update_xr");
 }
 
+int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha, int* info) {
+  hipLaunchKernelGGL(k_potrf_alpha, dim3(1), dim3(64), 0, cur_stream(), buf, t, T, mu, alpha, info);
+  return kfail("k_potrf_alpha");
+}
+
+int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double* alpha, double* P,
+                     double* AP, double* X, double* R, double* rtr_partials, int* nblk) {
+  int blocks = grid_rows(m, 2);
+  if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
+  *nblk = blocks;
+  TS_DISPATCH(ts, hipLaunchKernelGGL((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+                                     t, nc, U, alpha, P, AP, X, R, rtr_partials));
+  return kfail("k_trsm_update");
+}
+
 int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk) {
   int blocks = grid_rows(m, 4);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
@@ -931,8 +1047,8 @@ int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out)
   for (int c = 0; c < pl->nclass; ++c) {
     if (pl->class_count[c] <= 0) continue;
     int rc = 1;
-    TS_DISPATCH(ts, rc = bj_launch<TS_>(pl, pl->class_R[c], pl->class_list[c], pl->class_count[c],
-                                        in, out));
+    TS_DISPATCH(ts, rc = bj_launch<TS_>(pl, pl->class_R[c], pl->class_wmax[c], pl->class_list[c],
+                                        pl->class_count[c], in, out));
     if (rc) return rc;
   }
   return 0;

@@ -88,6 +88,12 @@ int pa_k_trsm(int m, int ts, int t, const double* U, double* P, double* AP);
  * stopping test (ecg.c:250) into rtr_partials[blk*ts + c]. */
 int pa_k_update_xr(int m, int ts, int t, int nc, const double* alpha, const double* P,
                    const double* AP, double* X, double* R, double* rtr_partials, int* nblk);
+/* buf = [W ; G^T] ((t+T) x t, leading dimension t+T) with W = AP^T P and G = P^T R of the
+ * un-normalised P  ->  mu = chol(W) (upper, t x t), alpha = U^-T G (t x T, ld t). */
+int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha, int* info);
+/* pa_k_trsm followed by pa_k_update_xr in one pass over P, AP, X, R. */
+int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double* alpha, double* P,
+                     double* AP, double* X, double* R, double* rtr_partials, int* nblk);
 /* Standalone sums of R(:,c)^2 (same layout as above). */
 int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk);
 /* res2[0] = sum over blocks and columns c < nc. */
@@ -127,6 +133,7 @@ typedef struct {
   int nclass;              /* parts grouped by register sets R = ceil((w+64)/64) */
   const int* class_R;      /* host array, nclass */
   const int* class_count;  /* host array */
+  const int* class_wmax;   /* host array: widest band in the class (sizes the LDS chunks) */
   const int* const* class_list; /* host array of device pointers to part ids */
 } pa_bj_plan_t;
 int pa_bj_max_R(void);
