@@ -7,9 +7,10 @@ torch.distributed.run, one rank per GPU) prints ONE JSON line on rank 0.
 A step = one full ECG iteration of the reference driver loop
 (examples/test_ecg_prealps_op.c:208-221): Iterate(rci 0) -> stopping test ->
 block-Jacobi apply -> Iterate(rci 1) -> SpMM, through the C ABI of
-libprealps_hip.so.  Workload at N=1: BASELINE.json configs[1], synthetic 7-pt
-3-D Poisson n = 100^3, t = 4, block-Jacobi, fp64, inputs resident in HBM
-before the timed region.  If the solve converges inside the timed region it
+libprealps_hip.so.  Default workload = what BASELINE.json's metric is quoted on:
+3-D elasticity, n ~ 1M dofs (Q1 hexahedra on 70^3 nodes, N = 1,029,000,
+nnz = 80,990,208), t = 4, block-Jacobi, fp64, inputs resident in HBM before the
+timed region.  `--workload poisson` runs BASELINE configs[1] (7-pt Poisson 100^3).  If the solve converges inside the timed region it
 is restarted from the same rhs (the restart is inside the timing).
 """
 import argparse
@@ -32,9 +33,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=100, help="grid points per side")
+    ap.add_argument("--workload", type=str, default="elasticity", choices=["poisson", "elasticity"])
+    ap.add_argument("--n", type=int, default=0, help="grid points (nodes) per side; default 100 (poisson) / 70 (elasticity)")
     ap.add_argument("--t", type=int, default=4, help="enlarging factor")
-    ap.add_argument("--box", type=str, default="5,5,10", help="subdomain box (nodes)")
+    ap.add_argument("--box", type=str, default="", help="subdomain box in nodes; default 5,5,10 (poisson) / 4,4,4 (elasticity)")
     ap.add_argument("--alg", type=str, default="odir", choices=["odir", "omin", "fused"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=8)
@@ -43,30 +45,14 @@ def parse():
 
 
 def run_iterations(prob, e, rhs, L, nsteps, state):
-    """Advance the reference driver loop by nsteps full iterations."""
-    import prealps_amd.lib as pl
+    """Advance the reference driver loop by nsteps full iterations (the loop itself is C:
+    preAlps_ECGAdvance, the same calls examples/test_ecg_prealps_op.c:208-221 makes)."""
     from prealps_amd.lib import check
-    rci, stop = state["rci"], C.c_int(0)
-    done = 0
-    while done < nsteps:
-        check(L.preAlps_ECGIterate(C.byref(e), C.byref(rci)), "ECGIterate")
-        if rci.value == 0:
-            check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
-            done += 1
-        else:
-            check(L.preAlps_ECGStoppingCriterion(C.byref(e), C.byref(stop)), "StoppingCriterion")
-            if stop.value == 1:
-                # converged: start again from the same rhs (counted in the timing)
-                state["restarts"] += 1
-                state["last_iters"] = e.iter
-                state["last_res"] = e.res
-                check(L._preAlps_ECGReset(C.byref(e), rhs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(rci)), "ECGReset")
-                check(L.preAlps_BlockJacobiApply(e.R, e.P), "BlockJacobiApply")
-                check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
-                done += 1
-                continue
-            src = e.R if e.ortho_alg == pl.ORTHOMIN else e.AP
-            check(L.preAlps_BlockJacobiApply(src, e.Z), "BlockJacobiApply")
+    restarts, last_it, last_res = C.c_int(0), C.c_int(state["last_iters"]), C.c_double(state["last_res"])
+    check(L.preAlps_ECGAdvance(C.byref(e), rhs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(state["rci"]),
+                               nsteps, C.byref(restarts), C.byref(last_it), C.byref(last_res)), "ECGAdvance")
+    state["restarts"] += restarts.value
+    state["last_iters"], state["last_res"] = last_it.value, last_res.value
 
 
 def main():
@@ -93,15 +79,24 @@ def main():
     from prealps_amd import gen
     from prealps_amd.lib import check
 
+    if a.n == 0:
+        a.n = 100 if a.workload == "poisson" else 70
+    if not a.box:
+        a.box = "5,5,10" if a.workload == "poisson" else "4,4,4"
     box = tuple(int(x) for x in a.box.split(","))
-    rowptr, colind, val = gen.poisson3d_csr(a.n)
-    part, nparts = gen.box_partition(a.n, box)
-    N, nnz = a.n ** 3, len(val)
+    if a.workload == "poisson":
+        rowptr, colind, val = gen.poisson3d_csr(a.n)
+        part, nparts = gen.box_partition(a.n, box)
+        N, wname = a.n ** 3, "BASELINE configs[1]: synthetic 7-pt 3-D Poisson SPD CSR %d^3" % a.n
+    else:
+        rowptr, colind, val = gen.elasticity3d_csr(a.n)
+        part, nparts = gen.box_partition_nodes(a.n, box)
+        N, wname = 3 * a.n ** 3, "Q1 3-D elasticity, %d^3 nodes, nu=0.25, stiff/soft inclusions (SURVEY A.3 structure)" % a.n
+    nnz = len(val)
     t_setup = time.perf_counter()
     prob = prealps_amd.EcgProblem(rowptr, colind, val, nparts, part, scale=True, device=local_rank,
                                   distributed=distributed)
     L = prob.L
-    L._preAlps_ECGReset.argtypes = [C.POINTER(pl.preAlps_ECG_t), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     prob.create_block_jacobi()
     t_setup = time.perf_counter() - t_setup
     rhs = prob.reference_rhs()
@@ -170,25 +165,24 @@ def main():
     # counters cannot be read from inside the process, so the committed summary is quoted when
     # the workload is the one it was collected on.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if world == 1 and (a.n, a.t, a.box) == (100, 4, "5,5,20") and os.path.exists(pmc):
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_elasticity.json")
+    if world == 1 and (a.workload, a.n, a.t, a.box) == ("elasticity", 70, 4, "4,4,4") and os.path.exists(pmc):
         with open(pmc) as f:
             traffic = json.load(f)["k_spmm"]["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r01_pmc_hbm_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+        traffic_src = "profiles/r01_pmc_hbm_traffic_elasticity.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
 
     out = {
         "metric": "ECG iters/sec + SpMM HBM GB/s (% roofline), 3D-elasticity n~1M t=4",
         "value": its, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: synthetic 7-pt 3-D Poisson SPD CSR %d^3 (N=%d, nnz=%d), "
-                               "ECG %s + block-Jacobi, t=%d, tol 1e-5" % (a.n, N, nnz, a.alg, a.t),
+        "config": {"workload": "%s (N=%d, nnz=%d), ECG %s + block-Jacobi, t=%d, tol 1e-5" % (wname, N, nnz, a.alg, a.t),
                    "nparts": int(nparts), "subdomain_box": list(box), "parallelism": "rows x%d" % world,
                    "restarts_in_timed_region": state["restarts"],
                    "iterations_to_converge": state["last_iters"], "setup_seconds": t_setup,
                    "bj_max_bandwidth": int(prob.stat("bj_max_bandwidth")),
                    "spmm_blocks": int(prob.stat("spmm_blocks"))},
-        "roofline": {"kernel": "k_spmm", "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "k_spmm_staged" if prob.stat("spmm_staged") else "k_spmm", "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": spmm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s,
                      "back_to_back_launch_us": 1e6 * spmm_b2b_s,
@@ -201,7 +195,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu:
         from oracle import oracle as O
         import scipy.sparse as sp
-        A = sp.csr_matrix((val, colind, rowptr), shape=(N, N))
+        A = sp.csr_matrix((val, colind.astype(np.int32), rowptr), shape=(N, N))
         B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, nparts)
         tf0 = time.perf_counter()
         ecg = O.ECG(B, rowpos, a.t, O.ORTHODIR if a.alg == "odir" else O.ORTHOMIN, O.NO_BS_RED, 1e-5, a.cpu_iters)

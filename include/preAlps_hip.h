@@ -82,6 +82,11 @@ int preAlps_hip_reference_rhs(double* rhs_local);
  * examples/test_ecg_bench_fused.c:243-259). res_hist may be NULL. */
 int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol,
                      double* res_hist, int* bs_hist, int max_hist, int* n_hist);
+/* The same loop advanced by nsteps full iterations from the current RCI state,
+ * restarting from rhs when the stopping test fires (counts go to the optional
+ * out-parameters).  Used for timing a fixed number of iterations. */
+int preAlps_ECGAdvance(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int nsteps, int* restarts,
+                       int* last_iters, double* last_res);
 /* Device panel <-> host column-major array (ld >= m). */
 int preAlps_hip_panel_alloc(CPLM_Mat_Dense_t* A, int M, int N, int m, int n, int enlFac);
 void preAlps_hip_panel_free(CPLM_Mat_Dense_t* A);

@@ -225,11 +225,10 @@ static int fetch_res2(preAlps_ECG_t* ecg, ecg_priv_t* pv, double* res2, int* inf
   double t0 = pa_wtime();
   if (pa_allreduce(pv->d_res2, 1)) return 1;
   ecg->comm_t += pa_wtime() - t0;
-  PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->d_res2, sizeof(double)));
-  PA_CHECK(pa_rt_d2h_async(pv->h_pin_i, pv->d_info, sizeof(int)));
+  PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->d_res2, 2 * sizeof(double)));
   PA_CHECK(pa_rt_sync());
   *res2 = pv->h_pin[0];
-  *info = pv->h_pin_i[0];
+  *info = (int)pv->h_pin[1];
   return 0;
 }
 
@@ -242,7 +241,7 @@ int preAlps_ECGStoppingCriterion(preAlps_ECG_t* ecg, int* stop) {
   if (!pv->rtr_valid) {
     PA_CHECK(pa_k_colnorm2(pv->m, pv->ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
   }
-  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2));
+  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2, pv->d_info));
   pv->rtr_valid = 0;
   double res2 = 0.0; int info = 0;
   if (fetch_res2(ecg, pv, &res2, &info)) return 1;
@@ -533,7 +532,7 @@ int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
   /* R has not changed since the previous call's update: its column norms are
    * already there, except on the first call */
   if (!pv->rtr_valid) PA_CHECK(pa_k_colnorm2(m, ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
-  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, ts, nrhs, pv->d_rtr));
+  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, ts, nrhs, pv->d_rtr, NULL));
   pa_time_end(PA_T_GRAM);
   ecg->gemm_t += pa_wtime() - t0;
   t0 = pa_wtime();
@@ -683,5 +682,36 @@ int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_h
   }
   if (n_hist) *n_hist = nh < max_hist ? nh : max_hist;
   if (sol) return preAlps_ECGFinalize(ecg, sol);
+  return 0;
+}
+
+/* Advance the driver loop (examples/test_ecg_prealps_op.c:208-221) by nsteps full
+ * iterations, restarting from the same rhs (as after preAlps_ECGInitialize) whenever the
+ * stopping test fires; what bench.py times.  Two-phase variants only. */
+int preAlps_ECGAdvance(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int nsteps, int* restarts,
+                       int* last_iters, double* last_res) {
+  int stop = 0, done = 0;
+  if (ecg->ortho_alg == ORTHODIR_FUSED) return PA_FAIL("preAlps_ECGAdvance drives the two-phase variants");
+  while (done < nsteps) {
+    if (preAlps_ECGIterate(ecg, rci_request)) return 1;
+    if (*rci_request == 0) {
+      if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+      ++done;
+    } else {
+      if (preAlps_ECGStoppingCriterion(ecg, &stop)) return 1;
+      if (stop == 1) {
+        if (restarts) ++*restarts;
+        if (last_iters) *last_iters = ecg->iter;
+        if (last_res) *last_res = ecg->res;
+        if (_preAlps_ECGReset(ecg, rhs, rci_request)) return 1;
+        if (preAlps_BlockJacobiApply(ecg->R, ecg->P)) return 1;
+        if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+        ++done;
+        continue;
+      }
+      if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
+      else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+    }
+  }
   return 0;
 }

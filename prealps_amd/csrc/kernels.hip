@@ -120,6 +120,62 @@ __global__ __launch_bounds__(WG) void k_spmm(
   }
 }
 
+// Staged SELL-64 SpMM: the block first copies every X row it will touch into
+// LDS (own rows as one coalesced range, then the listed neighbour / halo rows,
+// 16 B per lane), so the inner loop is branch-free: one coalesced 8-B value,
+// one coalesced 2-B LDS slot, TS/2 ds_read_b128 and TS FMAs per nonzero, and
+// the matrix stream shrinks from 12 to 10 bytes per nonzero.
+template <int TS>
+__global__ __launch_bounds__(WG) void k_spmm_staged(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ col16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ ext_rows, const int* __restrict__ order, int nlist,
+    const double* __restrict__ X, const double* __restrict__ Xh, double* __restrict__ Y) {
+  extern __shared__ double sx[];
+  const int cpx = (nlist + 7) >> 3;
+  const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  if (logical >= nlist) return;
+  const int b = order[logical];
+  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
+  const int r0 = sl_row0[s0];
+  const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
+  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0;
+  const int tid = threadIdx.x;
+  constexpr int H = TS / 2;  // double2 per row
+  {
+    const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)r0 * TS);
+    double2* dst = reinterpret_cast<double2*>(sx);
+    for (int i = tid; i < nown * H; i += WG) dst[i] = xsrc[i];
+    for (int q = tid; q < next * H; q += WG) {
+      const int i = q / H, j = q - i * H;
+      const int id = ext_rows[e0 + i];
+      const double2* src = reinterpret_cast<const double2*>(id < m ? X + (size_t)id * TS
+                                                                     : Xh + (size_t)(id - m) * TS);
+      dst[(size_t)(nown + i) * H + j] = src[j];
+    }
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int s = s0 + wave; s < s1; s += WG / 64) {
+    const long long off = sl_off[s];
+    const int len = sl_len[s];
+    const unsigned short* __restrict__ cp = col16 + off + lane;
+    const double* __restrict__ vp = val + off + lane;
+    double acc[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < len; ++k) {
+      const double v = vp[(size_t)k * 64];
+      const int slot = cp[(size_t)k * 64];
+      spmm_fma_row<TS>(acc, v, sx + (size_t)slot * TS);
+    }
+    if (lane < sl_nrows[s]) store_row<TS>(Y, (size_t)(sl_row0[s] + lane), acc);
+  }
+}
+
 template <int TS>
 __global__ __launch_bounds__(WG) void k_pack_rows(int n, const int* __restrict__ idx,
                                                   const double* __restrict__ X,
@@ -520,7 +576,8 @@ __global__ __launch_bounds__(WG) void k_colnorm2(int m, const double* __restrict
 }
 
 __global__ __launch_bounds__(WG) void k_trace_finish(const double* __restrict__ rtr, int nblk,
-                                                     int ts, int nc, double* __restrict__ res2) {
+                                                     int ts, int nc, double* __restrict__ res2,
+                                                     const int* __restrict__ info) {
   __shared__ double red[WG];
   double s = 0.0;
   for (int b = threadIdx.x; b < nblk; b += WG)
@@ -531,7 +588,8 @@ __global__ __launch_bounds__(WG) void k_trace_finish(const double* __restrict__ 
     if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) res2[0] = red[0];
+  // res2[1] carries the Cholesky status so the host fetches both with one copy
+  if (threadIdx.x == 0) { res2[0] = red[0]; res2[1] = info ? (double)info[0] : 0.0; }
 }
 
 // Z(:, :nc) -= [V0(:, :a_lo) | V1(:, :a_hi)] beta
@@ -848,6 +906,21 @@ template <int TS>
 static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, const double* X,
                        const double* Xh, double* Y) {
   if (nlist <= 0) return 0;
+  if (pl->staged) {
+    const size_t lds = (size_t)pl->stage_cap * TS * 8;
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_staged<TS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return kfail("hipFuncSetAttribute(k_spmm_staged)");
+      configured = lds;
+    }
+    const int cpx = (nlist + 7) / 8;
+    hipLaunchKernelGGL((k_spmm_staged<TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
+                       pl->blk_ext_off, pl->ext_rows, order, nlist, X, Xh, Y);
+    return kfail("k_spmm_staged");
+  }
   // the X window shares the 160 KiB LDS of a CU with other workgroups: at most 32 KiB of rows
   int win_cap = pl->win_cap;
   if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
@@ -866,14 +939,12 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
   return kfail("k_spmm");
 }
 
-constexpr int BJ_CH = 16;
-
-template <int TS>
-static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, int count,
-                     const double* in, double* out) {
+template <int TS, int CH>
+static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, int count,
+                        const double* in, double* out) {
   // LDS per wave: two chunk buffers of CH records of the widest band in this class
   const int wr = (wmax + 5) & ~1;
-  int per_wave = 2 * ((BJ_CH * wr + 127) & ~127);  // doubles, each buffer a multiple of 1 KiB
+  int per_wave = 2 * ((CH * wr + 127) & ~127);  // doubles, each buffer a multiple of 1 KiB
   int waves = (160 * 1024) / (per_wave * 8);
   if (waves > 4) waves = 4;
   if (waves < 1) { snprintf(g_kerr, sizeof(g_kerr), "block-Jacobi band too wide for LDS (R=%d)", R); return 1; }
@@ -883,14 +954,14 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
   case RR: {                                                                                      \
     static size_t configured = 0;                                                                 \
     if (lds > 64 * 1024 && lds > configured) {                                                    \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply<TS, RR, BJ_CH>),          \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply<TS, RR, CH>),             \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return kfail("hipFuncSetAttribute(k_bj_apply)");                                          \
       configured = lds;                                                                           \
     }                                                                                             \
-    hipLaunchKernelGGL((k_bj_apply<TS, RR, BJ_CH>), dim3(blocks), dim3(64 * waves), lds,          \
+    hipLaunchKernelGGL((k_bj_apply<TS, RR, CH>), dim3(blocks), dim3(64 * waves), lds,             \
                        cur_stream(), list, count, pl->row0, pl->nrows, pl->bw, pl->off,           \
-                       pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, per_wave, in, out);                  \
+                       pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, per_wave, in, out); \
   } break;
   switch (R) {
     BJ_CASE(1) BJ_CASE(2) BJ_CASE(3) BJ_CASE(4) BJ_CASE(5) BJ_CASE(6) BJ_CASE(7) BJ_CASE(8)
@@ -900,6 +971,15 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
   }
 #undef BJ_CASE
   return kfail("k_bj_apply");
+}
+
+template <int TS>
+static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, int count,
+                     const double* in, double* out) {
+  static int ch = -1;
+  if (ch < 0) { const char* e = getenv("PREALPS_BJ_CH"); ch = e ? atoi(e) : 16; }
+  if (ch == 8) return bj_launch_ch<TS, 8>(pl, R, wmax, list, count, in, out);
+  return bj_launch_ch<TS, 16>(pl, R, wmax, list, count, in, out);
 }
 
 extern "C" {
@@ -1002,9 +1082,10 @@ int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nbl
   return kfail("k_colnorm2");
 }
 
-int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2) {
+int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2,
+                      const int* info) {
   hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, nblk, ts, nc,
-                     res2);
+                     res2, info);
   return kfail("k_trace_finish");
 }
 

@@ -38,6 +38,10 @@ typedef struct {
   /* SpMM plan */
   pa_spmm_plan_t plan;
   int* d_blk_slice; int* d_blk_win; int* d_order;
+  unsigned short* d_col16; int* d_blk_ext_off; int* d_ext_rows;
+  int* lcol;             /* host: local column ids of the panel (own rows < m <= halo slots) */
+  int plan_ts;           /* panel stride the current SpMM plan was cut for (0: none) */
+  double stream_bytes;   /* bytes of matrix data one SpMM streams */
   /* halo exchange */
   int npeers;
   int* peers;        /* process ids */
@@ -88,13 +92,23 @@ static int part_of_row(const int* rowPos, int nparts, int row) {
 }
 
 /* --------------------------------------------------------------- free ---- */
-void preAlps_OperatorFree(void) {
-  pa_operator_t* o = &g_op;
-  free(o->info.rowPos); free(o->info.perm);
-  free(o->info.A.rowPtr); free(o->info.A.colInd); free(o->info.A.val);
+static void free_plan(pa_operator_t* o) {
   pa_rt_free(o->d_sl_off); pa_rt_free(o->d_sl_len); pa_rt_free(o->d_sl_row0); pa_rt_free(o->d_sl_nrows);
   pa_rt_free(o->d_col); pa_rt_free(o->d_val);
   pa_rt_free(o->d_blk_slice); pa_rt_free(o->d_blk_win); pa_rt_free(o->d_order);
+  pa_rt_free(o->d_col16); pa_rt_free(o->d_blk_ext_off); pa_rt_free(o->d_ext_rows);
+  o->d_sl_off = NULL; o->d_sl_len = o->d_sl_row0 = o->d_sl_nrows = o->d_col = NULL; o->d_val = NULL;
+  o->d_blk_slice = o->d_blk_win = o->d_order = NULL; o->d_col16 = NULL; o->d_blk_ext_off = o->d_ext_rows = NULL;
+  memset(&o->plan, 0, sizeof(o->plan));
+  o->plan_ts = 0;
+}
+
+void preAlps_OperatorFree(void) {
+  pa_operator_t* o = &g_op;
+  free_plan(o);
+  free(o->lcol);
+  free(o->info.rowPos); free(o->info.perm);
+  free(o->info.A.rowPtr); free(o->info.A.colInd); free(o->info.A.val);
   free(o->peers); free(o->send_rows); free(o->recv_rows); free(o->send_cnt); free(o->recv_cnt);
   free(o->send_idx); free(o->halo_cols);
   pa_rt_free(o->d_send_idx); pa_rt_free(o->d_sendbuf); pa_rt_free(o->d_halo);
@@ -107,9 +121,27 @@ void preAlps_OperatorFree(void) {
  * is a run of slices of one subdomain (at most PREALPS_SPMM_BLOCK_ROWS rows);
  * its LDS window is the subdomain's own row range, or the PREALPS_SPMM_WIN_CAP
  * rows around the block when the subdomain is larger than that. */
-static int build_plan(pa_operator_t* o, const int* rowptr, const int* colind, const double* val) {
+static int build_plan_staged(pa_operator_t* o, int ts);
+
+static int build_plan(pa_operator_t* o, int ts) {
   const pa_operator_info_t* in = &o->info;
+  const int* rowptr = in->A.rowPtr;
+  const int* colind = o->lcol;
+  const double* val = in->A.val;
   int m = in->m;
+  free_plan(o);
+  /* -1 (default): stage when the external rows a block copies are small next to its matrix
+   * slice (long rows: elasticity); short rows (7-point stencils) gather through L2 instead */
+  int want = env_int("PREALPS_SPMM_STAGED", -1);
+  if (want != 0) {
+    int rc = build_plan_staged(o, ts);
+    if (rc < 0) return 1;
+    if (rc == 0) {
+      double ext_bytes = (o->stream_bytes - 10.0 * o->sell_entries) / 4.0 * ts * 8.0;
+      if (want > 0 || ext_bytes < 0.25 * 10.0 * o->sell_entries) { o->plan_ts = ts; return 0; }
+    }
+    free_plan(o); /* too many rows to stage, or not worth it: use the general kernel */
+  }
   int win_cap = env_int("PREALPS_SPMM_WIN_CAP", 256);
   int blk_rows = env_int("PREALPS_SPMM_BLOCK_ROWS", 256);
   if (blk_rows < 64) blk_rows = 64;
@@ -213,7 +245,161 @@ static int build_plan(pa_operator_t* o, const int* rowptr, const int* colind, co
   pl->sl_row0 = o->d_sl_row0; pl->sl_nrows = o->d_sl_nrows; pl->col = o->d_col; pl->val = o->d_val;
   pl->nblk = nblk; pl->blk_slice = o->d_blk_slice; pl->blk_win = o->d_blk_win; pl->order = o->d_order;
   pl->n_interior = ni; pl->win_cap = max_win;
+  o->stream_bytes = 12.0 * (double)tot;
+  o->plan_ts = ts;
   return 0;
+}
+
+/* Staged plan for panel stride ts.  Returns 0 on success, -1 on error, 1 when
+ * some 64-row slice references more rows than fit the LDS staging area. */
+static int build_plan_staged(pa_operator_t* o, int ts) {
+  const pa_operator_info_t* in = &o->info;
+  const int* rowptr = in->A.rowPtr;
+  const int* colind = o->lcol;
+  const double* val = in->A.val;
+  int m = in->m, ncols = m + in->halo;
+  int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", 32768) / (ts * 8);
+  if (cap_rows > 65535) cap_rows = 65535;
+  int blk_rows = env_int("PREALPS_SPMM_BLOCK_ROWS", 256);
+  if (blk_rows < 64) blk_rows = 64;
+  blk_rows &= ~63;
+  if (blk_rows > cap_rows) blk_rows = cap_rows & ~63;
+  if (blk_rows < 64) return 1;
+  int nslices = 0;
+  for (int p = in->part0; p < in->part1; ++p) nslices += (in->rowPos[p + 1] - in->rowPos[p] + 63) / 64;
+  long long* sl_off = (long long*)malloc(((size_t)nslices + 1) * sizeof(long long));
+  int* sl_len = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
+  int* sl_row0 = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
+  int* sl_nrows = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
+  int* sl_part = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
+  int s = 0;
+  sl_off[0] = 0;
+  for (int p = in->part0; p < in->part1; ++p) {
+    int pr0 = in->rowPos[p] - in->row_off, pr1 = in->rowPos[p + 1] - in->row_off;
+    for (int r = pr0; r < pr1; r += 64, ++s) {
+      int nr = pr1 - r < 64 ? pr1 - r : 64, len = 0;
+      for (int i = 0; i < nr; ++i) { int l = rowptr[r + i + 1] - rowptr[r + i]; if (l > len) len = l; }
+      sl_len[s] = len; sl_row0[s] = r; sl_nrows[s] = nr; sl_part[s] = p;
+      sl_off[s + 1] = sl_off[s] + (long long)len * 64;
+    }
+  }
+  size_t tot = (size_t)sl_off[nslices];
+  /* blocks: runs of slices of one subdomain; shrink until everything they touch fits */
+  int* blk_slice = (int*)malloc(((size_t)nslices + 1) * sizeof(int));
+  int* blk_ext_off = (int*)malloc(((size_t)nslices + 1) * sizeof(int));
+  char* needs_halo = (char*)malloc(nslices ? nslices : 1);
+  int* stamp = (int*)calloc(ncols ? ncols : 1, sizeof(int));   /* block id + 1 that last saw the column */
+  int* slot_of = (int*)malloc((ncols ? ncols : 1) * sizeof(int));
+  size_t ext_cap = 1024, next_tot = 0;
+  int* ext_rows = (int*)malloc(ext_cap * sizeof(int));
+  unsigned short* c16 = (unsigned short*)malloc((tot + 64) * sizeof(unsigned short));
+  double* sval = (double*)calloc(tot + 64, sizeof(double));
+  int nblk = 0, q = 0, max_stage = 0, overflow = 0, gen = 0;
+  (void)sl_part;
+  if (!c16 || !sval || !stamp || !slot_of) { overflow = -1; }
+  while (q < nslices && !overflow) {
+    /* staged blocks may span consecutive subdomains: fewer external rows per row */
+    int nsl = 0;
+    while (q + nsl < nslices && (nsl + 1) * 64 <= blk_rows) ++nsl;
+    for (;;) {
+      int r0 = sl_row0[q], r1 = sl_row0[q + nsl - 1] + sl_nrows[q + nsl - 1];
+      int nown = r1 - r0, next = 0;
+      size_t mark0 = next_tot;
+      char h = 0;
+      ++gen;
+      for (int k = rowptr[r0]; k < rowptr[r1]; ++k) {
+        int c = colind[k];
+        if (c >= r0 && c < r1) continue;
+        if (stamp[c] != gen) {
+          stamp[c] = gen;
+          if (next_tot == ext_cap) { ext_cap *= 2; ext_rows = (int*)realloc(ext_rows, ext_cap * sizeof(int)); }
+          ext_rows[next_tot++] = c; ++next;
+          if (c >= m) h = 1;
+        }
+      }
+      if (nown + next > cap_rows) {
+        next_tot = mark0;
+        if (nsl == 1) { overflow = 1; break; }
+        nsl = (nsl + 1) / 2;
+        continue;
+      }
+      /* external rows in ascending order (neighbouring rows end up adjacent in LDS and in L2) */
+      int* er = ext_rows + mark0;
+      for (int a = 1; a < next; ++a) { int v = er[a], b2 = a; while (b2 > 0 && er[b2 - 1] > v) { er[b2] = er[b2 - 1]; --b2; } er[b2] = v; }
+      for (int a = 0; a < next; ++a) slot_of[er[a]] = nown + a;
+      for (int sq = q; sq < q + nsl; ++sq) {
+        int r = sl_row0[sq], nr = sl_nrows[sq], len = sl_len[sq];
+        unsigned short* cc = c16 + sl_off[sq];
+        double* vv = sval + sl_off[sq];
+        for (int i = 0; i < 64; ++i) {
+          int row = i < nr ? r + i : r;
+          int l = i < nr ? rowptr[row + 1] - rowptr[row] : 0;
+          for (int k = 0; k < len; ++k) {
+            if (k < l) {
+              int c = colind[rowptr[row] + k];
+              cc[(size_t)k * 64 + i] = (unsigned short)((c >= r0 && c < r1) ? c - r0 : slot_of[c]);
+              vv[(size_t)k * 64 + i] = val[rowptr[row] + k];
+            } else { cc[(size_t)k * 64 + i] = (unsigned short)(row - r0); vv[(size_t)k * 64 + i] = 0.0; }
+          }
+        }
+      }
+      if (nown + next > max_stage) max_stage = nown + next;
+      blk_slice[nblk] = q; blk_ext_off[nblk] = (int)mark0; needs_halo[nblk] = h;
+      ++nblk;
+      q += nsl;
+      break;
+    }
+  }
+  int rc = overflow;
+  if (!rc) {
+    blk_slice[nblk] = nslices; blk_ext_off[nblk] = (int)next_tot;
+    for (size_t k = tot; k < tot + 64; ++k) c16[k] = 0;
+    int* order = (int*)malloc((nblk > 0 ? nblk : 1) * sizeof(int));
+    int ni = 0;
+    for (int b = 0; b < nblk; ++b) if (!needs_halo[b]) order[ni++] = b;
+    int k2 = ni;
+    for (int b = 0; b < nblk; ++b) if (needs_halo[b]) order[k2++] = b;
+    o->d_sl_off = (long long*)pa_rt_malloc(((size_t)nslices + 1) * sizeof(long long));
+    o->d_sl_len = (int*)pa_rt_malloc((nslices ? nslices : 1) * sizeof(int));
+    o->d_sl_row0 = (int*)pa_rt_malloc((nslices ? nslices : 1) * sizeof(int));
+    o->d_sl_nrows = (int*)pa_rt_malloc((nslices ? nslices : 1) * sizeof(int));
+    o->d_col16 = (unsigned short*)pa_rt_malloc((tot + 64) * sizeof(unsigned short));
+    o->d_val = (double*)pa_rt_malloc((tot + 64) * sizeof(double));
+    o->d_blk_slice = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
+    o->d_blk_ext_off = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
+    o->d_ext_rows = (int*)pa_rt_malloc((next_tot ? next_tot : 1) * sizeof(int));
+    o->d_order = (int*)pa_rt_malloc((nblk > 0 ? nblk : 1) * sizeof(int));
+    int bad = (!o->d_sl_off || !o->d_sl_len || !o->d_sl_row0 || !o->d_sl_nrows || !o->d_col16 || !o->d_val ||
+               !o->d_blk_slice || !o->d_blk_ext_off || !o->d_ext_rows || !o->d_order);
+    bad = bad || pa_rt_h2d(o->d_sl_off, sl_off, ((size_t)nslices + 1) * sizeof(long long));
+    bad = bad || pa_rt_h2d(o->d_sl_len, sl_len, nslices * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_sl_row0, sl_row0, nslices * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_sl_nrows, sl_nrows, nslices * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_col16, c16, (tot + 64) * sizeof(unsigned short));
+    bad = bad || pa_rt_h2d(o->d_val, sval, (tot + 64) * sizeof(double));
+    bad = bad || pa_rt_h2d(o->d_blk_slice, blk_slice, ((size_t)nblk + 1) * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_blk_ext_off, blk_ext_off, ((size_t)nblk + 1) * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_ext_rows, ext_rows, next_tot * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_order, order, nblk * sizeof(int));
+    free(order);
+    if (bad) { PA_FAIL("uploading the SpMM plan failed: %s", pa_rt_error()); rc = -1; }
+    else {
+      pa_spmm_plan_t* pl = &o->plan;
+      pl->m = m; pl->nslices = nslices; pl->sl_off = o->d_sl_off; pl->sl_len = o->d_sl_len;
+      pl->sl_row0 = o->d_sl_row0; pl->sl_nrows = o->d_sl_nrows; pl->val = o->d_val;
+      pl->nblk = nblk; pl->blk_slice = o->d_blk_slice; pl->order = o->d_order; pl->n_interior = ni;
+      pl->staged = 1; pl->col16 = o->d_col16; pl->blk_ext_off = o->d_blk_ext_off; pl->ext_rows = o->d_ext_rows;
+      pl->stage_cap = max_stage;
+      o->sell_entries = (double)tot;
+      o->stream_bytes = 10.0 * (double)tot + 4.0 * (double)next_tot;
+    }
+  } else if (rc < 0) {
+    PA_FAIL("out of host memory for the SpMM plan");
+  }
+  free(sl_off); free(sl_len); free(sl_row0); free(sl_nrows); free(sl_part);
+  free(blk_slice); free(blk_ext_off); free(needs_halo); free(stamp); free(slot_of); free(ext_rows);
+  free(c16); free(sval);
+  return rc;
 }
 
 /* -------------------------------------------------------------- build ---- */
@@ -359,16 +545,14 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   free(mark);
   o->halo_cols = halo_cols;
   o->send_idx = send_idx;
-  if (g_plan_only) { free(lcol); in->built = 1; return 0; }
+  o->lcol = lcol;
+  if (g_plan_only) { in->built = 1; return 0; }
   int rc = 0;
   if (o->nsend > 0) {
     o->d_send_idx = (int*)pa_rt_malloc((size_t)o->nsend * sizeof(int));
     rc = !o->d_send_idx || pa_rt_h2d(o->d_send_idx, send_idx, (size_t)o->nsend * sizeof(int));
   }
-  if (rc) { free(lcol); return PA_FAIL("uploading the operator failed: %s", pa_rt_error()); }
-  rc = build_plan(o, A->rowPtr, lcol, A->val);
-  free(lcol);
-  if (rc) return rc;
+  if (rc) return PA_FAIL("uploading the operator failed: %s", pa_rt_error());
   in->built = 1;
   return 0;
 }
@@ -534,6 +718,7 @@ int preAlps_BlockOperator(CPLM_Mat_Dense_t* X, CPLM_Mat_Dense_t* AX) {
   if (pa_desc_stride(AX) != ts || X->info.m != o->info.m)
     return PA_FAIL("panel shapes do not match the operator (m %d vs %d, stride %d vs %d)", X->info.m,
                    o->info.m, ts, pa_desc_stride(AX));
+  if (o->plan_ts != ts && build_plan(o, ts)) return 1;
   pa_time_begin(PA_T_OPERATOR);
   if (pa_world_size() > 1 && o->npeers > 0) {
     int rc = ensure_halo_buffers(o, ts);
@@ -561,6 +746,9 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "spmm_blocks")) *value = o->plan.nblk;
   else if (!strcmp(key, "spmm_slices")) *value = o->plan.nslices;
   else if (!strcmp(key, "spmm_stored_entries")) *value = o->sell_entries;
+  else if (!strcmp(key, "spmm_stream_bytes")) *value = o->stream_bytes;
+  else if (!strcmp(key, "spmm_staged")) *value = o->plan.staged;
+  else if (!strcmp(key, "spmm_stage_rows")) *value = o->plan.stage_cap;
   else if (!strcmp(key, "spmm_interior_blocks")) *value = o->plan.n_interior;
   else if (!strcmp(key, "bj_factor_bytes")) *value = pa_bj_factor_bytes();
   else if (!strcmp(key, "bj_max_bandwidth")) *value = pa_bj_max_bandwidth();

@@ -55,6 +55,14 @@ typedef struct {
   const int* order;         /* block ids: interior blocks first, then blocks that read halo rows */
   int n_interior;
   int win_cap;              /* rows of the largest window */
+  /* staged variant (preferred): every X row a block touches is copied to LDS
+   * first -- its own row range, then the listed external rows -- and `col16`
+   * holds the LDS slot of each entry (2 B per nonzero instead of 4). */
+  int staged;
+  const unsigned short* col16;
+  const int* blk_ext_off;   /* nblk+1: range of the block in ext_rows */
+  const int* ext_rows;      /* local row ids (>= m: halo slot) staged after the own rows */
+  int stage_cap;            /* rows of the largest staging area */
 } pa_spmm_plan_t;
 /* phase 0: interior blocks, 1: halo-reading blocks, 2: all */
 int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo,
@@ -96,8 +104,9 @@ int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double
                      double* AP, double* X, double* R, double* rtr_partials, int* nblk);
 /* Standalone sums of R(:,c)^2 (same layout as above). */
 int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk);
-/* res2[0] = sum over blocks and columns c < nc. */
-int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2);
+/* res2[0] = sum over blocks and columns c < nc; res2[1] = *info (0 if info is NULL). */
+int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2,
+                      const int* info);
 /* Z(:, :nc) -= [V0(:, :a_lo) | V1(:, :a_hi)] beta, beta is (a_lo+a_hi) x nc,
  * leading dimension ldb (ecg.c:354,517). */
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,

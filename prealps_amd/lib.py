@@ -69,7 +69,7 @@ EXPORTS = [
     "preAlps_hip_init", "preAlps_hip_shutdown", "preAlps_hip_set_stream", "preAlps_hip_get_stream",
     "preAlps_hip_sync", "preAlps_hip_set_abort_mode", "preAlps_hip_last_error", "preAlps_hip_panel_stride",
     "preAlps_hip_set_world", "preAlps_hip_set_comm", "preAlps_OperatorBuildFromCSR",
-    "preAlps_OperatorGetPermPtr", "preAlps_hip_plan_only", "preAlps_OperatorGetHaloPlan", "preAlps_hip_nparts", "preAlps_hip_reference_rhs", "preAlps_ECGSolve",
+    "preAlps_OperatorGetPermPtr", "preAlps_hip_plan_only", "preAlps_OperatorGetHaloPlan", "preAlps_hip_nparts", "preAlps_hip_reference_rhs", "preAlps_ECGSolve", "preAlps_ECGAdvance",
     "preAlps_hip_panel_alloc", "preAlps_hip_panel_free", "preAlps_hip_panel_to_host",
     "preAlps_hip_panel_from_host", "preAlps_hip_get_stat", "preAlps_hip_timing",
     "preAlps_hip_timer_start", "preAlps_hip_timer_stop",
@@ -104,6 +104,8 @@ def load():
     L._preAlps_ECGFree.argtypes = [pe]
     L._preAlps_ECGFree.restype = None
     L.preAlps_ECGSolve.argtypes = [pe, pd, pd, pd, pi, C.c_int, pi]
+    L.preAlps_ECGAdvance.argtypes = [pe, pd, pi, C.c_int, pi, pi, pd]
+    L._preAlps_ECGReset.argtypes = [pe, pd, pi]
     L.preAlps_BlockOperator.argtypes = [_PD, _PD]
     L.preAlps_BlockJacobiApply.argtypes = [_PD, _PD]
     L.preAlps_BlockJacobiCreate.argtypes = [C.POINTER(CPLM_Mat_CSR_t), pi, C.c_int, pi, C.c_int]

@@ -198,3 +198,31 @@ def test_c_driver_end_to_end(tmp_path, golden):
     it = int(re.search(r"iter: (\d+)", r.stdout).group(1))
     res = float(re.search(r"res : (\S+)", r.stdout).group(1))
     assert it == golden["lfat5"]["np2_t2_odir"]["iters"] and res < 1e-11
+
+
+def test_elasticity_q1_parity():
+    """3 dofs per node, 81 nonzeros per interior row, coefficient jumps of 1e10: the
+    matrix class of the headline metric (long SELL slices, wider bands)."""
+    import prealps_amd as pa
+    from prealps_amd import gen
+    from oracle import oracle as O
+    nn = 9
+    rp, ci, v = gen.elasticity3d_csr(nn)
+    part, nparts = gen.box_partition_nodes(nn, (3, 3, 3))
+    A = sp.csr_matrix((v, ci, rp), shape=(3 * nn ** 3, 3 * nn ** 3))
+    assert abs(A - A.T).max() < 1e-12
+    prob, B, rowpos = _problem(A, nparts, part)
+    try:
+        X = np.random.default_rng(3).standard_normal((B.shape[0], 4))
+        ref = O.spmm(B, X)
+        np.testing.assert_allclose(prob.block_operator(X, 4), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+        zr = O.BlockJacobi(B, rowpos).apply(X)
+        np.testing.assert_allclose(prob.block_jacobi_apply(X, 4), zr, rtol=1e-8, atol=1e-9 * np.abs(zr).max())
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, 4, max_iter=400)
+        refs = O.ECG(B, rowpos, 4, max_iter=400).solve(rhs)
+        assert abs(got.iters - refs["iters"]) <= 1
+        k = min(len(got.res), len(refs["res"])) - 2
+        np.testing.assert_allclose(got.res[:k], refs["res"][:k], rtol=1e-5)
+    finally:
+        prob.close()
