@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--workload", type=str, default="elasticity", choices=["poisson", "elasticity"])
     ap.add_argument("--n", type=int, default=0, help="grid points (nodes) per side; default 100 (poisson) / 70 (elasticity)")
     ap.add_argument("--t", type=int, default=4, help="enlarging factor")
-    ap.add_argument("--box", type=str, default="", help="subdomain box in nodes; default 5,5,10 (poisson) / 4,4,4 (elasticity)")
+    ap.add_argument("--box", type=str, default="", help="subdomain box in nodes; default 5,5,10 (poisson) / 2,4,8 (elasticity)")
     ap.add_argument("--alg", type=str, default="odir", choices=["odir", "omin", "fused"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=8)
@@ -82,7 +82,7 @@ def main():
     if a.n == 0:
         a.n = 100 if a.workload == "poisson" else 70
     if not a.box:
-        a.box = "5,5,10" if a.workload == "poisson" else "4,4,4"
+        a.box = "5,5,10" if a.workload == "poisson" else "2,4,8"
     box = tuple(int(x) for x in a.box.split(","))
     if a.workload == "poisson":
         rowptr, colind, val = gen.poisson3d_csr(a.n)
@@ -166,7 +166,7 @@ def main():
     # the workload is the one it was collected on.
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_elasticity.json")
-    if world == 1 and (a.workload, a.n, a.t, a.box) == ("elasticity", 70, 4, "4,4,4") and os.path.exists(pmc):
+    if world == 1 and (a.workload, a.n, a.t, a.box) == ("elasticity", 70, 4, "2,4,8") and os.path.exists(pmc):
         with open(pmc) as f:
             traffic = json.load(f)["k_spmm"]["traffic_bytes_per_launch"]
         traffic_src = "profiles/r01_pmc_hbm_traffic_elasticity.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
@@ -178,6 +178,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s (N=%d, nnz=%d), ECG %s + block-Jacobi, t=%d, tol 1e-5" % (wname, N, nnz, a.alg, a.t),
                    "nparts": int(nparts), "subdomain_box": list(box), "parallelism": "rows x%d" % world,
+                   "comm": prob.comm_kind,
                    "restarts_in_timed_region": state["restarts"],
                    "iterations_to_converge": state["last_iters"], "setup_seconds": t_setup,
                    "bj_max_bandwidth": int(prob.stat("bj_max_bandwidth")),

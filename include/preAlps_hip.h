@@ -51,6 +51,14 @@ int preAlps_hip_set_world(int rank, int size);
 int preAlps_hip_set_comm(preAlps_allreduce_fn allreduce,
                          preAlps_exchange_fn exchange, void* ctx);
 
+/* Built-in hooks: RCCL (ncclAllReduce / grouped ncclSend+ncclRecv over xGMI) on the
+ * library stream.  Rank 0 creates the 128-byte id, the launcher broadcasts it, every
+ * rank calls preAlps_hip_rccl_init (which also does set_world + set_comm). */
+int preAlps_hip_rccl_unique_id(char* id128);
+int preAlps_hip_rccl_init(const char* id128, int rank, int size);
+/* Collective: checks the installed hooks with one all-reduce and one ring exchange. */
+int preAlps_hip_comm_selftest(void);
+
 /* ---- operator from memory ---------------------------------------------- */
 /* Same pipeline as preAlps_OperatorBuild (utils/operator.c:38-134) with the
  * matrix taken from memory instead of a MatrixMarket file and an explicit

@@ -66,6 +66,7 @@ void preAlps_hip_shutdown(void) {
   pa_rt_event_destroy(g_ev0);
   pa_rt_event_destroy(g_ev1);
   g_ev0 = g_ev1 = NULL;
+  pa_rccl_shutdown();
   pa_rt_shutdown();
 }
 
@@ -115,6 +116,50 @@ int preAlps_hip_set_comm(preAlps_allreduce_fn allreduce, preAlps_exchange_fn exc
   g_allreduce = allreduce; g_exchange = exchange; g_comm_ctx = ctx;
   return 0;
 }
+/* Native binding: RCCL on the library stream.  The 128-byte id comes from rank 0
+ * (preAlps_hip_rccl_unique_id) and is broadcast by whatever launched the processes. */
+int preAlps_hip_rccl_unique_id(char* id128) {
+  if (pa_rccl_unique_id(id128)) return PA_FAIL("%s", pa_rccl_error());
+  return 0;
+}
+int preAlps_hip_rccl_init(const char* id128, int rank, int size) {
+  PA_REQUIRE_GPU();
+  if (preAlps_hip_set_world(rank, size)) return 1;
+  if (pa_rccl_init(id128, rank, size)) return PA_FAIL("%s", pa_rccl_error());
+  g_allreduce = pa_rccl_allreduce; g_exchange = pa_rccl_exchange; g_comm_ctx = NULL;
+  return 0;
+}
+/* Round-trip check of whatever hooks are installed: sum of (rank+1) over the ranks, and a
+ * ring exchange (send our rank to rank+1, receive from rank-1).  0 = both came back right. */
+int preAlps_hip_comm_selftest(void) {
+  PA_REQUIRE_GPU();
+  if (g_size == 1) return 0;
+  double* d = (double*)pa_rt_malloc(4 * sizeof(double));
+  if (!d) return PA_FAIL("%s", pa_rt_error());
+  double h[4] = {(double)(g_rank + 1), 0.0, (double)g_rank, -1.0};
+  int rc = pa_rt_h2d(d, h, sizeof(h));
+  rc = rc || pa_allreduce(d, 1);
+  int nxt = (g_rank + 1) % g_size, prv = (g_rank + g_size - 1) % g_size;
+  if (!rc) {
+    if (g_size == 2) { /* one peer: it is both neighbours */
+      int peers[1] = {nxt}, sc[1] = {1}, rcnt[1] = {1};
+      rc = pa_exchange(d + 2, sc, d + 3, rcnt, peers, 1);
+    } else {
+      int peers[2], sc[2], rcnt[2];
+      /* peers in ascending order, like the operator's plan */
+      if (prv < nxt) { peers[0] = prv; sc[0] = 0; rcnt[0] = 1; peers[1] = nxt; sc[1] = 1; rcnt[1] = 0; }
+      else { peers[0] = nxt; sc[0] = 1; rcnt[0] = 0; peers[1] = prv; sc[1] = 0; rcnt[1] = 1; }
+      rc = pa_exchange(d + 2, sc, d + 3, rcnt, peers, 2);
+    }
+  }
+  rc = rc || pa_rt_d2h(h, d, sizeof(h));
+  pa_rt_free(d);
+  if (rc) return 1;
+  double want = 0.5 * g_size * (g_size + 1);
+  if (h[0] != want) return PA_FAIL("all-reduce self-test: got %g, expected %g", h[0], want);
+  if (h[3] != (double)prv) return PA_FAIL("exchange self-test: got %g from rank %d", h[3], prv);
+  return 0;
+}
 int pa_world_rank(void) { return g_rank; }
 int pa_world_size(void) { return g_size; }
 
@@ -124,7 +169,7 @@ int pa_allreduce(double* dev_buf, int count) {
   pa_time_begin(PA_T_COMM);
   int rc = g_allreduce(g_comm_ctx, dev_buf, count);
   pa_time_end(PA_T_COMM);
-  if (rc) return PA_FAIL("all-reduce hook returned %d", rc);
+  if (rc) return PA_FAIL("all-reduce hook returned %d (%s)", rc, g_allreduce == pa_rccl_allreduce ? pa_rccl_error() : "user hook");
   return 0;
 }
 
@@ -135,7 +180,7 @@ int pa_exchange(const double* dev_send, const int* send_counts, double* dev_recv
   pa_time_begin(PA_T_COMM);
   int rc = g_exchange(g_comm_ctx, dev_send, send_counts, dev_recv, recv_counts, peers, npeers);
   pa_time_end(PA_T_COMM);
-  if (rc) return PA_FAIL("halo-exchange hook returned %d", rc);
+  if (rc) return PA_FAIL("halo-exchange hook returned %d (%s)", rc, g_exchange == pa_rccl_exchange ? pa_rccl_error() : "user hook");
   return 0;
 }
 

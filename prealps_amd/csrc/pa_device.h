@@ -34,6 +34,15 @@ int pa_rt_event_record(void* e);
 double pa_rt_event_elapsed_s(void* a, void* b);
 int pa_rt_num_cus(void);
 
+/* ---- native RCCL hooks (comm_rccl.hip) --------------------------------- */
+const char* pa_rccl_error(void);
+int pa_rccl_unique_id(char* id128);
+int pa_rccl_init(const char* id128, int rank, int size);
+void pa_rccl_shutdown(void);
+int pa_rccl_allreduce(void* ctx, double* buf, int count);
+int pa_rccl_exchange(void* ctx, const double* send, const int* send_counts, double* recv,
+                     const int* recv_counts, const int* peers, int npeers);
+
 /* ---- SpMM (utils/cplm_v0/cplm_v0_matmult_v2.c:108-343, K1) ------------- */
 /* The local row panel in sliced-ELL form (SELL-64): rows are cut into slices
  * of 64 consecutive rows (slices never cross a subdomain), each slice padded to

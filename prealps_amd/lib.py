@@ -68,7 +68,7 @@ EXPORTS = [
     "preAlps_BlockJacobiCreate", "preAlps_BlockJacobiApply", "preAlps_BlockJacobiFree",
     "preAlps_hip_init", "preAlps_hip_shutdown", "preAlps_hip_set_stream", "preAlps_hip_get_stream",
     "preAlps_hip_sync", "preAlps_hip_set_abort_mode", "preAlps_hip_last_error", "preAlps_hip_panel_stride",
-    "preAlps_hip_set_world", "preAlps_hip_set_comm", "preAlps_OperatorBuildFromCSR",
+    "preAlps_hip_set_world", "preAlps_hip_set_comm", "preAlps_hip_rccl_unique_id", "preAlps_hip_rccl_init", "preAlps_hip_comm_selftest", "preAlps_OperatorBuildFromCSR",
     "preAlps_OperatorGetPermPtr", "preAlps_hip_plan_only", "preAlps_OperatorGetHaloPlan", "preAlps_hip_nparts", "preAlps_hip_reference_rhs", "preAlps_ECGSolve", "preAlps_ECGAdvance",
     "preAlps_hip_panel_alloc", "preAlps_hip_panel_free", "preAlps_hip_panel_to_host",
     "preAlps_hip_panel_from_host", "preAlps_hip_get_stat", "preAlps_hip_timing",
@@ -94,6 +94,8 @@ def load():
     L.preAlps_hip_get_stream.restype = C.c_void_p
     L.preAlps_hip_set_stream.argtypes = [C.c_void_p]
     L.preAlps_hip_set_comm.argtypes = [ALLREDUCE_FN, EXCHANGE_FN, C.c_void_p]
+    L.preAlps_hip_rccl_unique_id.argtypes = [C.c_char_p]
+    L.preAlps_hip_rccl_init.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.preAlps_ECGInitialize.argtypes = [pe, pd, pi]
     L.preAlps_ECGIterate.argtypes = [pe, pi]
     L.preAlps_ECGStoppingCriterion.argtypes = [pe, pi]

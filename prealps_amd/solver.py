@@ -112,6 +112,33 @@ class DistributedHooks:
             return 1
 
 
+def bind_process_group(L, prefer=None):
+    """Install the communication hooks of this process for the current torch.distributed
+    group.  With the "nccl" backend the library's own RCCL binding is used (C, on the
+    library stream: no host round trip); the torch.distributed hooks are the fallback
+    and what "gloo" uses.  Returns (kind, keep_alive_object)."""
+    import os
+    import ctypes as C
+    import torch.distributed as dist
+    prefer = prefer or os.environ.get("PREALPS_COMM", "rccl")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    if prefer == "rccl" and dist.get_backend() == "nccl":
+        try:
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                check(L.preAlps_hip_rccl_unique_id(buf), "preAlps_hip_rccl_unique_id")
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0)
+            check(L.preAlps_hip_rccl_init(box[0], rank, size), "preAlps_hip_rccl_init")
+            check(L.preAlps_hip_comm_selftest(), "preAlps_hip_comm_selftest")
+            return "rccl", None
+        except Exception as e:
+            print("[prealps_amd] native RCCL hooks unavailable (%s); using torch.distributed" % e)
+    hooks = DistributedHooks(L)
+    check(L.preAlps_hip_comm_selftest(), "preAlps_hip_comm_selftest")
+    return "torch." + dist.get_backend(), hooks
+
+
 class EcgProblem:
     """One operator + one block-Jacobi preconditioner (both process-global in
     the library, as in the reference) and solves on them."""
@@ -122,11 +149,11 @@ class EcgProblem:
         import os
         dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
         check(L.preAlps_hip_init(dev), "preAlps_hip_init")
-        self.hooks = None
+        self.hooks, self.comm_kind = None, "none"
         if distributed:
             import torch
             torch.cuda.set_device(dev)
-            self.hooks = DistributedHooks(L)
+            self.comm_kind, self.hooks = bind_process_group(L)
         if use_torch_stream:
             import torch
             check(L.preAlps_hip_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)),
