@@ -62,12 +62,14 @@ void orc_spmm(int n, const int* rowptr, const int* colind, const double* val,
               int t, const double* X, int ldx, double* Y, int ldy) {
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
-    for (int c = 0; c < t; ++c) {
-      double s = 0.0;
-      for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
-        s += val[k] * X[(size_t)c * ldx + colind[k]];
-      Y[(size_t)c * ldy + i] = s;
+    double s[128];
+    for (int c = 0; c < t; ++c) s[c] = 0.0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) { /* one pass over the row, all t columns */
+      const double v = val[k];
+      const double* x = X + colind[k];
+      for (int c = 0; c < t; ++c) s[c] += v * x[(size_t)c * ldx];
     }
+    for (int c = 0; c < t; ++c) Y[(size_t)c * ldy + i] = s[c];
   }
 }
 
