@@ -49,6 +49,7 @@ typedef struct {
   double* h_pin;      /* pinned: [0] res2, [1..] scratch */
   int* h_pin_i;
   int rotate;         /* NO_BS_RED: rotate pointers instead of copying */
+  void* ev_res;       /* recorded after the residual norm has been copied to the host */
   int fuse;           /* NO_BS_RED: two-pass first half (PREALPS_ECG_FUSE=0 keeps the four-pass one) */
 } ecg_priv_t;
 
@@ -124,6 +125,8 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
   pv->h_pin = (double*)pa_rt_host_alloc((16 + 4 * (size_t)T * T) * sizeof(double));
   pv->h_pin_i = (int*)pa_rt_host_alloc((8 + T) * sizeof(int));
   if (!pv->h_pin || !pv->h_pin_i) return PA_FAIL("pinned allocation failed: %s", pa_rt_error());
+  pv->ev_res = pa_rt_event_create();
+  if (!pv->ev_res) return PA_FAIL("hipEventCreate failed");
   publish_pointers(ecg, pv);
   return 0;
 }
@@ -221,14 +224,35 @@ int _preAlps_ECGSplit(double* x, CPLM_Mat_Dense_t* XSplit, int colIndex) {
 }
 
 /* ---------------------------------------------------------- stopping ---- */
-static int fetch_res2(preAlps_ECG_t* ecg, ecg_priv_t* pv, double* res2, int* info) {
+/* The stopping test in two halves: `begin` queues the reduction of the residual
+ * norm and its copy to pinned host memory and marks that point with an event;
+ * `end` waits for the event only -- not for the stream -- so work queued after
+ * `begin` (the preconditioner apply of the same iteration) keeps the GPU busy
+ * while the host reads the norm. */
+static int stopping_begin(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
+  int T = ecg->enlFac;
+  if (!pv->rtr_valid) {
+    PA_CHECK(pa_k_colnorm2(pv->m, pv->ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
+  }
+  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2, pv->d_info));
+  pv->rtr_valid = 0;
   double t0 = pa_wtime();
   if (pa_allreduce(pv->d_res2, 1)) return 1;
   ecg->comm_t += pa_wtime() - t0;
   PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->d_res2, 2 * sizeof(double)));
-  PA_CHECK(pa_rt_sync());
-  *res2 = pv->h_pin[0];
-  *info = (int)pv->h_pin[1];
+  PA_CHECK(pa_rt_event_record(pv->ev_res));
+  return 0;
+}
+
+static int stopping_end(preAlps_ECG_t* ecg, ecg_priv_t* pv, int* stop) {
+  PA_CHECK(pa_rt_event_wait(pv->ev_res));
+  double res2 = pv->h_pin[0];
+  int info = (int)pv->h_pin[1];
+  if (info != 0 && ecg->ortho_alg == ORTHOMIN) return PA_FAIL("ACHQR: dpotrf:\n ERROR: P^tAP is not spd!");
+  ecg->res = sqrt(res2);
+  /* !(a > b) also stops on NaN, like the reference's comparison */
+  if (ecg->res > ecg->normb * ecg->tol && ecg->iter < ecg->maxIter && ecg->bs > 0) *stop = 0;
+  else *stop = 1;
   return 0;
 }
 
@@ -237,19 +261,8 @@ int preAlps_ECGStoppingCriterion(preAlps_ECG_t* ecg, int* stop) {
   if (!pv) return PA_FAIL("solver not initialised");
   if (!stop) return PA_FAIL(" wrong test 'stop != NULL'");
   double tg = pa_wtime();
-  int T = ecg->enlFac;
-  if (!pv->rtr_valid) {
-    PA_CHECK(pa_k_colnorm2(pv->m, pv->ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
-  }
-  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2, pv->d_info));
-  pv->rtr_valid = 0;
-  double res2 = 0.0; int info = 0;
-  if (fetch_res2(ecg, pv, &res2, &info)) return 1;
-  if (info != 0 && ecg->ortho_alg == ORTHOMIN) return PA_FAIL("ACHQR: dpotrf:\n ERROR: P^tAP is not spd!");
-  ecg->res = sqrt(res2);
-  /* !(a > b) also stops on NaN, like the reference's comparison */
-  if (ecg->res > ecg->normb * ecg->tol && ecg->iter < ecg->maxIter && ecg->bs > 0) *stop = 0;
-  else *stop = 1;
+  if (stopping_begin(ecg, pv)) return 1;
+  if (stopping_end(ecg, pv, stop)) return 1;
   ecg->tot_t += pa_wtime() - tg;
   return 0;
 }
@@ -604,6 +617,7 @@ void _preAlps_ECGFree(preAlps_ECG_t* ecg) {
     pa_rt_free(pv->d_info);
     pa_rt_host_free(pv->h_pin);
     pa_rt_host_free(pv->h_pin_i);
+    pa_rt_event_destroy(pv->ev_res);
     pv->magic = 0;
   }
   free(ecg->X); free(ecg->R); free(ecg->V); free(ecg->AV); free(ecg->alpha); free(ecg->beta);
@@ -663,12 +677,17 @@ int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_h
       if (rci == 0) {
         if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
       } else if (rci == 1) {
-        if (preAlps_ECGStoppingCriterion(ecg, &stop)) return 1;
+        /* same calls as the reference loop; the apply is queued before the host waits for
+         * the residual norm (it does not depend on it and is simply unused after a stop) */
+        ecg_priv_t* pv = priv_of(ecg);
+        if (!pv) return PA_FAIL("solver not initialised");
+        if (stopping_begin(ecg, pv)) return 1;
+        if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
+        else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+        if (stopping_end(ecg, pv, &stop)) return 1;
         if (res_hist && nh < max_hist) { res_hist[nh] = ecg->res; if (bs_hist) bs_hist[nh] = ecg->bs; }
         ++nh;
         if (stop == 1) break;
-        if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
-        else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
       }
     }
   } else {
@@ -698,7 +717,14 @@ int preAlps_ECGAdvance(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int ns
       if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
       ++done;
     } else {
-      if (preAlps_ECGStoppingCriterion(ecg, &stop)) return 1;
+      /* queue the stopping test, then the preconditioner apply of this iteration, and only
+       * then wait for the norm: the apply does not depend on it and is discarded on stop */
+      ecg_priv_t* pv = priv_of(ecg);
+      if (!pv) return PA_FAIL("solver not initialised");
+      if (stopping_begin(ecg, pv)) return 1;
+      if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
+      else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+      if (stopping_end(ecg, pv, &stop)) return 1;
       if (stop == 1) {
         if (restarts) ++*restarts;
         if (last_iters) *last_iters = ecg->iter;
@@ -709,8 +735,6 @@ int preAlps_ECGAdvance(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int ns
         ++done;
         continue;
       }
-      if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
-      else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
     }
   }
   return 0;

@@ -31,6 +31,7 @@ int pa_rt_d2h_async(void* pinned, const void* d, size_t bytes);
 void* pa_rt_event_create(void);
 void pa_rt_event_destroy(void* e);
 int pa_rt_event_record(void* e);
+int pa_rt_event_wait(void* e);
 double pa_rt_event_elapsed_s(void* a, void* b);
 int pa_rt_num_cus(void);
 

@@ -123,6 +123,10 @@ int pa_rt_event_record(void* e) {
   RT(hipEventRecord((hipEvent_t)e, g_cur));
   return 0;
 }
+int pa_rt_event_wait(void* e) {
+  RT(hipEventSynchronize((hipEvent_t)e));
+  return 0;
+}
 double pa_rt_event_elapsed_s(void* a, void* b) {
   float ms = 0.f;
   if (hipEventSynchronize((hipEvent_t)b) != hipSuccess) return -1.0;
