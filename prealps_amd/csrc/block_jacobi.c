@@ -163,9 +163,15 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       xadj[i + 1] = e; deg[i] = e - xadj[i];
     }
     rcm_order(b, xadj, adj, deg, order, pos, queue, level);
-    int w = 0;
+    int w = 0, wnat = 0;
     for (int i = 0; i < b; ++i)
-      for (int k = xadj[i]; k < xadj[i + 1]; ++k) { int dd = pos[i] - pos[adj[k]]; if (dd < 0) dd = -dd; if (dd > w) w = dd; }
+      for (int k = xadj[i]; k < xadj[i + 1]; ++k) {
+        int dd = pos[i] - pos[adj[k]]; if (dd < 0) dd = -dd; if (dd > w) w = dd;
+        int dn = i - adj[k]; if (dn < 0) dn = -dn; if (dn > wnat) wnat = dn;
+      }
+    /* RCM is a heuristic: on elongated boxes of a structured grid the given row order (long
+     * axis slowest) can have the narrower band -- keep whichever is narrower */
+    if (wnat <= w) { w = wnat; for (int i = 0; i < b; ++i) { order[i] = i; pos[i] = i; } }
     bw[q] = w;
     /* band[i*(w+1) + d] = A(new i, new i-d) */
     double* band = (double*)calloc((size_t)b * (w + 1), sizeof(double));

@@ -200,9 +200,12 @@ def test_c_driver_end_to_end(tmp_path, golden):
     assert it == golden["lfat5"]["np2_t2_odir"]["iters"] and res < 1e-11
 
 
-def test_elasticity_q1_parity():
+@pytest.mark.parametrize("bsr3", ["0", "1"])
+def test_elasticity_q1_parity(bsr3, monkeypatch):
     """3 dofs per node, 81 nonzeros per interior row, coefficient jumps of 1e10: the
-    matrix class of the headline metric (long SELL slices, wider bands)."""
+    matrix class of the headline metric (long SELL slices, wider bands); with the scalar
+    staged SpMM (default) and with the opt-in 3x3-block one."""
+    monkeypatch.setenv("PREALPS_SPMM_BSR3", bsr3)
     import prealps_amd as pa
     from prealps_amd import gen
     from oracle import oracle as O
@@ -216,6 +219,7 @@ def test_elasticity_q1_parity():
         X = np.random.default_rng(3).standard_normal((B.shape[0], 4))
         ref = O.spmm(B, X)
         np.testing.assert_allclose(prob.block_operator(X, 4), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+        assert prob.stat("spmm_bsr3") == float(bsr3) and prob.stat("spmm_staged") == 1.0
         zr = O.BlockJacobi(B, rowpos).apply(X)
         np.testing.assert_allclose(prob.block_jacobi_apply(X, 4), zr, rtol=1e-8, atol=1e-9 * np.abs(zr).max())
         rhs = prob.reference_rhs()
