@@ -230,3 +230,43 @@ def test_elasticity_q1_parity(bsr3, monkeypatch):
         np.testing.assert_allclose(got.res[:k], refs["res"][:k], rtol=1e-5)
     finally:
         prob.close()
+
+
+@pytest.mark.parametrize("t,alg", [(3, "odir"), (5, "omin"), (16, "odir"), (12, "odir")])
+def test_enlarging_factors_off_the_power_of_two_grid(t, alg):
+    """t = 3, 5, 12 run on padded panels (stride 4, 8, 16); t = 16 is the largest supported."""
+    import prealps_amd as pa
+    from oracle import oracle as O
+    n, s3 = 16, 4
+    idx = np.arange(n ** 3)
+    i, j, k = idx // (n * n), (idx // n) % n, idx % n
+    part = (((i // s3) * (n // s3) + (j // s3)) * (n // s3) + (k // s3)).astype(np.int32)
+    prob, B, rowpos = _problem(O.poisson3d(n), (n // s3) ** 3, part)
+    try:
+        algs = {"odir": (pa.ORTHODIR, O.ORTHODIR), "omin": (pa.ORTHOMIN, O.ORTHOMIN)}[alg]
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, t, ortho_alg=algs[0])
+        ref = O.ECG(B, rowpos, t, algs[1], O.NO_BS_RED).solve(rhs)
+        assert got.iters == ref["iters"]
+        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-7)
+        np.testing.assert_allclose(got.x, ref["x"], rtol=1e-6, atol=1e-9 * np.abs(ref["x"]).max())
+    finally:
+        prob.close()
+
+
+def test_unsupported_sizes_fail_loudly():
+    import prealps_amd as pa
+    from oracle import oracle as O
+    prob, B, rowpos = _problem(O.poisson3d(12), 27, None)
+    try:
+        with pytest.raises(pa.PreAlpsError, match="enlarging factor"):
+            prob.solve(prob.reference_rhs(), 17)
+    finally:
+        prob.close()
+    # one block of 32768 rows has a band far wider than the wave-resident solve supports
+    prob, B, rowpos = _problem(O.poisson3d(32), 1, None)
+    try:
+        with pytest.raises(pa.PreAlpsError, match="bandwidth"):
+            prob.create_block_jacobi()
+    finally:
+        prob.close()
