@@ -55,6 +55,8 @@ typedef struct {
   int* d_send_idx;
   double* d_sendbuf; double* d_halo;
   int buf_ts;        /* stride the buffers are sized for */
+  void* ev_packed;   /* send buffer is packed (main stream) */
+  void* ev_halo;     /* halo rows have arrived (side stream) */
   int* colPos_dummy;
 } pa_operator_t;
 
@@ -112,6 +114,7 @@ void preAlps_OperatorFree(void) {
   free(o->info.A.rowPtr); free(o->info.A.colInd); free(o->info.A.val);
   free(o->peers); free(o->send_rows); free(o->recv_rows); free(o->send_cnt); free(o->recv_cnt);
   free(o->send_idx); free(o->halo_cols);
+  pa_rt_event_destroy(o->ev_packed); pa_rt_event_destroy(o->ev_halo);
   pa_rt_free(o->d_send_idx); pa_rt_free(o->d_sendbuf); pa_rt_free(o->d_halo);
   free(o->colPos_dummy);
   memset(o, 0, sizeof(*o));
@@ -734,11 +737,23 @@ int preAlps_BlockOperator(CPLM_Mat_Dense_t* X, CPLM_Mat_Dense_t* AX) {
     int rc = ensure_halo_buffers(o, ts);
     if (rc) return rc;
     for (int i = 0; i < o->npeers; ++i) { o->send_cnt[i] = o->send_rows[i] * ts; o->recv_cnt[i] = o->recv_rows[i] * ts; }
+    if (!o->ev_packed) { o->ev_packed = pa_rt_event_create(); o->ev_halo = pa_rt_event_create(); }
+    if (!o->ev_packed || !o->ev_halo) return PA_FAIL("hipEventCreate failed");
+    /* pack on the main stream; the exchange runs on the side stream while the main stream
+     * computes the blocks that read no halo row; the halo-reading blocks wait for it */
+    void* main_stream = pa_rt_stream();
+    void* side = pa_rt_side_stream();
     PA_CHECK(pa_k_pack_rows(o->nsend, ts, o->d_send_idx, X->val, o->d_sendbuf));
-    /* interior rows first: they do not wait for the neighbours */
-    PA_CHECK(pa_k_spmm(&o->plan, ts, X->val, o->d_halo, AX->val, 0));
+    PA_CHECK(pa_rt_event_record_on(o->ev_packed, main_stream));
+    PA_CHECK(pa_rt_stream_wait_event(side, o->ev_packed));
+    pa_rt_set_stream(side);
     rc = pa_exchange(o->d_sendbuf, o->send_cnt, o->d_halo, o->recv_cnt, o->peers, o->npeers);
+    int rc2 = rc ? 0 : pa_rt_event_record_on(o->ev_halo, side);
+    pa_rt_set_stream(main_stream);
     if (rc) return rc;
+    if (rc2) return PA_FAIL("%s", pa_rt_error());
+    PA_CHECK(pa_k_spmm(&o->plan, ts, X->val, o->d_halo, AX->val, 0));
+    PA_CHECK(pa_rt_stream_wait_event(main_stream, o->ev_halo));
     PA_CHECK(pa_k_spmm(&o->plan, ts, X->val, o->d_halo, AX->val, 1));
   } else {
     PA_CHECK(pa_k_spmm(&o->plan, ts, X->val, NULL, AX->val, 2));

@@ -28,6 +28,9 @@ int pa_rt_h2d(void* d, const void* h, size_t bytes);
 int pa_rt_d2h(void* h, const void* d, size_t bytes);
 int pa_rt_d2d(void* dst, const void* src, size_t bytes);
 int pa_rt_d2h_async(void* pinned, const void* d, size_t bytes);
+void* pa_rt_side_stream(void);
+int pa_rt_stream_wait_event(void* stream, void* event);
+int pa_rt_event_record_on(void* event, void* stream);
 void* pa_rt_event_create(void);
 void pa_rt_event_destroy(void* e);
 int pa_rt_event_record(void* e);

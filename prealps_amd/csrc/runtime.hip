@@ -9,6 +9,7 @@
 namespace {
 hipStream_t g_own = nullptr;
 hipStream_t g_cur = nullptr;
+hipStream_t g_side = nullptr;   // halo exchange runs here, beside the interior SpMM
 bool g_ready = false;
 int g_cus = 0;
 char g_err[512] = "";
@@ -50,6 +51,7 @@ int pa_rt_init(int device) {
   }
   g_cus = prop.multiProcessorCount;
   RT(hipStreamCreateWithFlags(&g_own, hipStreamNonBlocking));
+  RT(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
   g_cur = g_own;
   g_ready = true;
   return 0;
@@ -59,7 +61,8 @@ void pa_rt_shutdown(void) {
   if (!g_ready) return;
   (void)hipStreamSynchronize(g_cur);
   (void)hipStreamDestroy(g_own);
-  g_own = g_cur = nullptr;
+  (void)hipStreamDestroy(g_side);
+  g_own = g_cur = g_side = nullptr;
   g_ready = false;
 }
 
@@ -113,6 +116,16 @@ int pa_rt_d2h_async(void* pinned, const void* d, size_t bytes) {
   return 0;
 }
 
+void* pa_rt_side_stream(void) { return (void*)g_side; }
+/* make stream `s` wait for everything recorded in event `e` */
+int pa_rt_stream_wait_event(void* s, void* e) {
+  RT(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0));
+  return 0;
+}
+int pa_rt_event_record_on(void* e, void* s) {
+  RT(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+  return 0;
+}
 void* pa_rt_event_create(void) {
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return nullptr;

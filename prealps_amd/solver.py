@@ -50,11 +50,19 @@ class DistributedHooks:
         self.staged = dist.get_backend() != "nccl"
         # everything the hooks do is queued on the library's own stream, so it is ordered
         # after the kernels that produced the buffers and before the ones that consume them
-        self.stream = torch.cuda.ExternalStream(int(L.preAlps_hip_get_stream()))
+        self._streams = {}
         self._ar = _l.ALLREDUCE_FN(self._allreduce)
         self._ex = _l.EXCHANGE_FN(self._exchange)
         check(L.preAlps_hip_set_world(self.rank, self.size), "preAlps_hip_set_world")
         check(L.preAlps_hip_set_comm(self._ar, self._ex, None), "preAlps_hip_set_comm")
+
+    def _stream(self):
+        # the library switches to its side stream around the halo exchange
+        h = int(self.L.preAlps_hip_get_stream())
+        st = self._streams.get(h)
+        if st is None:
+            st = self._streams[h] = self.torch.cuda.ExternalStream(h)
+        return st
 
     def _wrap(self, ptr, count):
         """Zero-copy float64 view of `count` doubles of device memory owned by the library."""
@@ -68,7 +76,7 @@ class DistributedHooks:
 
     def _allreduce(self, ctx, ptr, count):
         try:
-            with self.torch.cuda.stream(self.stream):
+            with self.torch.cuda.stream(self._stream()):
                 t = self._wrap(ptr, count)
                 if self.staged:
                     h = t.cpu()
@@ -86,7 +94,7 @@ class DistributedHooks:
             dist, torch = self.dist, self.torch
             ns = sum(send_counts[i] for i in range(npeers))
             nr = sum(recv_counts[i] for i in range(npeers))
-            with torch.cuda.stream(self.stream):
+            with torch.cuda.stream(self._stream()):
                 ts_ = self._wrap(send, max(ns, 1))
                 tr_ = self._wrap(recv, max(nr, 1))
                 if self.staged:
