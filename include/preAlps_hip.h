@@ -70,6 +70,9 @@ int preAlps_hip_comm_selftest(void);
 int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd,
                                  const double* val, int nparts, const int* part,
                                  int scale);
+/* Cut the SpMM plan (slices, LDS staging lists) for this enlarging factor now rather than
+ * inside the first preAlps_BlockOperator call; optional. */
+int preAlps_hip_prepare_operator(int enlFac);
 /* Plan-only mode: build the sharding and halo lists on the host without a GPU
  * (used by the multi-process CPU tests); preAlps_BlockOperator is refused. */
 void preAlps_hip_plan_only(int on);

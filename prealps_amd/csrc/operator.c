@@ -138,6 +138,7 @@ static int build_plan(pa_operator_t* o, int ts) {
   /* -1 (default): stage when the external rows a block copies are small next to its matrix
    * slice (long rows: elasticity); short rows (7-point stencils) gather through L2 instead */
   int want = env_int("PREALPS_SPMM_STAGED", -1);
+  if (want < 0 && ts >= 16) want = 0; /* wide panels: the 128-B X rows gather well from L2 (measured) */
   if (want != 0 && env_int("PREALPS_SPMM_BSR3", 0)) {
     /* vector problems with dense 3x3 node blocks: the most compact stream, but slower in
      * practice than the scalar staged kernel (see kernels.hip), hence opt-in */
@@ -271,7 +272,8 @@ static int build_plan_staged(pa_operator_t* o, int ts) {
   const int* colind = o->lcol;
   const double* val = in->A.val;
   int m = in->m, ncols = m + in->halo;
-  int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", 32768) / (ts * 8);
+  /* LDS budget of a block: 32 KiB at ts <= 4, 64 KiB at ts = 8 (two workgroups per CU) */
+  int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", ts <= 4 ? 32768 : 65536) / (ts * 8);
   if (cap_rows > 65535) cap_rows = 65535;
   int blk_rows = env_int("PREALPS_SPMM_BLOCK_ROWS", 256);
   if (blk_rows < 64) blk_rows = 64;
@@ -718,6 +720,17 @@ static int ensure_halo_buffers(pa_operator_t* o, int ts) {
   o->d_halo = (double*)pa_rt_malloc((size_t)(o->info.halo ? o->info.halo : 1) * ts * sizeof(double));
   if (!o->d_sendbuf || !o->d_halo) return PA_FAIL("halo buffers: %s", pa_rt_error());
   o->buf_ts = ts;
+  return 0;
+}
+
+/* Cut the SpMM plan for a given enlarging factor now instead of at the first
+ * preAlps_BlockOperator call (it is host work proportional to the local nonzeros). */
+int preAlps_hip_prepare_operator(int enlFac) {
+  pa_operator_t* o = &g_op;
+  if (!o->info.built) return PA_FAIL("operator not built");
+  if (g_plan_only) return 0;
+  int ts = pa_panel_stride(enlFac);
+  if (o->plan_ts != ts && build_plan(o, ts)) return 1;
   return 0;
 }
 

@@ -252,6 +252,7 @@ class EcgProblem:
             self.create_block_jacobi()
         import time
         L = self.L
+        check(L.preAlps_hip_prepare_operator(int(t)), "preAlps_hip_prepare_operator")
         e = self.new_ecg(t, ortho_alg, bs_red, tol, max_iter)
         rhs = np.ascontiguousarray(rhs, dtype=np.float64)
         sol = np.zeros(self.m)
