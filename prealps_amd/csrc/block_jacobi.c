@@ -216,13 +216,21 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   /* pass 2: sweep layouts */
   off[0] = 0;
   int maxw = 0;
-  /* one record of wr doubles per step: [1/L(j,j) | row id | 0 | L(j+1..j+w, j) | 0], wr even */
-  for (int q = 0; q < np; ++q) { off[q + 1] = off[q] + (long long)nrows[q] * ((bw[q] + 5) & ~1); if (bw[q] > maxw) maxw = bw[q]; }
-  s->max_bw = maxw;
+  /* narrow bands (one wavefront per block): one record of wr doubles per step,
+   * [1/L(j,j) | row id | 0 | L(j+1..j+w, j) | 0], wr even.  Wide bands (one workgroup per
+   * block): records of W = roundup(w + 64, 256) doubles in window-slot order, the value for
+   * target row i at column i mod W. */
   int maxR = pa_bj_max_R();
-  if (!rc && (maxw + 127) / 64 > maxR)
-    rc = PA_FAIL("block-Jacobi: a diagonal block has bandwidth %d after RCM; the wavefront-resident solve "
-                 "supports up to %d -- use more (smaller) subdomains", maxw, 64 * maxR - 64);
+  for (int q = 0; q < np; ++q) {
+    int wide = (bw[q] + 127) / 64 > maxR;
+    long long reclen = wide ? ((bw[q] + 64 + 255) & ~255) : ((bw[q] + 5) & ~1);
+    off[q + 1] = off[q] + (long long)nrows[q] * reclen;
+    if (bw[q] > maxw) maxw = bw[q];
+  }
+  s->max_bw = maxw;
+  if (!rc && ((maxw + 64 + 255) & ~255) > 4096)
+    rc = PA_FAIL("block-Jacobi: a diagonal block has bandwidth %d after reordering; the workgroup-resident "
+                 "solve supports up to 4032 -- use more (smaller) subdomains", maxw);
   size_t tot = (size_t)off[np];
   const size_t pad = 256; /* the last LDS-DMA piece of a chunk may read up to 1 KiB past it */
   double* Lf = NULL; double* Lb = NULL;
@@ -239,6 +247,19 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       const double* band = bands[q];
       double* f = Lf + off[q];
       double* g = Lb + off[q];
+      if ((w + 127) / 64 > maxR) { /* wide: window-slot order, pre-divided by the pivot */
+        size_t W = (size_t)((w + 64 + 255) & ~255);
+        for (int j = 0; j < b; ++j) {
+          int jr = b - 1 - j;
+          invd_f[r0 + j] = 1.0 / band[(size_t)j * ld];
+          invd_b[r0 + j] = 1.0 / band[(size_t)jr * ld];
+          for (int dd = 1; dd <= w; ++dd) {
+            if (j + dd < b) f[(size_t)j * W + (size_t)(j + dd) % W] = band[(size_t)(j + dd) * ld + dd] * invd_f[r0 + j];
+            if (jr - dd >= 0) g[(size_t)j * W + (size_t)(j + dd) % W] = band[(size_t)jr * ld + dd] * invd_b[r0 + j];
+          }
+        }
+        continue;
+      }
       for (int j = 0; j < b; ++j) {
         int jr = b - 1 - j;
         long long idf = map_f[r0 + j], idb = map_b[r0 + j];
@@ -262,6 +283,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     s->nclass = 0;
     for (int q = 0; q < np; ++q) {
       int R = (bw[q] + 127) / 64, c;
+      if (R > maxR) R = 0; /* wide class */
       for (c = 0; c < s->nclass; ++c) if (s->class_R[c] == R) break;
       if (c == s->nclass) { s->class_R[c] = R; s->class_count[c] = 0; s->class_wmax[c] = 0; s->nclass++; }
       cls[q] = c; s->class_count[c]++;

@@ -954,6 +954,140 @@ __global__ void k_bj_apply(
   bj_sweep<TS, R, CH>(b, w, wr, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, lds0, lds1, lane);
 }
 
+// Wide bands (RCM bandwidth > 448: few, large subdomains).  One workgroup of up to 16
+// wavefronts per subdomain; the W = 64*R*NW rows in flight are spread over the waves'
+// registers exactly as in the one-wave kernel.  Per step the owning wave broadcasts the
+// pivot through LDS (double buffered, one raw s_barrier per step), then every wave updates
+// its rows.  Records are stored in window-slot order -- the value for target row i sits at
+// column i mod W -- so a lane reads the same column of every record: no index arithmetic,
+// coalesced, and prefetched D steps ahead in registers.
+template <int TS, int R, int D>
+__device__ __forceinline__ void bjw_sweep(int b, int W, const double* __restrict__ rec,
+                                          const double* __restrict__ invd,
+                                          const int* __restrict__ iomap, size_t rowbase,
+                                          const double* __restrict__ src, double* __restrict__ dst,
+                                          double (*ybuf)[TS], int wave, int lane, bool active) {
+  // idle waves of a narrower block alias wave 0's columns: they compute, never store
+  const int s0 = (active ? wave : 0) * 64 * R + lane;   // slot of register set 0 of this lane
+  double acc[R][TS];
+  int rowid[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int j = s0 + k * 64;
+    rowid[k] = 0;
+    if (active && j < b) { rowid[k] = iomap[j]; load_row<TS>(src, rowbase + rowid[k], acc[k]); }
+    else
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
+  }
+  const double* __restrict__ col = rec + s0;    // lane's column of every record
+  for (int jb = 0; jb < b; jb += 64) {
+    const int sb = jb % W;
+    const int ow = sb / (64 * R), ok = (sb >> 6) % R;   // wave / register set that owns this block
+    const bool mine = active && wave == ow;
+    const int lim = (b - jb) < 64 ? (b - jb) : 64;
+    double nxt[TS];
+    double idl = 0.0;
+    int nrow = 0;
+    if (mine) {
+      const int jn = jb + W + lane;
+      if (jb + lane < b) idl = invd[jb + lane];
+      if (jn < b) { nrow = iomap[jn]; load_row<TS>(src, rowbase + nrow, nxt); }
+      else
+#pragma unroll
+        for (int c = 0; c < TS; ++c) nxt[c] = 0.0;
+    }
+    // register ring of the next D steps' band values; loads are unconditional (past the
+    // end of the block they re-read its last record) so the compiler emits no branches
+    const double* __restrict__ cp = col + (size_t)jb * W;
+    double q[D][R];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int lu = u < lim ? u : lim - 1;
+#pragma unroll
+      for (int k = 0; k < R; ++k) q[u][k] = cp[(size_t)lu * W + k * 64];
+    }
+    for (int l0 = 0; l0 < lim; l0 += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int l = l0 + u;
+        if (l < lim) {
+          const int j = jb + l;
+          if (mine) {
+            double piv[TS];
+#pragma unroll
+            for (int c = 0; c < TS; ++c) {
+              double v = acc[0][c];
+#pragma unroll
+              for (int k = 1; k < R; ++k) v = (ok == k) ? acc[k][c] : v;
+              piv[c] = readlane_f64(v, l);
+            }
+            if (lane == 0)
+#pragma unroll
+              for (int c = 0; c < TS; ++c) ybuf[j & 1][c] = piv[c];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          double y[TS];
+#pragma unroll
+          for (int c = 0; c < TS; ++c) y[c] = ybuf[j & 1][c];
+          const int ln = (l + D) < lim ? (l + D) : lim - 1;
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            const double lv = q[u][k];
+#pragma unroll
+            for (int c = 0; c < TS; ++c) acc[k][c] = fma(-lv, y[c], acc[k][c]);
+            q[u][k] = cp[(size_t)ln * W + k * 64];
+          }
+        }
+      }
+    }
+    if (mine) {
+      double v[TS];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) {
+        double a = acc[0][c];
+#pragma unroll
+        for (int k = 1; k < R; ++k) a = (ok == k) ? acc[k][c] : a;
+        v[c] = a * idl;
+      }
+      int rid = rowid[0];
+#pragma unroll
+      for (int k = 1; k < R; ++k) rid = (ok == k) ? rowid[k] : rid;
+      if (lane < lim) store_row<TS>(dst, rowbase + rid, v);
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        if (ok == k) {
+#pragma unroll
+          for (int c = 0; c < TS; ++c) acc[k][c] = nxt[c];
+          rowid[k] = nrow;
+        }
+    }
+  }
+}
+
+template <int TS, int R>
+__global__ __launch_bounds__(1024) void k_bj_wide(
+    const int* __restrict__ list, int count, const int* __restrict__ row0,
+    const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off,
+    const int* __restrict__ map_f, const int* __restrict__ map_b, const double* __restrict__ Lf,
+    const double* __restrict__ Lb, const double* __restrict__ invd_f,
+    const double* __restrict__ invd_b, const double* __restrict__ in, double* __restrict__ out) {
+  __shared__ double ybuf[2][TS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int p = __builtin_amdgcn_readfirstlane(list[blockIdx.x]);
+  const int r0 = __builtin_amdgcn_readfirstlane(row0[p]);
+  const int b = __builtin_amdgcn_readfirstlane(nrows[p]);
+  const int w = __builtin_amdgcn_readfirstlane(bw[p]);
+  const int W = (w + 64 + 255) & ~255;
+  const bool active = wave < W / (64 * R);
+  const size_t o = (size_t)off[p];
+  bjw_sweep<TS, R, (R * TS >= 16 ? 4 : 8)>(b, W, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in, out, ybuf, wave, lane, active);
+  __threadfence_block();
+  __syncthreads();
+  bjw_sweep<TS, R, (R * TS >= 16 ? 4 : 8)>(b, W, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, ybuf, wave, lane, active);
+}
+
 inline int grid_rows(int m, int per_thread_rows = 1) {
   long long blocks = ((long long)m + (long long)WG * per_thread_rows - 1) / ((long long)WG * per_thread_rows);
   if (blocks < 1) blocks = 1;
@@ -1058,6 +1192,24 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
   if (ch < 0) { const char* e = getenv("PREALPS_BJ_CH"); ch = e ? atoi(e) : 8; }
   if (ch == 8) return bj_launch_ch<TS, 8>(pl, R, wmax, list, count, in, out);
   return bj_launch_ch<TS, 16>(pl, R, wmax, list, count, in, out);
+}
+
+template <int TS, int R>
+static int bj_launch_wide(const pa_bj_plan_t* pl, int wmax, const int* list, int count,
+                          const double* in, double* out) {
+  const int W = (wmax + 64 + 255) & ~255;
+  const int nw = W / (64 * R);
+  if (nw > 16) {
+    snprintf(g_kerr, sizeof(g_kerr),
+             "block-Jacobi: bandwidth %d needs %d wavefronts at panel stride %d (limit 16); use more subdomains",
+             wmax, nw, TS);
+    fprintf(stderr, "[prealps_hip] %s\n", g_kerr);
+    return 1;
+  }
+  hipLaunchKernelGGL((k_bj_wide<TS, R>), dim3(count), dim3(64 * nw), 0, cur_stream(), list, count, pl->row0,
+                     pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
+                     pl->invd_b, in, out);
+  return kfail("k_bj_wide");
 }
 
 extern "C" {
@@ -1206,6 +1358,17 @@ int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out)
   for (int c = 0; c < pl->nclass; ++c) {
     if (pl->class_count[c] <= 0) continue;
     int rc = 1;
+    if (pl->class_R[c] == 0) {   /* wide bands: one workgroup per subdomain */
+      switch (ts) {
+        case 2: rc = bj_launch_wide<2, 4>(pl, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out); break;
+        case 4: rc = bj_launch_wide<4, 4>(pl, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out); break;
+        case 8: rc = bj_launch_wide<8, 2>(pl, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out); break;
+        case 16: rc = bj_launch_wide<16, 1>(pl, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out); break;
+        default: rc = 1;
+      }
+      if (rc) return rc;
+      continue;
+    }
     TS_DISPATCH(ts, rc = bj_launch<TS_>(pl, pl->class_R[c], pl->class_wmax[c], pl->class_list[c],
                                         pl->class_count[c], in, out));
     if (rc) return rc;

@@ -158,7 +158,8 @@ typedef struct {
   const double* Lb;
   const double* invd_f;    /* 1 / L(j,j) in forward step order (m entries) */
   const double* invd_b;    /* ... in backward step order */
-  int nclass;              /* parts grouped by register sets R = ceil((w+64)/64) */
+  int nclass;              /* parts grouped by register sets R = ceil((w+64)/64); R = 0: wide band,
+                              one workgroup per part, records of roundup(w+64, 256) doubles in slot order */
   const int* class_R;      /* host array, nclass */
   const int* class_count;  /* host array */
   const int* class_wmax;   /* host array: widest band in the class (sizes the LDS chunks) */

@@ -263,10 +263,26 @@ def test_unsupported_sizes_fail_loudly():
             prob.solve(prob.reference_rhs(), 17)
     finally:
         prob.close()
-    # one block of 32768 rows has a band far wider than the wave-resident solve supports
-    prob, B, rowpos = _problem(O.poisson3d(32), 1, None)
+
+
+@pytest.mark.parametrize("t", [4, 8, 16])
+def test_wide_band_blocks_few_large_subdomains(t):
+    """Few, large subdomains (the reference's regime at small rank counts): bands wider
+    than one wavefront holds go through the workgroup-resident block solve."""
+    import prealps_amd as pa
+    from oracle import oracle as O
+    n, P = 32, 2                       # 2 slabs of 16 x 32 x 32: bandwidth ~ 500-1000
+    prob, B, rowpos = _problem(O.poisson3d(n), P)
     try:
-        with pytest.raises(pa.PreAlpsError, match="bandwidth"):
-            prob.create_block_jacobi()
+        X = np.random.default_rng(t).standard_normal((B.shape[0], t))
+        zr = O.BlockJacobi(B, rowpos).apply(X)
+        np.testing.assert_allclose(prob.block_jacobi_apply(X, t), zr, rtol=1e-9, atol=1e-10 * np.abs(zr).max())
+        assert prob.stat("bj_max_bandwidth") > 448
+        if t == 4:
+            rhs = prob.reference_rhs()          # enlarging factor <= number of subdomains
+            got = prob.solve(rhs, 2)
+            ref = O.ECG(B, rowpos, 2).solve(rhs)
+            assert got.iters == ref["iters"]
+            np.testing.assert_allclose(got.res, ref["res"], rtol=RTOL_HIST)
     finally:
         prob.close()
