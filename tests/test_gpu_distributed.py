@@ -39,12 +39,14 @@ def _worker(rank, world, port, alg, q):
         prob = pa.EcgProblem(rp, ci, v, nparts, part, scale=True, device=0, distributed=True)
         rhs = prob.reference_rhs()
         algs = {"odir": (pa.ORTHODIR, O.ORTHODIR), "omin": (pa.ORTHOMIN, O.ORTHOMIN),
-                "fused": (pa.ORTHODIR_FUSED, O.ORTHODIR_FUSED)}[alg]
-        got = prob.solve(rhs, t, ortho_alg=algs[0])
+                "fused": (pa.ORTHODIR_FUSED, O.ORTHODIR_FUSED), "dodir": (pa.ORTHODIR, O.ORTHODIR)}[alg]
+        red = (pa.ADAPT_BS, O.ADAPT_BS) if alg == "dodir" else (pa.NO_BS_RED, O.NO_BS_RED)
+        got = prob.solve(rhs, t, ortho_alg=algs[0], bs_red=red[0])
         import scipy.sparse as sp
         A = sp.csr_matrix((v, ci, rp), shape=(n ** 3, n ** 3))
         B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, nparts)
-        ref = O.ECG(B, rowpos, t, algs[1], O.NO_BS_RED).solve(O.reference_rhs(rowpos))
+        ref = O.ECG(B, rowpos, t, algs[1], red[1]).solve(O.reference_rhs(rowpos))
+        assert list(got.bs) == list(ref["bs"])
         p0, p1 = rank * nparts // world, (rank + 1) * nparts // world
         lo, hi = int(rowpos[p0]), int(rowpos[p1])
         assert prob.stat("halo_rows") > 0
@@ -61,7 +63,7 @@ def _worker(rank, world, port, alg, q):
         q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize("alg", ["odir", "omin", "fused"])
+@pytest.mark.parametrize("alg", ["odir", "omin", "fused", "dodir"])
 def test_two_ranks_one_gpu_match_oracle(alg):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
