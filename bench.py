@@ -192,21 +192,41 @@ def main():
                          "achieved_GBs": bj_bytes / bj_s / 1e9},
     }
 
-    # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, rank 0, N=1
+    # ---- CPU baseline on the host cores, rank 0, N=1.  Two ports of the same algorithm are timed on
+    #      a bounded sample and the FASTER one is reported: (a) oracle/ecg_oracle.c, plain C + OpenMP,
+    #      one thread per group of subdomains (the reference's one-rank-per-core layout); (b) the
+    #      reference's own kernels, mkl_dcsrmm + MKL PARDISO + BLAS, threaded inside one process.
     if rank == 0 and world == 1 and not a.no_cpu:
         from oracle import oracle as O
+        from oracle import mkl_path as M
         import scipy.sparse as sp
         A = sp.csr_matrix((val, colind.astype(np.int32), rowptr), shape=(N, N))
         B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, nparts)
+        rhs_cpu = O.reference_rhs(rowpos)
         tf0 = time.perf_counter()
         ecg = O.ECG(B, rowpos, a.t, O.ORTHODIR if a.alg == "odir" else O.ORTHOMIN, O.NO_BS_RED, 1e-5, a.cpu_iters)
         tfac = time.perf_counter() - tf0
-        r = ecg.solve(O.reference_rhs(rowpos))
-        out["cpu_baseline"] = {"value": r["iters"] / r["t_total"], "unit": "iterations/s",
-                               "cores": O.lib().orc_num_threads(), "kind": "port",
-                               "sample": "%d ECG iterations of the same workload (same matrix, scaling, partition, rhs) "
-                                         "by oracle/ecg_oracle.c with OpenMP; operator %.3fs precond %.3fs of %.3fs; "
-                                         "factorisation %.1fs outside the rate" % (r["iters"], r["t_op"], r["t_prec"], r["t_total"], tfac),
+        r = ecg.solve(rhs_cpu)
+        cands = [(r["iters"] / r["t_total"], O.lib().orc_num_threads(),
+                  "C/OpenMP port (oracle/ecg_oracle.c): %d iterations, operator %.3fs precond %.3fs of %.3fs, "
+                  "factorisation %.1fs outside the rate" % (r["iters"], r["t_op"], r["t_prec"], r["t_total"], tfac))]
+        if a.alg == "odir" and M.load_mkl() is not None:
+            try:
+                e_cpu = M.MklEcg(B, rowpos, a.t, 1e-5, a.cpu_iters, threads=min(os.cpu_count() or 1, 128))
+                rm = e_cpu.solve(rhs_cpu)
+                cands.append((rm["iters"] / rm["t_total"], int(rm["threads"]),
+                              "MKL kernels (mkl_dcsrmm %.3fs, PARDISO solves %.3fs, BLAS dense %.3fs of %.3fs for %d "
+                              "iterations, PARDISO factorisation %.1fs outside the rate)"
+                              % (rm["t_op"], rm["t_prec"], rm["t_dense"], rm["t_total"], rm["iters"], e_cpu.t_factor)))
+            except Exception as ex:  # the baseline must never take the GPU result down with it
+                cands.append((0.0, 0, "MKL path failed: %s" % ex))
+        else:
+            cands.append((0.0, 0, "libmkl_rt not on this host"))
+        best = max(cands, key=lambda c: c[0])
+        out["cpu_baseline"] = {"value": best[0], "unit": "iterations/s", "cores": best[1], "kind": "port",
+                               "sample": "same workload (matrix, scaling, partition, rhs), %d ECG iterations each; reported = the "
+                                         "faster of: [%s] = %.2f it/s; [%s] = %.2f it/s"
+                                         % (a.cpu_iters, cands[0][2], cands[0][0], cands[1][2], cands[1][0]),
                                "host_cores_online": os.cpu_count()}
     if rank == 0:
         print(json.dumps(out))

@@ -119,3 +119,21 @@ def test_block_jacobi_exact_and_spmm():
         s = slice(rowpos[p], rowpos[p + 1])
         D = B[s, s].toarray()
         np.testing.assert_allclose(D @ Z[s], X[s], rtol=1e-9, atol=1e-10)
+
+
+def test_mkl_cpu_path_reproduces_the_recorded_reference_history(golden):
+    """The CPU baseline of bench.py: the same algorithm on the reference's own kernels
+    (mkl_dcsrmm + MKL PARDISO).  Skipped where libmkl_rt is not installed."""
+    from oracle import mkl_path as M
+    if M.load_mkl() is None:
+        pytest.skip("libmkl_rt not available")
+    B, rowpos, rhs = _poisson24()
+    g = golden["poisson24_np8_t4"]
+    e = M.MklEcg(B, rowpos, 4, threads=4)
+    X = np.asfortranarray(np.random.default_rng(0).standard_normal((B.shape[0], 4)))
+    np.testing.assert_allclose(e.spmm(X), B @ X, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(e.precond(X), O.BlockJacobi(B, rowpos).apply(X), rtol=1e-10, atol=1e-11)
+    r = e.solve(rhs)
+    assert r["iters"] == g["odir"]["iters"]
+    assert abs(r["normb"] - g["normb"]) < 1e-13
+    np.testing.assert_allclose(r["res"], g["odir"]["res"], rtol=RTOL_HIST)
