@@ -183,7 +183,7 @@ def main():
                    "iterations_to_converge": state["last_iters"], "setup_seconds": t_setup,
                    "bj_max_bandwidth": int(prob.stat("bj_max_bandwidth")),
                    "spmm_blocks": int(prob.stat("spmm_blocks"))},
-        "roofline": {"kernel": "k_spmm_bsr3" if prob.stat("spmm_bsr3") else ("k_spmm_staged" if prob.stat("spmm_staged") else "k_spmm"), "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "k_spmm_runs" if prob.stat("spmm_runs") else ("k_spmm_staged" if prob.stat("spmm_staged") else "k_spmm"), "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": spmm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s,
                      "back_to_back_launch_us": 1e6 * spmm_b2b_s,

@@ -176,73 +176,66 @@ __global__ __launch_bounds__(WG) void k_spmm_staged(
   }
 }
 
-// 3x3-block staged SpMM (vector problems such as 3-D elasticity, dof = 3*node + c): lane =
-// node, 3*TS sums in registers; per block entry one 2-B slot, nine coalesced 8-B values and
-// one contiguous 24*TS-byte read of the neighbour node's three X rows from LDS.  8.2 B per
-// nonzero of matrix stream instead of 10, a third of the LDS reads and a ninth of the index
-// traffic of the scalar kernel.  One slice (64 nodes) per one-wave workgroup.
-// Opt-in (PREALPS_SPMM_BSR3=1): on Q1 elasticity 70^3 it measured 215 us against 181 us for
-// k_spmm_staged -- a third of the lanes per row leaves too few loads in flight.
+// Staged SpMM over runs of three consecutive LDS slots (rows whose nonzeros sit in groups
+// of neighbouring columns, e.g. the 3 dofs of a node): per run one coalesced 2-B slot, three
+// coalesced 8-B values and 3*TS/2 ds_read_b128 off one address -- 8.67 B of matrix stream
+// per nonzero instead of 10 and a third of the index arithmetic.  The staging area is
+// [external rows below | own rows | external rows above | two zero rows].
 template <int TS>
-__global__ __launch_bounds__(64) void k_spmm_bsr3(
-    int m, const long long* __restrict__ sl_off, const long long* __restrict__ sl_off9,
-    const int* __restrict__ sl_len, const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ col16, const double* __restrict__ bval,
-    const int* __restrict__ blk_ext_off, const int* __restrict__ ext_rows,
+__global__ __launch_bounds__(WG) void k_spmm_runs(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
     const int* __restrict__ order, int nlist, const double* __restrict__ X,
     const double* __restrict__ Xh, double* __restrict__ Y) {
   extern __shared__ double sx[];
   const int cpx = (nlist + 7) >> 3;
   const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
   if (logical >= nlist) return;
-  const int s = order[logical];
-  const int r0 = sl_row0[s], nown = sl_nrows[s];
-  const int e0 = blk_ext_off[s], next = blk_ext_off[s + 1] - e0;
-  const int lane = threadIdx.x;
-  constexpr int H = TS / 2;
+  const int b = order[logical];
+  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
+  const int r0 = sl_row0[s0];
+  const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
+  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0, nlow = blk_nlow[b];
+  const int tid = threadIdx.x;
+  constexpr int H = TS / 2;  // double2 per row
   {
     const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)r0 * TS);
     double2* dst = reinterpret_cast<double2*>(sx);
-    for (int i = lane; i < nown * H; i += 64) dst[i] = xsrc[i];
-    for (int q = lane; q < next * H; q += 64) {
+    for (int i = tid; i < nown * H; i += WG) dst[(size_t)nlow * H + i] = xsrc[i];
+    for (int q = tid; q < next * H; q += WG) {
       const int i = q / H, j = q - i * H;
       const int id = ext_rows[e0 + i];
       const double2* src = reinterpret_cast<const double2*>(id < m ? X + (size_t)id * TS
                                                                      : Xh + (size_t)(id - m) * TS);
-      dst[(size_t)(nown + i) * H + j] = src[j];
+      dst[(size_t)(i < nlow ? i : nown + i) * H + j] = src[j];
     }
+    if (tid < 2 * H) dst[(size_t)(nown + next) * H + tid] = make_double2(0.0, 0.0);
   }
   __syncthreads();
-  const int len = sl_len[s];
-  const unsigned short* __restrict__ cp = col16 + sl_off[s] + lane;
-  const double* __restrict__ vp = bval + sl_off9[s] + lane;
-  double acc[3][TS];
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int s = s0 + wave; s < s1; s += WG / 64) {
+    const long long off = sl_off[s];
+    const int len = sl_len[s];
+    const unsigned short* __restrict__ cp = slot16 + off + lane;
+    const double* __restrict__ vp = val + 3 * off + lane;
+    double acc[TS];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int c = 0; c < TS; ++c) acc[i][c] = 0.0;
-#pragma unroll 2
-  for (int k = 0; k < len; ++k) {
-    const int slot = cp[(size_t)k * 64];
-    double v[9];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) v[e] = vp[((size_t)k * 9 + e) * 64];
-    const double* __restrict__ xr = sx + (size_t)slot * TS;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      double x[TS];
-      const double2* q = reinterpret_cast<const double2*>(xr + j * TS);
-#pragma unroll
-      for (int h = 0; h < H; ++h) { const double2 t2 = q[h]; x[2 * h] = t2.x; x[2 * h + 1] = t2.y; }
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int c = 0; c < TS; ++c) acc[i][c] = fma(v[3 * i + j], x[c], acc[i][c]);
+    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < len; ++k) {
+      const int slot = cp[(size_t)k * 64];
+      const double v0 = vp[(size_t)(3 * k) * 64];
+      const double v1 = vp[(size_t)(3 * k + 1) * 64];
+      const double v2 = vp[(size_t)(3 * k + 2) * 64];
+      const double* __restrict__ xr = sx + (size_t)slot * TS;
+      spmm_fma_row<TS>(acc, v0, xr);
+      spmm_fma_row<TS>(acc, v1, xr + TS);
+      spmm_fma_row<TS>(acc, v2, xr + 2 * TS);
     }
-  }
-  if (3 * lane < nown) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) store_row<TS>(Y, (size_t)(r0 + 3 * lane + i), acc[i]);
+    if (lane < sl_nrows[s]) store_row<TS>(Y, (size_t)(sl_row0[s] + lane), acc);
   }
 }
 
@@ -1110,13 +1103,20 @@ template <int TS>
 static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, const double* X,
                        const double* Xh, double* Y) {
   if (nlist <= 0) return 0;
-  if (pl->bsr3) {
+  if (pl->runs) {
     const size_t lds = (size_t)pl->stage_cap * TS * 8;
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return kfail("hipFuncSetAttribute(k_spmm_runs)");
+      configured = lds;
+    }
     const int cpx = (nlist + 7) / 8;
-    hipLaunchKernelGGL((k_spmm_bsr3<TS>), dim3(cpx * 8), dim3(64), lds, cur_stream(), pl->m, pl->sl_off,
-                       pl->sl_off9, pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->bval,
-                       pl->blk_ext_off, pl->ext_rows, order, nlist, X, Xh, Y);
-    return kfail("k_spmm_bsr3");
+    hipLaunchKernelGGL((k_spmm_runs<TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
+                       pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
+    return kfail("k_spmm_runs");
   }
   if (pl->staged) {
     const size_t lds = (size_t)pl->stage_cap * TS * 8;

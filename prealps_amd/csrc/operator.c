@@ -38,7 +38,7 @@ typedef struct {
   /* SpMM plan */
   pa_spmm_plan_t plan;
   int* d_blk_slice; int* d_blk_win; int* d_order;
-  unsigned short* d_col16; int* d_blk_ext_off; int* d_ext_rows; long long* d_sl_off9;
+  unsigned short* d_col16; int* d_blk_ext_off; int* d_ext_rows; int* d_blk_nlow;
   int* lcol;             /* host: local column ids of the panel (own rows < m <= halo slots) */
   int plan_ts;           /* panel stride the current SpMM plan was cut for (0: none) */
   double stream_bytes;   /* bytes of matrix data one SpMM streams */
@@ -98,8 +98,8 @@ static void free_plan(pa_operator_t* o) {
   pa_rt_free(o->d_sl_off); pa_rt_free(o->d_sl_len); pa_rt_free(o->d_sl_row0); pa_rt_free(o->d_sl_nrows);
   pa_rt_free(o->d_col); pa_rt_free(o->d_val);
   pa_rt_free(o->d_blk_slice); pa_rt_free(o->d_blk_win); pa_rt_free(o->d_order);
-  pa_rt_free(o->d_col16); pa_rt_free(o->d_blk_ext_off); pa_rt_free(o->d_ext_rows); pa_rt_free(o->d_sl_off9);
-  o->d_sl_off9 = NULL;
+  pa_rt_free(o->d_col16); pa_rt_free(o->d_blk_ext_off); pa_rt_free(o->d_ext_rows); pa_rt_free(o->d_blk_nlow);
+  o->d_blk_nlow = NULL;
   o->d_sl_off = NULL; o->d_sl_len = o->d_sl_row0 = o->d_sl_nrows = o->d_col = NULL; o->d_val = NULL;
   o->d_blk_slice = o->d_blk_win = o->d_order = NULL; o->d_col16 = NULL; o->d_blk_ext_off = o->d_ext_rows = NULL;
   memset(&o->plan, 0, sizeof(o->plan));
@@ -126,7 +126,7 @@ void preAlps_OperatorFree(void) {
  * its LDS window is the subdomain's own row range, or the PREALPS_SPMM_WIN_CAP
  * rows around the block when the subdomain is larger than that. */
 static int build_plan_staged(pa_operator_t* o, int ts);
-static int build_plan_bsr3(pa_operator_t* o, int ts);
+static int build_plan_runs(pa_operator_t* o, int ts);
 
 static int build_plan(pa_operator_t* o, int ts) {
   const pa_operator_info_t* in = &o->info;
@@ -139,10 +139,10 @@ static int build_plan(pa_operator_t* o, int ts) {
    * slice (long rows: elasticity); short rows (7-point stencils) gather through L2 instead */
   int want = env_int("PREALPS_SPMM_STAGED", -1);
   if (want < 0 && ts >= 16) want = 0; /* wide panels: the 128-B X rows gather well from L2 (measured) */
-  if (want != 0 && env_int("PREALPS_SPMM_BSR3", 0)) {
-    /* vector problems with dense 3x3 node blocks: the most compact stream, but slower in
-     * practice than the scalar staged kernel (see kernels.hip), hence opt-in */
-    int rc = build_plan_bsr3(o, ts);
+  if (want != 0 && env_int("PREALPS_SPMM_RUNS", 1)) {
+    /* rows whose nonzeros come in runs of consecutive columns (vector problems: 3 dofs per
+     * node) share one LDS slot per run of three: 8.67 B per nonzero instead of 10 */
+    int rc = build_plan_runs(o, ts);
     if (rc < 0) return 1;
     if (rc == 0) { o->plan_ts = ts; return 0; }
     free_plan(o);
@@ -786,7 +786,7 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "spmm_stored_entries")) *value = o->sell_entries;
   else if (!strcmp(key, "spmm_stream_bytes")) *value = o->stream_bytes;
   else if (!strcmp(key, "spmm_staged")) *value = o->plan.staged;
-  else if (!strcmp(key, "spmm_bsr3")) *value = o->plan.bsr3;
+  else if (!strcmp(key, "spmm_runs")) *value = o->plan.runs;
   else if (!strcmp(key, "spmm_stage_rows")) *value = o->plan.stage_cap;
   else if (!strcmp(key, "spmm_interior_blocks")) *value = o->plan.n_interior;
   else if (!strcmp(key, "bj_factor_bytes")) *value = pa_bj_factor_bytes();
@@ -824,152 +824,194 @@ int preAlps_hip_reference_rhs(double* rhs_local) {
   return 0;
 }
 
-/* 3x3-block staged plan.  Returns 0 on success, 1 when the panel is not made of dense 3x3
- * node blocks (or a slice does not fit the staging area), -1 on error. */
-static int build_plan_bsr3(pa_operator_t* o, int ts) {
+/* Staged plan with one LDS slot per run of up to three consecutive columns.  The staging
+ * area lists the external rows below the block's own range, the own range, the external
+ * rows above it and two zero rows, so slots ascend with the column and a run never breaks
+ * at the edge of the own range.  A run covers slots [s, s+2]; entries of the row that fall
+ * inside it fill its three values, the rest are zeros.  Returns 0 on success, 1 when the
+ * plan does not pay (zero fill above 6 % of the plain SELL storage, external rows above a
+ * quarter of the matrix stream, or a slice that does not fit the staging area), -1 on error. */
+static int build_plan_runs(pa_operator_t* o, int ts) {
   const pa_operator_info_t* in = &o->info;
   const int* rowptr = in->A.rowPtr;
   const int* colind = o->lcol;
   const double* val = in->A.val;
   int m = in->m, ncols = m + in->halo;
-  if (m < 3 || m % 3 != 0 || in->halo % 3 != 0) return 1;
-  for (int p = in->part0; p <= in->part1; ++p) if ((in->rowPos[p] - in->row_off) % 3 != 0) return 1;
-  int nnodes = m / 3;
-  for (int i = 0; i < nnodes; ++i) {
-    int b0 = rowptr[3 * i], l = rowptr[3 * i + 1] - b0;
-    if (l % 3 != 0 || rowptr[3 * i + 2] - rowptr[3 * i + 1] != l || rowptr[3 * i + 3] - rowptr[3 * i + 2] != l) return 1;
-    for (int k = 0; k < l; k += 3) {
-      int c = colind[b0 + k];
-      if (c % 3 != 0) return 1;
-      for (int r = 0; r < 3; ++r)
-        for (int q = 0; q < 3; ++q)
-          if (colind[b0 + r * l + k + q] != c + q) return 1;
-    }
-  }
-  int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", 32768) / (ts * 8);
-  if (cap_rows > 65535) cap_rows = 65535;
+  int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", ts <= 4 ? 32768 : 65536) / (ts * 8) - 2;
+  if (cap_rows > 65533) cap_rows = 65533;
+  int blk_rows = env_int("PREALPS_SPMM_BLOCK_ROWS", 256);
+  if (blk_rows < 64) blk_rows = 64;
+  blk_rows &= ~63;
+  if (blk_rows > cap_rows) blk_rows = cap_rows & ~63;
+  if (blk_rows < 64) return 1;
   int nslices = 0;
-  for (int p = in->part0; p < in->part1; ++p) nslices += ((in->rowPos[p + 1] - in->rowPos[p]) / 3 + 63) / 64;
-  long long* sl_off = (long long*)malloc(((size_t)nslices + 1) * sizeof(long long));
-  long long* sl_off9 = (long long*)malloc(((size_t)nslices + 1) * sizeof(long long));
-  int* sl_len = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
-  int* sl_row0 = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
-  int* sl_nrows = (int*)malloc((nslices ? nslices : 1) * sizeof(int));
+  double plain = 0.0;
+  for (int p = in->part0; p < in->part1; ++p) nslices += (in->rowPos[p + 1] - in->rowPos[p] + 63) / 64;
+  size_t ns1 = (size_t)(nslices ? nslices : 1);
+  long long* sl_off = (long long*)malloc((ns1 + 1) * sizeof(long long));
+  int* sl_len = (int*)malloc(ns1 * sizeof(int));
+  int* sl_row0 = (int*)malloc(ns1 * sizeof(int));
+  int* sl_nrows = (int*)malloc(ns1 * sizeof(int));
   int s = 0;
-  sl_off[0] = 0; sl_off9[0] = 0;
   for (int p = in->part0; p < in->part1; ++p) {
     int pr0 = in->rowPos[p] - in->row_off, pr1 = in->rowPos[p + 1] - in->row_off;
-    for (int r = pr0; r < pr1; r += 192, ++s) {
-      int nr = pr1 - r < 192 ? pr1 - r : 192, len = 0;
-      for (int i = 0; i < nr; i += 3) { int l = (rowptr[r + i + 1] - rowptr[r + i]) / 3; if (l > len) len = l; }
-      sl_len[s] = len; sl_row0[s] = r; sl_nrows[s] = nr;
-      sl_off[s + 1] = sl_off[s] + (long long)len * 64;
-      sl_off9[s + 1] = sl_off9[s] + (long long)len * 9 * 64;
+    for (int r = pr0; r < pr1; r += 64, ++s) {
+      int nr = pr1 - r < 64 ? pr1 - r : 64, len = 0;
+      for (int i = 0; i < nr; ++i) { int l = rowptr[r + i + 1] - rowptr[r + i]; if (l > len) len = l; }
+      sl_row0[s] = r; sl_nrows[s] = nr;
+      plain += 64.0 * len;
     }
   }
-  size_t tot = (size_t)sl_off[nslices], tot9 = (size_t)sl_off9[nslices];
-  int* blk_ext_off = (int*)malloc(((size_t)nslices + 1) * sizeof(int));
-  char* needs_halo = (char*)malloc(nslices ? nslices : 1);
+  int* blk_slice = (int*)malloc((ns1 + 1) * sizeof(int));
+  int* blk_ext_off = (int*)malloc((ns1 + 1) * sizeof(int));
+  int* blk_nlow = (int*)malloc(ns1 * sizeof(int));
+  char* needs_halo = (char*)malloc(ns1);
   int* stamp = (int*)calloc(ncols ? ncols : 1, sizeof(int));
   int* slot_of = (int*)malloc((ncols ? ncols : 1) * sizeof(int));
   size_t ext_cap = 1024, next_tot = 0;
   int* ext_rows = (int*)malloc(ext_cap * sizeof(int));
-  unsigned short* c16 = (unsigned short*)malloc((tot + 64) * sizeof(unsigned short));
-  double* bval = (double*)calloc(tot9 + 64, sizeof(double));
-  int rc = 0, max_stage = 0;
-  if (!c16 || !bval || !stamp || !slot_of || !ext_rows) rc = -1;
-  for (int q = 0; q < nslices && !rc; ++q) {
-    int r0 = sl_row0[q], nown = sl_nrows[q], r1 = r0 + nown, len = sl_len[q], next = 0;
-    size_t mark0 = next_tot;
-    char h = 0;
-    for (int i = 0; i < nown; i += 3) {
-      int b0 = rowptr[r0 + i], l = rowptr[r0 + i + 1] - b0;
-      for (int k = 0; k < l; k += 3) {
-        int c = colind[b0 + k];
+  size_t run_cap = (size_t)(plain / 3.0 * 1.1) + 4096, nruns = 0;   /* stored runs (64 per step of a slice) */
+  unsigned short* c16 = (unsigned short*)malloc(run_cap * sizeof(unsigned short));
+  double* sval = (double*)malloc(run_cap * 3 * sizeof(double));
+  int nblk = 0, q = 0, max_stage = 0, rc = 0, gen = 0;
+  if (!c16 || !sval || !stamp || !slot_of || !ext_rows) rc = -1;
+  sl_off[0] = 0;
+  while (q < nslices && !rc) {
+    int nsl = 0;
+    while (q + nsl < nslices && (nsl + 1) * 64 <= blk_rows) ++nsl;
+    for (;;) {
+      int r0 = sl_row0[q], r1 = sl_row0[q + nsl - 1] + sl_nrows[q + nsl - 1];
+      int nown = r1 - r0, next = 0, nlow = 0;
+      size_t mark0 = next_tot;
+      char h = 0;
+      ++gen;
+      for (int k = rowptr[r0]; k < rowptr[r1]; ++k) {
+        int c = colind[k];
         if (c >= r0 && c < r1) continue;
-        if (stamp[c] != q + 1) {
-          stamp[c] = q + 1;
-          if (next_tot + 3 > ext_cap) { ext_cap *= 2; ext_rows = (int*)realloc(ext_rows, ext_cap * sizeof(int)); }
-          ext_rows[next_tot++] = c; next += 3; /* node: its three rows follow after sorting */
+        if (stamp[c] != gen) {
+          stamp[c] = gen;
+          if (next_tot == ext_cap) { ext_cap *= 2; ext_rows = (int*)realloc(ext_rows, ext_cap * sizeof(int)); }
+          ext_rows[next_tot++] = c; ++next;
+          if (c < r0) ++nlow;
           if (c >= m) h = 1;
         }
       }
-    }
-    if (nown + next > cap_rows) { rc = 1; break; }
-    /* sort the node list, then expand every node to its three rows in place */
-    int* er = ext_rows + mark0;
-    int nn = next / 3;
-    for (int a = 1; a < nn; ++a) { int v = er[a], b2 = a; while (b2 > 0 && er[b2 - 1] > v) { er[b2] = er[b2 - 1]; --b2; } er[b2] = v; }
-    if (next_tot + 2 * (size_t)nn > ext_cap) { while (next_tot + 2 * (size_t)nn > ext_cap) ext_cap *= 2; ext_rows = (int*)realloc(ext_rows, ext_cap * sizeof(int)); er = ext_rows + mark0; }
-    for (int a = nn - 1; a >= 0; --a) { int c = er[a]; er[3 * a] = c; er[3 * a + 1] = c + 1; er[3 * a + 2] = c + 2; slot_of[c] = nown + 3 * a; }
-    next_tot = mark0 + (size_t)next;
-    unsigned short* cc = c16 + sl_off[q];
-    double* vv = bval + sl_off9[q];
-    for (int i = 0; i < 64; ++i) {
-      int have = 3 * i < nown;
-      int row = have ? r0 + 3 * i : r0;
-      int b0 = rowptr[row], l = have ? rowptr[row + 1] - b0 : 0;
-      for (int k = 0; k < len; ++k) {
-        if (3 * k < l) {
-          int c = colind[b0 + 3 * k];
-          cc[(size_t)k * 64 + i] = (unsigned short)((c >= r0 && c < r1) ? c - r0 : slot_of[c]);
-          for (int ri = 0; ri < 3; ++ri)
-            for (int cj = 0; cj < 3; ++cj)
-              vv[((size_t)k * 9 + 3 * ri + cj) * 64 + i] = val[rowptr[row + ri] + 3 * k + cj];
-        } else {
-          cc[(size_t)k * 64 + i] = (unsigned short)(row - r0); /* zero block on the own node */
-        }
+      if (nown + next > cap_rows) {
+        next_tot = mark0;
+        if (nsl == 1) { rc = 1; break; }
+        nsl = (nsl + 1) / 2;
+        continue;
       }
+      int* er = ext_rows + mark0;
+      for (int a = 1; a < next; ++a) { int v = er[a], b2 = a; while (b2 > 0 && er[b2 - 1] > v) { er[b2] = er[b2 - 1]; --b2; } er[b2] = v; }
+      for (int a = 0; a < next; ++a) slot_of[er[a]] = a < nlow ? a : nown + a;
+      for (int sq = q; sq < q + nsl; ++sq) {
+        int r = sl_row0[sq], nr = sl_nrows[sq], len3 = 0;
+        /* pass 1: runs per row */
+        for (int i = 0; i < nr; ++i) {
+          int row = r + i, nrun = 0, last = -4;
+          for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+            int c = colind[k], sl = (c >= r0 && c < r1) ? nlow + c - r0 : slot_of[c];
+            if (sl > last + 2 || sl < last) { last = sl; ++nrun; }
+          }
+          if (nrun > len3) len3 = nrun;
+        }
+        if (nruns + (size_t)len3 * 64 > run_cap) {
+          run_cap = (run_cap + (size_t)len3 * 64) * 3 / 2;
+          c16 = (unsigned short*)realloc(c16, run_cap * sizeof(unsigned short));
+          sval = (double*)realloc(sval, run_cap * 3 * sizeof(double));
+          if (!c16 || !sval) { rc = -1; break; }
+        }
+        unsigned short* cc = c16 + nruns;
+        double* vv = sval + 3 * nruns;
+        for (int i = 0; i < 64; ++i) {
+          int row = i < nr ? r + i : r, own = nlow + row - r0, nrun = 0, last = -4;
+          if (i < nr)
+            for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+              int c = colind[k], sl = (c >= r0 && c < r1) ? nlow + c - r0 : slot_of[c];
+              if (sl > last + 2 || sl < last) {
+                last = sl;
+                cc[(size_t)nrun * 64 + i] = (unsigned short)sl;
+                vv[((size_t)3 * nrun + 0) * 64 + i] = 0.0; vv[((size_t)3 * nrun + 1) * 64 + i] = 0.0;
+                vv[((size_t)3 * nrun + 2) * 64 + i] = 0.0;
+                ++nrun;
+              }
+              vv[((size_t)3 * (nrun - 1) + (sl - last)) * 64 + i] = val[k];
+            }
+          for (int k = nrun; k < len3; ++k) {     /* padding: zeros against the row's own slot */
+            cc[(size_t)k * 64 + i] = (unsigned short)own;
+            vv[((size_t)3 * k + 0) * 64 + i] = 0.0; vv[((size_t)3 * k + 1) * 64 + i] = 0.0;
+            vv[((size_t)3 * k + 2) * 64 + i] = 0.0;
+          }
+        }
+        sl_len[sq] = len3;
+        nruns += (size_t)len3 * 64;
+        sl_off[sq + 1] = (long long)nruns;
+      }
+      if (rc) break;
+      if (nown + next + 2 > max_stage) max_stage = nown + next + 2;
+      blk_slice[nblk] = q; blk_ext_off[nblk] = (int)mark0; blk_nlow[nblk] = nlow; needs_halo[nblk] = h;
+      ++nblk;
+      q += nsl;
+      break;
     }
-    if (nown + next > max_stage) max_stage = nown + next;
-    blk_ext_off[q] = (int)mark0; needs_halo[q] = h;
   }
   if (!rc) {
-    blk_ext_off[nslices] = (int)next_tot;
-    for (size_t k = tot; k < tot + 64; ++k) c16[k] = 0;
-    int* order = (int*)malloc((nslices > 0 ? nslices : 1) * sizeof(int));
+    double stream = 26.0 * (double)nruns + 4.0 * (double)next_tot;
+    double ext_bytes = (double)next_tot * ts * 8.0;
+    /* PREALPS_SPMM_RUNS=2 forces the plan (tests on irregular patterns) */
+    if (env_int("PREALPS_SPMM_RUNS", 1) < 2 && (3.0 * (double)nruns > 1.06 * plain || ext_bytes >= 0.25 * 10.0 * plain)) rc = 1;
+    else o->stream_bytes = stream;
+  }
+  if (!rc) {
+    blk_slice[nblk] = nslices; blk_ext_off[nblk] = (int)next_tot;
+    int* order = (int*)malloc((nblk > 0 ? nblk : 1) * sizeof(int));
     int ni = 0;
-    for (int b = 0; b < nslices; ++b) if (!needs_halo[b]) order[ni++] = b;
+    for (int b = 0; b < nblk; ++b) if (!needs_halo[b]) order[ni++] = b;
     int k2 = ni;
-    for (int b = 0; b < nslices; ++b) if (needs_halo[b]) order[k2++] = b;
-    o->d_sl_off = (long long*)pa_rt_malloc(((size_t)nslices + 1) * sizeof(long long));
-    o->d_sl_off9 = (long long*)pa_rt_malloc(((size_t)nslices + 1) * sizeof(long long));
-    o->d_sl_len = (int*)pa_rt_malloc((nslices ? nslices : 1) * sizeof(int));
-    o->d_sl_row0 = (int*)pa_rt_malloc((nslices ? nslices : 1) * sizeof(int));
-    o->d_sl_nrows = (int*)pa_rt_malloc((nslices ? nslices : 1) * sizeof(int));
-    o->d_col16 = (unsigned short*)pa_rt_malloc((tot + 64) * sizeof(unsigned short));
-    o->d_val = (double*)pa_rt_malloc((tot9 + 64) * sizeof(double));
-    o->d_blk_ext_off = (int*)pa_rt_malloc(((size_t)nslices + 1) * sizeof(int));
+    for (int b = 0; b < nblk; ++b) if (needs_halo[b]) order[k2++] = b;
+    size_t nr1 = nruns ? nruns : 1;
+    o->d_sl_off = (long long*)pa_rt_malloc((ns1 + 1) * sizeof(long long));
+    o->d_sl_len = (int*)pa_rt_malloc(ns1 * sizeof(int));
+    o->d_sl_row0 = (int*)pa_rt_malloc(ns1 * sizeof(int));
+    o->d_sl_nrows = (int*)pa_rt_malloc(ns1 * sizeof(int));
+    o->d_col16 = (unsigned short*)pa_rt_malloc(nr1 * sizeof(unsigned short));
+    o->d_val = (double*)pa_rt_malloc(nr1 * 3 * sizeof(double));
+    o->d_blk_slice = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
+    o->d_blk_ext_off = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
+    o->d_blk_nlow = (int*)pa_rt_malloc((size_t)(nblk > 0 ? nblk : 1) * sizeof(int));
     o->d_ext_rows = (int*)pa_rt_malloc((next_tot ? next_tot : 1) * sizeof(int));
-    o->d_order = (int*)pa_rt_malloc((nslices > 0 ? nslices : 1) * sizeof(int));
-    int bad = (!o->d_sl_off || !o->d_sl_off9 || !o->d_sl_len || !o->d_sl_row0 || !o->d_sl_nrows || !o->d_col16 ||
-               !o->d_val || !o->d_blk_ext_off || !o->d_ext_rows || !o->d_order);
+    o->d_order = (int*)pa_rt_malloc((nblk > 0 ? nblk : 1) * sizeof(int));
+    int bad = (!o->d_sl_off || !o->d_sl_len || !o->d_sl_row0 || !o->d_sl_nrows || !o->d_col16 || !o->d_val ||
+               !o->d_blk_slice || !o->d_blk_ext_off || !o->d_blk_nlow || !o->d_ext_rows || !o->d_order);
     bad = bad || pa_rt_h2d(o->d_sl_off, sl_off, ((size_t)nslices + 1) * sizeof(long long));
-    bad = bad || pa_rt_h2d(o->d_sl_off9, sl_off9, ((size_t)nslices + 1) * sizeof(long long));
     bad = bad || pa_rt_h2d(o->d_sl_len, sl_len, nslices * sizeof(int));
     bad = bad || pa_rt_h2d(o->d_sl_row0, sl_row0, nslices * sizeof(int));
     bad = bad || pa_rt_h2d(o->d_sl_nrows, sl_nrows, nslices * sizeof(int));
-    bad = bad || pa_rt_h2d(o->d_col16, c16, (tot + 64) * sizeof(unsigned short));
-    bad = bad || pa_rt_h2d(o->d_val, bval, (tot9 + 64) * sizeof(double));
-    bad = bad || pa_rt_h2d(o->d_blk_ext_off, blk_ext_off, ((size_t)nslices + 1) * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_col16, c16, nruns * sizeof(unsigned short));
+    bad = bad || pa_rt_h2d(o->d_val, sval, nruns * 3 * sizeof(double));
+    bad = bad || pa_rt_h2d(o->d_blk_slice, blk_slice, ((size_t)nblk + 1) * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_blk_ext_off, blk_ext_off, ((size_t)nblk + 1) * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_blk_nlow, blk_nlow, (size_t)nblk * sizeof(int));
     bad = bad || pa_rt_h2d(o->d_ext_rows, ext_rows, next_tot * sizeof(int));
-    bad = bad || pa_rt_h2d(o->d_order, order, nslices * sizeof(int));
+    bad = bad || pa_rt_h2d(o->d_order, order, nblk * sizeof(int));
     free(order);
     if (bad) { PA_FAIL("uploading the SpMM plan failed: %s", pa_rt_error()); rc = -1; }
     else {
       pa_spmm_plan_t* pl = &o->plan;
-      pl->m = m; pl->nslices = nslices; pl->sl_off = o->d_sl_off; pl->sl_off9 = o->d_sl_off9; pl->sl_len = o->d_sl_len;
-      pl->sl_row0 = o->d_sl_row0; pl->sl_nrows = o->d_sl_nrows; pl->bval = o->d_val; pl->val = o->d_val;
-      pl->nblk = nslices; pl->order = o->d_order; pl->n_interior = ni;
-      pl->staged = 1; pl->bsr3 = 1; pl->col16 = o->d_col16; pl->blk_ext_off = o->d_blk_ext_off; pl->ext_rows = o->d_ext_rows;
+      pl->m = m; pl->nslices = nslices; pl->sl_off = o->d_sl_off; pl->sl_len = o->d_sl_len;
+      pl->sl_row0 = o->d_sl_row0; pl->sl_nrows = o->d_sl_nrows; pl->val = o->d_val;
+      pl->nblk = nblk; pl->blk_slice = o->d_blk_slice; pl->order = o->d_order; pl->n_interior = ni;
+      pl->staged = 1; pl->runs = 1; pl->col16 = o->d_col16; pl->blk_ext_off = o->d_blk_ext_off;
+      pl->blk_nlow = o->d_blk_nlow; pl->ext_rows = o->d_ext_rows;
       pl->stage_cap = max_stage;
-      o->sell_entries = (double)tot9;
-      o->stream_bytes = 8.0 * (double)tot9 + 2.0 * (double)tot + 4.0 * (double)next_tot;
+      o->sell_entries = 3.0 * (double)nruns;
     }
   } else if (rc < 0) {
     PA_FAIL("out of host memory for the SpMM plan");
   }
-  free(sl_off); free(sl_off9); free(sl_len); free(sl_row0); free(sl_nrows);
-  free(blk_ext_off); free(needs_halo); free(stamp); free(slot_of); free(ext_rows); free(c16); free(bval);
+  free(sl_off); free(sl_len); free(sl_row0); free(sl_nrows);
+  free(blk_slice); free(blk_ext_off); free(blk_nlow); free(needs_halo); free(stamp); free(slot_of); free(ext_rows);
+  free(c16); free(sval);
   return rc;
 }

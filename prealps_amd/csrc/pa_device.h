@@ -76,12 +76,12 @@ typedef struct {
   const int* blk_ext_off;   /* nblk+1: range of the block in ext_rows */
   const int* ext_rows;      /* local row ids (>= m: halo slot) staged after the own rows */
   int stage_cap;            /* rows of the largest staging area */
-  /* 3x3-block variant of the staged plan (vector problems, dof = 3*node + c): a slice is 64
-   * nodes, bval holds the 9 values of a block entry-major ([k][e][lane]), col16 the LDS slot
-   * of the neighbour node's first row.  One slice per (one-wave) workgroup. */
-  int bsr3;
-  const double* bval;
-  const long long* sl_off9; /* nslices+1: offset of the slice in bval */
+  /* run variant of the staged plan: `col16` holds one LDS slot per run of three consecutive
+   * slots and `val` three values per run ([k][3][lane], sl_off / sl_len count runs); the
+   * staging area is [external rows below the own range | own rows | external rows above |
+   * two zero rows], blk_nlow = how many of a block's external rows lie below its own range. */
+  int runs;
+  const int* blk_nlow;
 } pa_spmm_plan_t;
 /* phase 0: interior blocks, 1: halo-reading blocks, 2: all */
 int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo,

@@ -27,6 +27,8 @@ def _worker(rank, world, port, alg, q):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         os.environ["LOCAL_RANK"] = "0"
+        if alg == "fused":
+            os.environ["PREALPS_SPMM_RUNS"] = "2"   # halo slots inside the run plan of the SpMM
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)

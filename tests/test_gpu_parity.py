@@ -92,6 +92,32 @@ def test_spmm_and_block_solve_on_ragged_rows():
         prob.close()
 
 
+@pytest.mark.parametrize("t", [2, 4, 8])
+@pytest.mark.parametrize("kind", ["random", "poisson", "elasticity_cut"])
+def test_spmm_run_plan_on_irregular_patterns(kind, t, monkeypatch):
+    """The run plan (one slot per three consecutive staging slots) forced onto patterns it
+    would not choose: broken runs, gaps inside a run, runs that straddle the edge of a
+    block's own rows, and subdomains that cut a node's three dofs apart."""
+    monkeypatch.setenv("PREALPS_SPMM_RUNS", "2")
+    from oracle import oracle as O
+    from prealps_amd import gen
+    if kind == "random":
+        A, P, part = _random_spd(1500, 0.004, 11), 7, None
+    elif kind == "poisson":
+        A, P, part = O.poisson3d(12), 5, None
+    else:
+        rp, ci, v = gen.elasticity3d_csr(7)
+        A, P, part = sp.csr_matrix((v, ci, rp), shape=(3 * 343, 3 * 343)), 8, None   # contiguous rows: 1029/8 cuts nodes
+    prob, B, rowpos = _problem(A, P, part)
+    try:
+        X = np.random.default_rng(5).standard_normal((B.shape[0], t))
+        ref = O.spmm(B, X)
+        np.testing.assert_allclose(prob.block_operator(X, t), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+        assert prob.stat("spmm_runs") == 1.0
+    finally:
+        prob.close()
+
+
 def test_ecg_odir_history_vs_recorded_reference(poisson24, golden):
     prob, B, rowpos = poisson24
     g = golden["poisson24_np8_t4"]
@@ -200,12 +226,12 @@ def test_c_driver_end_to_end(tmp_path, golden):
     assert it == golden["lfat5"]["np2_t2_odir"]["iters"] and res < 1e-11
 
 
-@pytest.mark.parametrize("bsr3", ["0", "1"])
-def test_elasticity_q1_parity(bsr3, monkeypatch):
+@pytest.mark.parametrize("runs", ["0", "1"])
+def test_elasticity_q1_parity(runs, monkeypatch):
     """3 dofs per node, 81 nonzeros per interior row, coefficient jumps of 1e10: the
-    matrix class of the headline metric (long SELL slices, wider bands); with the scalar
-    staged SpMM (default) and with the opt-in 3x3-block one."""
-    monkeypatch.setenv("PREALPS_SPMM_BSR3", bsr3)
+    matrix class of the headline metric (long SELL slices, wider bands); with the staged
+    SpMM that shares one LDS slot per run of three columns (default) and the scalar one."""
+    monkeypatch.setenv("PREALPS_SPMM_RUNS", runs)
     import prealps_amd as pa
     from prealps_amd import gen
     from oracle import oracle as O
@@ -219,7 +245,7 @@ def test_elasticity_q1_parity(bsr3, monkeypatch):
         X = np.random.default_rng(3).standard_normal((B.shape[0], 4))
         ref = O.spmm(B, X)
         np.testing.assert_allclose(prob.block_operator(X, 4), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
-        assert prob.stat("spmm_bsr3") == float(bsr3) and prob.stat("spmm_staged") == 1.0
+        assert prob.stat("spmm_runs") == float(runs) and prob.stat("spmm_staged") == 1.0
         zr = O.BlockJacobi(B, rowpos).apply(X)
         np.testing.assert_allclose(prob.block_jacobi_apply(X, 4), zr, rtol=1e-8, atol=1e-9 * np.abs(zr).max())
         rhs = prob.reference_rhs()
