@@ -231,15 +231,23 @@ int _preAlps_ECGSplit(double* x, CPLM_Mat_Dense_t* XSplit, int colIndex) {
  * while the host reads the norm. */
 static int stopping_begin(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   int T = ecg->enlFac;
-  if (!pv->rtr_valid) {
-    PA_CHECK(pa_k_colnorm2(pv->m, pv->ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
+  int single = pa_world_size() == 1;
+  if (pv->rtr_valid < 2) {
+    if (!pv->rtr_valid) {
+      PA_CHECK(pa_k_colnorm2(pv->m, pv->ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
+    }
+    PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2, pv->d_info));
+    pv->rtr_valid = 3;   /* summed, but not on the host yet */
   }
-  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2, pv->d_info));
+  /* rtr_valid == 2: the update kernel summed the norm itself and, in a single-process run,
+   * already wrote it to the pinned words the host reads */
+  if (!single || pv->rtr_valid == 3) {
+    double t0 = pa_wtime();
+    if (pa_allreduce(pv->d_res2, 1)) return 1;
+    ecg->comm_t += pa_wtime() - t0;
+    PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->d_res2, 2 * sizeof(double)));
+  }
   pv->rtr_valid = 0;
-  double t0 = pa_wtime();
-  if (pa_allreduce(pv->d_res2, 1)) return 1;
-  ecg->comm_t += pa_wtime() - t0;
-  PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->d_res2, 2 * sizeof(double)));
   PA_CHECK(pa_rt_event_record(pv->ev_res));
   return 0;
 }
@@ -271,12 +279,12 @@ int preAlps_ECGStoppingCriterion(preAlps_ECG_t* ecg, int* stop) {
 /* W = AP^T P -> all-reduce -> U^T U ; P <- P U^-1 ; AP <- AP U^-1 ;
  * alpha = P^T R -> all-reduce   (ecg.c:311-333, :425-443) */
 static int a_orthonormalise_and_alpha(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
-  int nb = 0, m = pv->m, ts = pv->ts;
+  int m = pv->m, ts = pv->ts;
   double t0;
   pa_time_begin(PA_T_GRAM);
   t0 = pa_wtime();
-  PA_CHECK(pa_k_gram(m, ts, ecg->AP->val, NULL, ecg->P->val, pv->d_partials, &nb));
-  PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, t, 0, t, pv->d_mu, t));
+  PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, NULL, ecg->P->val, pv->d_partials, t, 0, t, pv->d_mu, t,
+                            0, 0, NULL, NULL, NULL));
   ecg->gemm_t += pa_wtime() - t0;
   pa_time_end(PA_T_GRAM);
   t0 = pa_wtime();
@@ -294,9 +302,8 @@ static int a_orthonormalise_and_alpha(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t)
   pa_time_end(PA_T_TRSM);
   pa_time_begin(PA_T_GRAM);
   t0 = pa_wtime();
-  PA_CHECK(pa_k_gram(m, ts, ecg->P->val, NULL, ecg->R->val, pv->d_partials, &nb));
-  PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, ecg->alpha->info.m, 0, ecg->alpha->info.n,
-                       pv->d_alpha, ecg->alpha->info.lda));
+  PA_CHECK(pa_k_gram_finish(m, ts, ecg->P->val, NULL, ecg->R->val, pv->d_partials, ecg->alpha->info.m, 0,
+                            ecg->alpha->info.n, pv->d_alpha, ecg->alpha->info.lda, 0, 0, NULL, NULL, NULL));
   ecg->gemm_t += pa_wtime() - t0;
   pa_time_end(PA_T_GRAM);
   t0 = pa_wtime();
@@ -312,27 +319,39 @@ static int a_orthonormalise_and_alpha(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t)
  * ecg.c:425-443 + :500-501; alpha is formed from the Gram of the un-normalised P. */
 static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
   int nb = 0, m = pv->m, ts = pv->ts, T = ecg->enlFac;
+  int single = pa_world_size() == 1;
   double* buf = pv->d_q; /* (t+T) x t */
   double t0 = pa_wtime();
   pa_time_begin(PA_T_GRAM);
-  PA_CHECK(pa_k_gram(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, &nb));
-  PA_CHECK(pa_k_finish(pv->d_partials, nb, 2, ts, t, T, t, buf, t + T));
-  pa_time_end(PA_T_GRAM);
-  ecg->gemm_t += pa_wtime() - t0;
-  t0 = pa_wtime();
-  if (pa_allreduce(buf, (t + T) * t)) return 1;
-  ecg->comm_t += pa_wtime() - t0;
-  t0 = pa_wtime();
-  pa_time_begin(PA_T_SMALL);
-  PA_CHECK(pa_k_potrf_alpha(buf, t, T, pv->d_mu, pv->d_alpha, pv->d_info));
-  pa_time_end(PA_T_SMALL);
-  ecg->potrf_t += pa_wtime() - t0;
+  if (single) {
+    /* nothing to reduce across processes: the Gram kernel's last workgroup sums the partial
+     * blocks and factors them right away */
+    PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, t, T, t, buf, t + T,
+                              t, T, pv->d_mu, pv->d_alpha, pv->d_info));
+    pa_time_end(PA_T_GRAM);
+    ecg->gemm_t += pa_wtime() - t0;
+  } else {
+    PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, t, T, t, buf, t + T,
+                              0, 0, NULL, NULL, NULL));
+    pa_time_end(PA_T_GRAM);
+    ecg->gemm_t += pa_wtime() - t0;
+    t0 = pa_wtime();
+    if (pa_allreduce(buf, (t + T) * t)) return 1;
+    ecg->comm_t += pa_wtime() - t0;
+    t0 = pa_wtime();
+    pa_time_begin(PA_T_SMALL);
+    PA_CHECK(pa_k_potrf_alpha(buf, t, T, pv->d_mu, pv->d_alpha, pv->d_info));
+    pa_time_end(PA_T_SMALL);
+    ecg->potrf_t += pa_wtime() - t0;
+  }
   t0 = pa_wtime();
   pa_time_begin(PA_T_UPDATE);
   PA_CHECK(pa_k_trsm_update(m, ts, t, ecg->X->info.n, pv->d_mu, pv->d_alpha, ecg->P->val, ecg->AP->val,
-                            pv->d_X, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
+                            pv->d_X, pv->d_R, pv->d_rtr_part, &nb, T, pv->d_res2, pv->d_info,
+                            single ? pv->h_pin : NULL));
+  pv->rtr_nblk = nb;
   pa_time_end(PA_T_UPDATE);
-  pv->rtr_valid = 1;
+  pv->rtr_valid = 2;
   ecg->trsm_t += pa_wtime() - t0;
   return 0;
 }
@@ -342,9 +361,10 @@ static int update_iterate(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   double t0 = pa_wtime();
   pa_time_begin(PA_T_UPDATE);
   PA_CHECK(pa_k_update_xr(pv->m, pv->ts, ecg->P->info.n, ecg->X->info.n, pv->d_alpha, ecg->P->val,
-                          ecg->AP->val, pv->d_X, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
+                          ecg->AP->val, pv->d_X, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk, ecg->enlFac,
+                          pv->d_res2, pv->d_info, pa_world_size() == 1 ? pv->h_pin : NULL));
   pa_time_end(PA_T_UPDATE);
-  pv->rtr_valid = 1;
+  pv->rtr_valid = 2;
   ecg->gemm_t += pa_wtime() - t0;
   return 0;
 }
@@ -374,15 +394,14 @@ static int shift_directions(preAlps_ECG_t* ecg, ecg_priv_t* pv, int ncopy) {
 /* beta = AV^T Z over kbs columns of [slot 0 | slot 1] -> all-reduce ;
  * Z -= V beta (ecg.c:510-517) */
 static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
-  int T = ecg->enlFac, nb = 0;
+  int T = ecg->enlFac;
   int kb = ecg->beta->info.m; /* rows of beta = columns of V in use */
   int a_lo = kb < T ? kb : T, a_hi = kb - a_lo;
   double t0 = pa_wtime();
   pa_time_begin(PA_T_GRAM);
-  PA_CHECK(pa_k_gram(pv->m, pv->ts, pv->buf_av[0], a_hi > 0 ? pv->buf_av[1] : NULL, pv->buf_z,
-                     pv->d_partials, &nb));
-  PA_CHECK(pa_k_finish(pv->d_partials, nb, a_hi > 0 ? 2 : 1, pv->ts, a_lo, a_hi, ecg->beta->info.n,
-                       pv->d_beta, ecg->beta->info.lda));
+  PA_CHECK(pa_k_gram_finish(pv->m, pv->ts, pv->buf_av[0], a_hi > 0 ? pv->buf_av[1] : NULL, pv->buf_z,
+                            pv->d_partials, a_lo, a_hi, ecg->beta->info.n, pv->d_beta, ecg->beta->info.lda,
+                            0, 0, NULL, NULL, NULL));
   pa_time_end(PA_T_GRAM);
   ecg->gemm_t += pa_wtime() - t0;
   t0 = pa_wtime();
@@ -528,20 +547,21 @@ int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
 int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
   ecg_priv_t* pv = priv_of(ecg);
   if (!pv) return PA_FAIL("solver not initialised");
-  int m = pv->m, ts = pv->ts, nrhs = ecg->enlFac, nb = 0;
+  int m = pv->m, ts = pv->ts, nrhs = ecg->enlFac;
   int t = ecg->P->info.n;
   double t0 = pa_wtime();
   /* the four local Gram blocks, stacked [alpha | beta | mu | RtR] (ecg.c:554-560) */
   pa_time_begin(PA_T_GRAM);
-  PA_CHECK(pa_k_gram(m, ts, ecg->P->val, NULL, ecg->R->val, pv->d_partials, &nb));
-  PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, ecg->alpha->info.m, 0, ecg->alpha->info.n, pv->d_alpha, ecg->alpha->info.lda));
+  PA_CHECK(pa_k_gram_finish(m, ts, ecg->P->val, NULL, ecg->R->val, pv->d_partials, ecg->alpha->info.m, 0,
+                            ecg->alpha->info.n, pv->d_alpha, ecg->alpha->info.lda, 0, 0, NULL, NULL, NULL));
   {
     int kb = ecg->beta->info.m, a_lo = kb < nrhs ? kb : nrhs, a_hi = kb - a_lo;
-    PA_CHECK(pa_k_gram(m, ts, pv->buf_av[0], a_hi > 0 ? pv->buf_av[1] : NULL, pv->buf_z, pv->d_partials, &nb));
-    PA_CHECK(pa_k_finish(pv->d_partials, nb, a_hi > 0 ? 2 : 1, ts, a_lo, a_hi, ecg->beta->info.n, pv->d_beta, ecg->beta->info.lda));
+    PA_CHECK(pa_k_gram_finish(m, ts, pv->buf_av[0], a_hi > 0 ? pv->buf_av[1] : NULL, pv->buf_z, pv->d_partials,
+                              a_lo, a_hi, ecg->beta->info.n, pv->d_beta, ecg->beta->info.lda, 0, 0, NULL, NULL,
+                              NULL));
   }
-  PA_CHECK(pa_k_gram(m, ts, ecg->AP->val, NULL, ecg->P->val, pv->d_partials, &nb));
-  PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, t, 0, t, pv->d_mu, t));
+  PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, NULL, ecg->P->val, pv->d_partials, t, 0, t, pv->d_mu, t, 0, 0,
+                            NULL, NULL, NULL));
   /* R has not changed since the previous call's update: its column norms are
    * already there, except on the first call */
   if (!pv->rtr_valid) PA_CHECK(pa_k_colnorm2(m, ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));

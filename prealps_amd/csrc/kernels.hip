@@ -247,6 +247,115 @@ __global__ __launch_bounds__(WG) void k_pack_rows(int n, const int* __restrict__
   if (i < n) out[(size_t)i * TS + c] = X[(size_t)idx[i] * TS + c];
 }
 
+// ------------------------------------------------ small finishing steps ----
+// Measured and rejected: letting the last workgroup of the producing kernel (ticket counter)
+// do these sums.  The device-scope release every workgroup needs before taking its ticket
+// writes the whole dirty L2 back on gfx950 (one L2 per XCD): +130 us per iteration.
+// Sum the per-workgroup partial blocks (fixed order) and scatter the active
+// sub-block into the reference's t x t layout.  BS threads, red = BS doubles.
+template <int BS>
+__device__ __forceinline__ void finish_sum(const double* partials, int nblk, int npan, int ts,
+                                           int a_lo, int a_hi, int nb, double* out, int ld_out,
+                                           double* red) {
+  const int ldp = npan * ts;
+  const int na = a_lo + a_hi;
+  const int ne = na * nb;
+  int ner = 1;
+  while (ner < ne && ner < BS) ner <<= 1;
+  const int nsl = BS / ner;
+  const int tid = threadIdx.x;
+  const int e0 = tid % ner, s = tid / ner;
+  for (int base = 0; base < ne; base += ner) {
+    const int e = base + e0;
+    double sum = 0.0;
+    int i = 0, j = 0;
+    if (e < ne) {
+      i = e % na; j = e / na;
+      const int src = (i < a_lo ? i : ts + (i - a_lo)) + ldp * j;
+      const double* q = partials + src;
+      const size_t bstride = (size_t)ldp * ts;
+      int b = s;
+      for (; b + 7 * nsl < nblk; b += 8 * nsl) {       // eight loads in flight, added in order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(b + u * nsl) * bstride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+      }
+      for (; b < nblk; b += nsl) sum += q[(size_t)b * bstride];
+    }
+    red[tid] = sum;
+    __syncthreads();
+    if (s == 0 && e < ne) {
+      double tot = 0.0;
+      for (int q2 = 0; q2 < nsl; ++q2) tot += red[q2 * ner + e0];
+      out[i + ld_out * j] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+// [W ; G^T] ((t+T) x t, ld t+T) -> mu = chol(W) (t x t, ld t), alpha = U^-T G (t x T, ld t);
+// called by a whole workgroup, W / G = 256 doubles of LDS each.  (ecg.c:431 + :438 with the
+// Gram of the un-normalised P: (P U^-1)^T R = U^-T (P^T R).)
+__device__ __forceinline__ void potrf_alpha_wg(const double* buf, int t, int T, double* mu,
+                                               double* alpha, int* info, double* W, double* G) {
+  const int ld = t + T, nt = blockDim.x;
+  for (int e = threadIdx.x; e < t * t; e += nt) W[e] = buf[(e % t) + ld * (e / t)];
+  for (int e = threadIdx.x; e < t * T; e += nt) { const int i = e % t, c = e / t; G[e] = buf[(t + c) + ld * i]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int fail = 0;
+    for (int j = 0; j < t; ++j) {
+      double d = W[j + t * j];
+      for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
+      if (!(d > 0.0)) { W[j + t * j] = d; fail = j + 1; break; }
+      d = sqrt(d);
+      W[j + t * j] = d;
+      for (int i = j + 1; i < t; ++i) {
+        double s = W[j + t * i];
+        for (int k = 0; k < j; ++k) s -= W[k + t * j] * W[k + t * i];
+        W[j + t * i] = s / d;
+      }
+    }
+    *info = fail;
+  }
+  __syncthreads();
+  if (threadIdx.x < T) {            // one column of alpha per lane: forward substitution with U^T
+    const int c = threadIdx.x;
+    for (int i = 0; i < t; ++i) {
+      double s = G[i + t * c];
+      for (int k = 0; k < i; ++k) s -= W[k + t * i] * G[k + t * c];
+      G[i + t * c] = s / W[i + t * i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < t * t; e += nt) mu[e] = W[e];
+  for (int e = threadIdx.x; e < t * T; e += nt) alpha[e] = G[e];
+}
+
+// Residual norm from the per-workgroup column sums: fixed-order tree over WG threads.
+// res2[1] carries the Cholesky status so the host fetches both with one copy; `host`
+// (pinned, device-visible) receives the same two values when given.
+__device__ __forceinline__ void trace_finish_wg(const double* rtr, int nblk, int ts, int nc,
+                                                double* res2, const int* info, double* host,
+                                                double* red) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += WG)
+    for (int c = 0; c < nc; ++c) s += rtr[(size_t)b * ts + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = WG / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double r2 = red[0], st = info ? (double)info[0] : 0.0;
+    res2[0] = r2; res2[1] = st;
+    if (host) { host[0] = r2; host[1] = st; __threadfence_system(); }
+  }
+}
+
 // ---------------------------------------------------------------- Gram ----
 // C = [A0 | A1]^T B over the local rows.  Each lane owns a TI x TI tile of C
 // for a strided set of rows; NPAN*(TS/TI)^2 lanes cover one row.  Lanes are
@@ -312,38 +421,25 @@ __global__ __launch_bounds__(WG) void k_gram(int m, const double* __restrict__ A
   }
 }
 
-// Sum the per-workgroup partial blocks (fixed order) and scatter the active
-// sub-block into the reference's t x t layout.
 __global__ __launch_bounds__(1024) void k_finish(const double* __restrict__ partials, int nblk,
                                                int npan, int ts, int a_lo, int a_hi, int nb,
                                                double* __restrict__ out, int ld_out) {
   __shared__ double red[1024];
-  const int ldp = npan * ts;
-  const int na = a_lo + a_hi;
-  const int ne = na * nb;
-  int ner = 1;
-  while (ner < ne && ner < 1024) ner <<= 1;
-  const int nsl = 1024 / ner;
-  const int tid = threadIdx.x;
-  const int e0 = tid % ner, s = tid / ner;
-  for (int base = 0; base < ne; base += ner) {
-    const int e = base + e0;
-    double sum = 0.0;
-    int i = 0, j = 0;
-    if (e < ne) {
-      i = e % na; j = e / na;
-      const int src = (i < a_lo ? i : ts + (i - a_lo)) + ldp * j;
-      for (int b = s; b < nblk; b += nsl) sum += partials[(size_t)b * (ldp * ts) + src];
-    }
-    red[tid] = sum;
-    __syncthreads();
-    if (s == 0 && e < ne) {
-      double tot = 0.0;
-      for (int q = 0; q < nsl; ++q) tot += red[q * ner + e0];
-      out[i + ld_out * j] = tot;
-    }
-    __syncthreads();
-  }
+  finish_sum<1024>(partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out, red);
+}
+
+// k_finish followed by k_potrf_alpha on its output, one launch (single-process runs, where no
+// all-reduce sits between the two).
+__global__ __launch_bounds__(1024) void k_finish_potrf_alpha(const double* __restrict__ partials,
+                                                           int nblk, int npan, int ts, int t, int T,
+                                                           double* out, double* __restrict__ mu,
+                                                           double* __restrict__ alpha,
+                                                           int* __restrict__ info) {
+  __shared__ double red[1024];
+  finish_sum<1024>(partials, nblk, npan, ts, t, T, t, out, t + T, red);
+  __threadfence_block();
+  __syncthreads();
+  potrf_alpha_wg(out, t, T, mu, alpha, info, red, red + 256);
 }
 
 // t x t upper Cholesky, one lane (t <= 16).  LAPACK dpotf2 'U': on failure
@@ -520,45 +616,11 @@ __global__ __launch_bounds__(WG) void k_update_xr(int m, int t, int nc,
   block_sum_cols<TS>(rr, rtr + (size_t)blockIdx.x * TS);
 }
 
-// [W ; G^T] ((t+T) x t, ld t+T) -> mu = chol(W) (t x t, ld t), alpha = U^-T G (t x T, ld t).
-// One wave, everything in LDS.  (ecg.c:431 + :438 with the Gram of the
-// un-normalised P: (P U^-1)^T R = U^-T (P^T R).)
 __global__ void k_potrf_alpha(const double* __restrict__ buf, int t, int T, double* __restrict__ mu,
                               double* __restrict__ alpha, int* __restrict__ info) {
   __shared__ double W[16 * 16];
   __shared__ double G[16 * 16];
-  const int ld = t + T;
-  for (int e = threadIdx.x; e < t * t; e += 64) W[e] = buf[(e % t) + ld * (e / t)];
-  for (int e = threadIdx.x; e < t * T; e += 64) { const int i = e % t, c = e / t; G[e] = buf[(t + c) + ld * i]; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int fail = 0;
-    for (int j = 0; j < t; ++j) {
-      double d = W[j + t * j];
-      for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
-      if (!(d > 0.0)) { W[j + t * j] = d; fail = j + 1; break; }
-      d = sqrt(d);
-      W[j + t * j] = d;
-      for (int i = j + 1; i < t; ++i) {
-        double s = W[j + t * i];
-        for (int k = 0; k < j; ++k) s -= W[k + t * j] * W[k + t * i];
-        W[j + t * i] = s / d;
-      }
-    }
-    *info = fail;
-  }
-  __syncthreads();
-  if (threadIdx.x < T) {            // one column of alpha per lane: forward substitution with U^T
-    const int c = threadIdx.x;
-    for (int i = 0; i < t; ++i) {
-      double s = G[i + t * c];
-      for (int k = 0; k < i; ++k) s -= W[k + t * i] * G[k + t * c];
-      G[i + t * c] = s / W[i + t * i];
-    }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < t * t; e += 64) mu[e] = W[e];
-  for (int e = threadIdx.x; e < t * T; e += 64) alpha[e] = G[e];
+  potrf_alpha_wg(buf, t, T, mu, alpha, info, W, G);
 }
 
 // P <- P U^-1, AP <- AP U^-1, X += P alpha, R -= AP alpha and the column sums of
@@ -640,19 +702,9 @@ __global__ __launch_bounds__(WG) void k_colnorm2(int m, const double* __restrict
 
 __global__ __launch_bounds__(WG) void k_trace_finish(const double* __restrict__ rtr, int nblk,
                                                      int ts, int nc, double* __restrict__ res2,
-                                                     const int* __restrict__ info) {
+                                                     const int* __restrict__ info, double* host) {
   __shared__ double red[WG];
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += WG)
-    for (int c = 0; c < nc; ++c) s += rtr[(size_t)b * ts + c];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = WG / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
-  // res2[1] carries the Cholesky status so the host fetches both with one copy
-  if (threadIdx.x == 0) { res2[0] = red[0]; res2[1] = info ? (double)info[0] : 0.0; }
+  trace_finish_wg(rtr, nblk, ts, nc, res2, info, host, red);
 }
 
 // Z(:, :nc) -= [V0(:, :a_lo) | V1(:, :a_hi)] beta
@@ -1250,6 +1302,24 @@ int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B
   return kfail("k_gram");
 }
 
+int pa_k_gram_finish(int m, int ts, const double* A0, const double* A1, const double* B,
+                     double* partials, int a_lo, int a_hi, int nb, double* out, int ld_out, int t,
+                     int T, double* mu, double* alpha, int* info) {
+  int nblk = 0;
+  if ((a_lo + a_hi) * nb <= 0) return 0;
+  if (pa_k_gram(m, ts, A0, A1, B, partials, &nblk)) return 1;
+  if (t > 0) {
+    if (a_lo != t || a_hi != T || nb != t || ld_out != t + T || !A1) {
+      snprintf(g_kerr, sizeof(g_kerr), "pa_k_gram_finish: [W ; G^T] layout expected");
+      return 1;
+    }
+    hipLaunchKernelGGL(k_finish_potrf_alpha, dim3(1), dim3(1024), 0, cur_stream(), partials, nblk, 2, ts,
+                       t, T, out, mu, alpha, info);
+    return kfail("k_finish_potrf_alpha");
+  }
+  return pa_k_finish(partials, nblk, A1 ? 2 : 1, ts, a_lo, a_hi, nb, out, ld_out);
+}
+
 int pa_k_finish(const double* partials, int nblk, int npan, int ts, int a_lo, int a_hi, int nb,
                 double* out, int ld_out) {
   if ((a_lo + a_hi) * nb <= 0) return 0;
@@ -1278,13 +1348,18 @@ int pa_k_trsm(int m, int ts, int t, const double* U, double* P, double* AP) {
 }
 
 int pa_k_update_xr(int m, int ts, int t, int nc, const double* alpha, const double* P,
-                   const double* AP, double* X, double* R, double* rtr_partials, int* nblk) {
+                   const double* AP, double* X, double* R, double* rtr_partials, int* nblk,
+                   int trace_nc, double* res2, const int* info, double* host) {
   int blocks = grid_rows(m, 2);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
   TS_DISPATCH(ts, hipLaunchKernelGGL((k_update_xr<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                      t, nc, alpha, P, AP, X, R, rtr_partials));
-  return kfail("k_update_xr");
+  if (kfail("k_update_xr")) return 1;
+  if (trace_nc <= 0) return 0;
+  hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, blocks, ts, trace_nc,
+                     res2, info, host);
+  return kfail("k_trace_finish");
 }
 
 int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha, int* info) {
@@ -1293,13 +1368,18 @@ int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha,
 }
 
 int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double* alpha, double* P,
-                     double* AP, double* X, double* R, double* rtr_partials, int* nblk) {
+                     double* AP, double* X, double* R, double* rtr_partials, int* nblk, int trace_nc,
+                     double* res2, const int* info, double* host) {
   int blocks = grid_rows(m, 2);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
   TS_DISPATCH(ts, hipLaunchKernelGGL((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                      t, nc, U, alpha, P, AP, X, R, rtr_partials));
-  return kfail("k_trsm_update");
+  if (kfail("k_trsm_update")) return 1;
+  if (trace_nc <= 0) return 0;
+  hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, blocks, ts, trace_nc,
+                     res2, info, host);
+  return kfail("k_trace_finish");
 }
 
 int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk) {
@@ -1314,7 +1394,7 @@ int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nbl
 int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2,
                       const int* info) {
   hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, nblk, ts, nc,
-                     res2, info);
+                     res2, info, (double*)nullptr);
   return kfail("k_trace_finish");
 }
 

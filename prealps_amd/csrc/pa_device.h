@@ -95,6 +95,11 @@ int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendb
  * workgroups through nblk.  A1 may be NULL (npan = 1). */
 int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B,
               double* partials, int* nblk);
+/* pa_k_gram + pa_k_finish.  With t > 0 (out = [W ; G^T], a_lo = nb = t, a_hi = T,
+ * ld_out = t + T) the finishing launch goes on like pa_k_potrf_alpha on `out`. */
+int pa_k_gram_finish(int m, int ts, const double* A0, const double* A1, const double* B,
+                     double* partials, int a_lo, int a_hi, int nb, double* out, int ld_out, int t,
+                     int T, double* mu, double* alpha, int* info);
 int pa_gram_max_blocks(void);
 /* out[i + ld_out*j] = sum over blocks, for rows i < a_lo (panel 0) and
  * a_lo <= i < a_lo + a_hi (panel 1, column i - a_lo), j < nb. */
@@ -114,13 +119,17 @@ int pa_k_trsm(int m, int ts, int t, const double* U, double* P, double* AP);
  * leading dimension t; also the per-workgroup sums of R(:,c)^2 for the
  * stopping test (ecg.c:250) into rtr_partials[blk*ts + c]. */
 int pa_k_update_xr(int m, int ts, int t, int nc, const double* alpha, const double* P,
-                   const double* AP, double* X, double* R, double* rtr_partials, int* nblk);
+                   const double* AP, double* X, double* R, double* rtr_partials, int* nblk,
+                   int trace_nc, double* res2, const int* info, double* host);
+/* trace_nc > 0: followed by pa_k_trace_finish over trace_nc columns into res2 and, when
+ * `host` (pinned, device-visible) is given, into host[0..1] as well (no copy needed). */
 /* buf = [W ; G^T] ((t+T) x t, leading dimension t+T) with W = AP^T P and G = P^T R of the
  * un-normalised P  ->  mu = chol(W) (upper, t x t), alpha = U^-T G (t x T, ld t). */
 int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha, int* info);
 /* pa_k_trsm followed by pa_k_update_xr in one pass over P, AP, X, R. */
 int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double* alpha, double* P,
-                     double* AP, double* X, double* R, double* rtr_partials, int* nblk);
+                     double* AP, double* X, double* R, double* rtr_partials, int* nblk, int trace_nc,
+                     double* res2, const int* info, double* host);
 /* Standalone sums of R(:,c)^2 (same layout as above). */
 int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk);
 /* res2[0] = sum over blocks and columns c < nc; res2[1] = *info (0 if info is NULL). */
