@@ -161,6 +161,9 @@ def main():
     check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
     bj_s = sec.value / a.spmm_reps
     bj_bytes = prob.stat("bj_factor_bytes") + 16.0 * m_loc * a.t + 8.0 * m_loc
+    # streaming ceilings of this very device (calibration kernels of the library, 1 GiB buffers)
+    copy_gbs, read_gbs = C.c_double(), C.c_double()
+    check(L.preAlps_hip_hbm_probe(1 << 30, 20, C.byref(copy_gbs), C.byref(read_gbs)), "hbm_probe")
     # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/): the
     # counters cannot be read from inside the process, so the committed summary is quoted when
     # the workload is the one it was collected on.
@@ -187,6 +190,8 @@ def main():
                      "unit": "GB/s", "frac": spmm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s,
                      "back_to_back_launch_us": 1e6 * spmm_b2b_s,
+                     "measured_copy_ceiling_GBs": copy_gbs.value, "measured_read_ceiling_GBs": read_gbs.value,
+                     "frac_of_measured_read_ceiling": spmm_gbs / read_gbs.value,
                      "note": "each timed launch follows one preconditioner apply (cache state of the solver loop)"},
         "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "factor_bytes": prob.stat("bj_factor_bytes"),
                          "achieved_GBs": bj_bytes / bj_s / 1e9},

@@ -112,6 +112,9 @@ int preAlps_hip_get_stat(const char* key, double* value);
  * between them (what bench.py uses to time a batch of launches). */
 int preAlps_hip_timer_start(void);
 int preAlps_hip_timer_stop(double* seconds);
+/* Streaming ceilings of the device from two calibration kernels (plain copy, plain read) over
+ * `bytes` of freshly allocated HBM, `reps` launches each, timed with the stopwatch above. */
+int preAlps_hip_hbm_probe(size_t bytes, int reps, double* copy_GBs, double* read_GBs);
 /* Per-phase device time in seconds accumulated since the last reset, from
  * hipEvents on the library stream when timing is enabled (it adds a stream
  * sync per call, so it is off by default).  Keys: "operator", "precond",

@@ -41,6 +41,15 @@ typedef struct {
   double factor_bytes; int max_bw;
 } pa_bj_t;
 
+/* window of a wide block = record length (kernels.hip: bjw_window) */
+static int bj_wide_window(int w) {
+  int W = (w + 64 + 63) & ~63;
+  if (W <= 1024) return W;
+  W = (w + 64 + 127) & ~127;
+  if (W <= 2048) return W;
+  return (w + 64 + 255) & ~255;
+}
+
 static pa_bj_t g_bj;
 
 double pa_bj_factor_bytes(void) { return g_bj.created ? g_bj.factor_bytes : 0.0; }
@@ -218,17 +227,17 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   int maxw = 0;
   /* narrow bands (one wavefront per block): one record of wr doubles per step,
    * [1/L(j,j) | row id | 0 | L(j+1..j+w, j) | 0], wr even.  Wide bands (one workgroup per
-   * block): records of W = roundup(w + 64, 256) doubles in window-slot order, the value for
-   * target row i at column i mod W. */
+   * block): records of W = bj_wide_window(w) >= w + 64 doubles in window-slot order, the value
+   * for target row i at column i mod W. */
   int maxR = pa_bj_max_R();
   for (int q = 0; q < np; ++q) {
     int wide = (bw[q] + 127) / 64 > maxR;
-    long long reclen = wide ? ((bw[q] + 64 + 255) & ~255) : ((bw[q] + 5) & ~1);
+    long long reclen = wide ? bj_wide_window(bw[q]) : ((bw[q] + 5) & ~1);
     off[q + 1] = off[q] + (long long)nrows[q] * reclen;
     if (bw[q] > maxw) maxw = bw[q];
   }
   s->max_bw = maxw;
-  if (!rc && ((maxw + 64 + 255) & ~255) > 4096)
+  if (!rc && bj_wide_window(maxw) > 4096)
     rc = PA_FAIL("block-Jacobi: a diagonal block has bandwidth %d after reordering; the workgroup-resident "
                  "solve supports up to 4032 -- use more (smaller) subdomains", maxw);
   size_t tot = (size_t)off[np];
@@ -248,7 +257,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       double* f = Lf + off[q];
       double* g = Lb + off[q];
       if ((w + 127) / 64 > maxR) { /* wide: window-slot order, pre-divided by the pivot */
-        size_t W = (size_t)((w + 64 + 255) & ~255);
+        size_t W = (size_t)bj_wide_window(w);
         for (int j = 0; j < b; ++j) {
           int jr = b - 1 - j;
           invd_f[r0 + j] = 1.0 / band[(size_t)j * ld];
@@ -283,7 +292,10 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     s->nclass = 0;
     for (int q = 0; q < np; ++q) {
       int R = (bw[q] + 127) / 64, c;
-      if (R > maxR) R = 0; /* wide class */
+      if (R > maxR) { /* wide classes: -(register sets per lane) */
+        int W = bj_wide_window(bw[q]);
+        R = W <= 1024 ? -1 : (W <= 2048 ? -2 : -4);
+      }
       for (c = 0; c < s->nclass; ++c) if (s->class_R[c] == R) break;
       if (c == s->nclass) { s->class_R[c] = R; s->class_count[c] = 0; s->class_wmax[c] = 0; s->nclass++; }
       cls[q] = c; s->class_count[c]++;

@@ -228,6 +228,30 @@ int preAlps_hip_timer_stop(double* seconds) {
   return 0;
 }
 
+/* Streaming ceilings of this device, measured with the plainest kernels on `bytes` of HBM
+ * (take it well above the 256 MiB Infinity Cache): copy counts bytes read + written. */
+int preAlps_hip_hbm_probe(size_t bytes, int reps, double* copy_GBs, double* read_GBs) {
+  PA_REQUIRE_GPU();
+  if (bytes < (1u << 20) || reps < 1) return PA_FAIL("probe needs at least 1 MiB and one repetition");
+  bytes &= ~(size_t)4095;
+  double* a = (double*)pa_rt_malloc(bytes);
+  double* b = (double*)pa_rt_malloc(bytes);
+  int rc = !a || !b || pa_rt_memset(a, 0, bytes) || pa_rt_memset(b, 0, bytes);
+  double sec = 0.0;
+  for (int which = 0; which < 2 && !rc; ++which) {
+    rc = pa_k_probe(which, bytes, a, b) || preAlps_hip_timer_start();   /* one warm-up launch */
+    for (int r = 0; r < reps && !rc; ++r) rc = pa_k_probe(which, bytes, a, b);
+    rc = rc || preAlps_hip_timer_stop(&sec);
+    if (!rc) {
+      double gbs = (which == 0 ? 2.0 : 1.0) * (double)bytes * reps / sec / 1e9;
+      if (which == 0) { if (copy_GBs) *copy_GBs = gbs; } else if (read_GBs) *read_GBs = gbs;
+    }
+  }
+  pa_rt_free(a); pa_rt_free(b);
+  if (rc) return PA_FAIL("HBM probe failed: %s", pa_rt_error());
+  return 0;
+}
+
 int preAlps_hip_get_time(const char* key, double* seconds) {
   for (int i = 0; i < PA_T_COUNT; ++i)
     if (strcmp(key, k_time_keys[i]) == 0) { *seconds = g_times[i]; return 0; }

@@ -247,6 +247,23 @@ __global__ __launch_bounds__(WG) void k_pack_rows(int n, const int* __restrict__
   if (i < n) out[(size_t)i * TS + c] = X[(size_t)idx[i] * TS + c];
 }
 
+// ------------------------------------------------ HBM calibration ----
+// What this device sustains on the plainest streaming kernels, measured in the same process
+// as the solver kernels (bench.py quotes the SpMM against the 8 TB/s spec and against this).
+__global__ __launch_bounds__(WG) void k_probe_copy(size_t n2, const double2* __restrict__ src,
+                                                   double2* __restrict__ dst) {
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += stride) dst[i] = src[i];
+}
+__global__ __launch_bounds__(WG) void k_probe_read(size_t n2, const double2* __restrict__ src,
+                                                   double* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * WG;
+  double s = 0.0;
+#pragma unroll 4
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += stride) { const double2 v = src[i]; s += v.x + v.y; }
+  if (s == 12345.678) out[0] = s;   // keeps the loads alive, never true for the zero-filled buffer
+}
+
 // ------------------------------------------------ small finishing steps ----
 // Measured and rejected: letting the last workgroup of the producing kernel (ticket counter)
 // do these sums.  The device-scope release every workgroup needs before taking its ticket
@@ -1006,131 +1023,230 @@ __global__ void k_bj_apply(
 // its rows.  Records are stored in window-slot order -- the value for target row i sits at
 // column i mod W -- so a lane reads the same column of every record: no index arithmetic,
 // coalesced, and prefetched D steps ahead in registers.
+// Window (rows in flight = record length) of a wide block and the register sets per lane it
+// needs: the same rule as block_jacobi.c (bj_wide_window).
+__host__ __device__ inline int bjw_window(int w) {
+  int W = (w + 64 + 63) & ~63;
+  if (W <= 1024) return W;
+  W = (w + 64 + 127) & ~127;
+  if (W <= 2048) return W;
+  return (w + 64 + 255) & ~255;
+}
+
+// The sweep is blocked by 64 pivots.  Phase A: the wave that holds the block's rows
+// eliminates them among themselves (in-wave, v_readlane; its 64 x 64 coefficients were
+// brought into LDS by LDS-DMA during the previous block) and publishes the 64 solved rows in
+// LDS.  Barrier.  Phase B: every wave applies the 64 pivots to its other rows, reading them
+// back as LDS broadcasts; the band values come through a register ring that keeps D steps
+// (D*R loads per lane, 16-32 KiB per wave) in flight across block boundaries.  Barrier.
+// Two barriers per 64 steps instead of one per step; every record entry is read once.
+// Always 64 steps: in a short last block the missing pivots are zero rows and their (clamped)
+// coefficients multiply zeros, so no step is conditional.  The coefficients arrive in LDS by
+// LDS-DMA; they are read with explicit ds_read_b64 + s_waitcnt (8 steps per batch) because a
+// compiler-visible LDS read of a DMA target makes the compiler drain every outstanding VMEM
+// load of the wave (the whole prefetch ring) first.  `la` = LDS byte address of dl[lane].
+template <int TS, int R, int K>
+__device__ __forceinline__ void bjb_diag(double (&acc)[R][TS], unsigned la) {
+  constexpr int DA = 8;
+#pragma unroll
+  for (int l0 = 0; l0 < 64; l0 += DA) {
+    double q[DA];
+#pragma unroll
+    for (int u = 0; u < DA; ++u)
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[u]) : "v"(la), "n"((l0 + u) * 512));
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]));
+#pragma unroll
+    for (int u = 0; u < DA; ++u) {
+      const int l = l0 + u;
+#pragma unroll
+      for (int c = 0; c < TS; ++c) {
+        const double y = readlane_f64(acc[K][c], l);
+        acc[K][c] = fma(-q[u], y, acc[K][c]);
+      }
+    }
+  }
+  asm volatile("" ::: "memory");   // the next LDS-DMA into this buffer stays behind these reads
+}
+
+// 64 records x 64 slots of the diagonal block starting at record `rec0` -> LDS, 1 KiB (two
+// records) per instruction; records past the end of the block are clamped (never used).
+__device__ __forceinline__ void bjb_issue_diag(const double* __restrict__ rec, int W, int jb, int b,
+                                               double* dl, int lane) {
+  const int sb = jb % W;
+  const int half = lane >> 5, l16 = lane & 31;
+  for (int i = 0; i < 32; ++i) {
+    int r = jb + 2 * i + half;
+    r = r < b ? r : b - 1;
+    const char* g = reinterpret_cast<const char*>(rec + (size_t)r * W + sb) + l16 * 16;
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(reinterpret_cast<char*>(dl) + i * 1024), 16, 0, 0);
+  }
+}
+
+// Phase B of one block; q is the ring (step jb + l sits in q[l % D]), refilled D steps ahead
+// (into the next block's records, clamped at the end of the subdomain).  recb = first record
+// of the block (wave-uniform, so the loads take a scalar base + the lane's slot offset);
+// kskip = the owner's register set, whose slots of these records belong to phase A (-1: none).
+template <int TS, int R, int D>
+__device__ __forceinline__ void bjb_update(double (&acc)[R][TS], double (&q)[D][R],
+                                           const double* __restrict__ recb, int s0, int W, int nleft,
+                                           const double (*yb)[TS], int kskip) {
+  // the pivots are read P steps ahead of their use (LDS broadcasts, ~100 cycles each)
+  constexpr int P = TS * R <= 8 ? 2 : 1;
+  double2 yq[P][TS / 2];
+#pragma unroll
+  for (int a = 0; a < P; ++a)
+#pragma unroll
+    for (int c = 0; c < TS / 2; ++c) yq[a][c] = reinterpret_cast<const double2*>(yb[a])[c];
+#pragma unroll
+  for (int l = 0; l < 64; ++l) {
+    const int u = l % D;
+    double y[TS];
+#pragma unroll
+    for (int c = 0; c < TS / 2; ++c) { y[2 * c] = yq[l % P][c].x; y[2 * c + 1] = yq[l % P][c].y; }
+    if (l + P < 64) {
+#pragma unroll
+      for (int c = 0; c < TS / 2; ++c) yq[l % P][c] = reinterpret_cast<const double2*>(yb[l + P])[c];
+    }
+    const int ln = (l + D) < nleft ? (l + D) : nleft - 1;
+    const double* __restrict__ pr = recb + (size_t)ln * W;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const double lv = (k == kskip) ? 0.0 : q[u][k];
+      q[u][k] = pr[s0 + k * 64];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[k][c] = fma(-lv, y[c], acc[k][c]);
+    }
+    // keep the issue order of the source: the scheduler otherwise sinks the LDS reads back
+    // next to their uses to save registers and every step eats the full LDS latency
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// phase A + hand-over of the owner wave for register set K.  The id of the row that takes
+// over the slot was fetched one ownership earlier (rownext), so its load does not hang on a
+// fresh index load behind the whole prefetch ring.
+template <int TS, int R, int K>
+__device__ __forceinline__ void bjb_own(double (&acc)[R][TS], int (&rowid)[R], int (&rownext)[R],
+                                        const double* dl, int W, int lim, int jb, int b,
+                                        const double* __restrict__ invd, const int* __restrict__ iomap,
+                                        size_t rowbase, const double* __restrict__ src,
+                                        double* __restrict__ dst, double (*yb)[TS], int lane) {
+  double nxt[TS];
+  double idl = 0.0;
+  const int nrow = rownext[K];
+  const int jn = jb + W + lane;
+  if (jb + lane < b) idl = invd[jb + lane];
+  if (jn < b) load_row<TS>(src, rowbase + nrow, nxt);
+  else
+#pragma unroll
+    for (int c = 0; c < TS; ++c) nxt[c] = 0.0;
+  int rn = (jn + W < b) ? iomap[jn + W] : 0;
+  bjb_diag<TS, R, K>(acc, (unsigned)(uintptr_t)(lds_void_ptr)(dl + lane));
+  // lane l now holds the solved (unscaled) row jb + l: publish, scale, store, take the next row
+  double2* yq = reinterpret_cast<double2*>(yb[lane]);
+#pragma unroll
+  for (int c = 0; c < TS / 2; ++c) yq[c] = make_double2(acc[K][2 * c], acc[K][2 * c + 1]);
+  double v[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) v[c] = acc[K][c] * idl;
+  if (lane < lim) store_row<TS>(dst, rowbase + rowid[K], v);
+  // the incoming row and the id prefetched for the next ownership are touched here, where
+  // their loads have long landed: otherwise the compiler sinks the copy into the loop latch
+  // (draining every wave's prefetch ring there) and waits for the id at the start of the next
+  // ownership, behind the whole ring
+#pragma unroll
+  for (int c = 0; c < TS; ++c) { asm volatile("" : "+v"(nxt[c])); acc[K][c] = nxt[c]; }
+  rowid[K] = nrow;
+  asm volatile("" : "+v"(rn));
+  rownext[K] = rn;
+}
+
 template <int TS, int R, int D>
 __device__ __forceinline__ void bjw_sweep(int b, int W, const double* __restrict__ rec,
                                           const double* __restrict__ invd,
                                           const int* __restrict__ iomap, size_t rowbase,
                                           const double* __restrict__ src, double* __restrict__ dst,
-                                          double (*ybuf)[TS], int wave, int lane, bool active) {
-  // idle waves of a narrower block alias wave 0's columns: they compute, never store
+                                          double (*ybuf)[64][TS], double (*dlbuf)[64 * 64], int wave,
+                                          int lane, bool active) {
   const int s0 = (active ? wave : 0) * 64 * R + lane;   // slot of register set 0 of this lane
   double acc[R][TS];
-  int rowid[R];
+  int rowid[R], rownext[R];
+  // diagonal coefficients of the first two blocks; later ones are fetched two blocks ahead by
+  // the owner that has just finished with the buffer
+  if (wave == 0) {
+    bjb_issue_diag(rec, W, 0, b, dlbuf[0], lane);
+    if (64 < b) bjb_issue_diag(rec, W, 64, b, dlbuf[1], lane);
+  }
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     const int j = s0 + k * 64;
     rowid[k] = 0;
+    rownext[k] = (active && j + W < b) ? iomap[j + W] : 0;
     if (active && j < b) { rowid[k] = iomap[j]; load_row<TS>(src, rowbase + rowid[k], acc[k]); }
     else
 #pragma unroll
       for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
   }
-  const double* __restrict__ col = rec + s0;    // lane's column of every record
+  double q[D][R];
+#pragma unroll
+  for (int u = 0; u < D; ++u)
+#pragma unroll
+    for (int k = 0; k < R; ++k) q[u][k] = rec[(size_t)(u < b ? u : b - 1) * W + s0 + k * 64];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   for (int jb = 0; jb < b; jb += 64) {
     const int sb = jb % W;
     const int ow = sb / (64 * R), ok = (sb >> 6) % R;   // wave / register set that owns this block
     const bool mine = active && wave == ow;
     const int lim = (b - jb) < 64 ? (b - jb) : 64;
-    double nxt[TS];
-    double idl = 0.0;
-    int nrow = 0;
+    const int par = (jb >> 6) & 1;
+    double (*yb)[TS] = ybuf[par];
     if (mine) {
-      const int jn = jb + W + lane;
-      if (jb + lane < b) idl = invd[jb + lane];
-      if (jn < b) { nrow = iomap[jn]; load_row<TS>(src, rowbase + nrow, nxt); }
-      else
-#pragma unroll
-        for (int c = 0; c < TS; ++c) nxt[c] = 0.0;
-    }
-    // register ring of the next D steps' band values; loads are unconditional (past the
-    // end of the block they re-read its last record) so the compiler emits no branches
-    const double* __restrict__ cp = col + (size_t)jb * W;
-    double q[D][R];
-#pragma unroll
-    for (int u = 0; u < D; ++u) {
-      const int lu = u < lim ? u : lim - 1;
-#pragma unroll
-      for (int k = 0; k < R; ++k) q[u][k] = cp[(size_t)lu * W + k * 64];
-    }
-    for (int l0 = 0; l0 < lim; l0 += D) {
-#pragma unroll
-      for (int u = 0; u < D; ++u) {
-        const int l = l0 + u;
-        if (l < lim) {
-          const int j = jb + l;
-          if (mine) {
-            double piv[TS];
-#pragma unroll
-            for (int c = 0; c < TS; ++c) {
-              double v = acc[0][c];
-#pragma unroll
-              for (int k = 1; k < R; ++k) v = (ok == k) ? acc[k][c] : v;
-              piv[c] = readlane_f64(v, l);
-            }
-            if (lane == 0)
-#pragma unroll
-              for (int c = 0; c < TS; ++c) ybuf[j & 1][c] = piv[c];
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          double y[TS];
-#pragma unroll
-          for (int c = 0; c < TS; ++c) y[c] = ybuf[j & 1][c];
-          const int ln = (l + D) < lim ? (l + D) : lim - 1;
-#pragma unroll
-          for (int k = 0; k < R; ++k) {
-            const double lv = q[u][k];
-#pragma unroll
-            for (int c = 0; c < TS; ++c) acc[k][c] = fma(-lv, y[c], acc[k][c]);
-            q[u][k] = cp[(size_t)ln * W + k * 64];
-          }
-        }
+      double* dl = dlbuf[par];
+      if (ok == 0) bjb_own<TS, R, 0>(acc, rowid, rownext, dl, W, lim, jb, b, invd, iomap, rowbase, src, dst, yb, lane);
+      if constexpr (R > 1) if (ok == 1) bjb_own<TS, R, 1>(acc, rowid, rownext, dl, W, lim, jb, b, invd, iomap, rowbase, src, dst, yb, lane);
+      if constexpr (R > 2) {
+        if (ok == 2) bjb_own<TS, R, 2>(acc, rowid, rownext, dl, W, lim, jb, b, invd, iomap, rowbase, src, dst, yb, lane);
+        if (ok == 3) bjb_own<TS, R, 3>(acc, rowid, rownext, dl, W, lim, jb, b, invd, iomap, rowbase, src, dst, yb, lane);
       }
     }
-    if (mine) {
-      double v[TS];
-#pragma unroll
-      for (int c = 0; c < TS; ++c) {
-        double a = acc[0][c];
-#pragma unroll
-        for (int k = 1; k < R; ++k) a = (ok == k) ? acc[k][c] : a;
-        v[c] = a * idl;
-      }
-      int rid = rowid[0];
-#pragma unroll
-      for (int k = 1; k < R; ++k) rid = (ok == k) ? rowid[k] : rid;
-      if (lane < lim) store_row<TS>(dst, rowbase + rid, v);
-#pragma unroll
-      for (int k = 0; k < R; ++k)
-        if (ok == k) {
-#pragma unroll
-          for (int c = 0; c < TS; ++c) acc[k][c] = nxt[c];
-          rowid[k] = nrow;
-        }
-    }
+    // everything this wave has in flight lands before the barrier (the compiler drains all
+    // counters in front of an s_barrier on gfx9 anyway): the published pivots, and the owner's
+    // coefficient fetch of the previous block
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the owner's coefficient buffer is free again: fetch the block after next into it.  The
+    // fetch is complete at the next barrier, one block before it is read.
+    if (mine && jb + 128 < b) bjb_issue_diag(rec, W, jb + 128, b, dlbuf[par], lane);
+    if (active) bjb_update<TS, R, D>(acc, q, rec + (size_t)jb * W, s0, W, b - jb, yb, mine ? ok : -1);
   }
 }
 
-template <int TS, int R>
-__global__ __launch_bounds__(1024) void k_bj_wide(
+// NT = threads the launch may use: with at most 12 wavefronts (3 per SIMD) a lane has 168
+// VGPRs and the ring can hold twice as many steps.
+template <int TS, int R, int NT>
+__global__ __launch_bounds__(NT) void k_bj_wide(
     const int* __restrict__ list, int count, const int* __restrict__ row0,
     const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off,
     const int* __restrict__ map_f, const int* __restrict__ map_b, const double* __restrict__ Lf,
     const double* __restrict__ Lb, const double* __restrict__ invd_f,
     const double* __restrict__ invd_b, const double* __restrict__ in, double* __restrict__ out) {
-  __shared__ double ybuf[2][TS];
+  __shared__ double ybuf[2][64][TS];
+  __shared__ double dl[2][64 * 64];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int p = __builtin_amdgcn_readfirstlane(list[blockIdx.x]);
   const int r0 = __builtin_amdgcn_readfirstlane(row0[p]);
   const int b = __builtin_amdgcn_readfirstlane(nrows[p]);
   const int w = __builtin_amdgcn_readfirstlane(bw[p]);
-  const int W = (w + 64 + 255) & ~255;
+  const int W = bjw_window(w);
   const bool active = wave < W / (64 * R);
   const size_t o = (size_t)off[p];
-  bjw_sweep<TS, R, (R * TS >= 16 ? 4 : 8)>(b, W, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in, out, ybuf, wave, lane, active);
+  constexpr int D = (TS == 16 ? 8 : 16) * (NT <= 768 ? 2 : 1) / R;
+  bjw_sweep<TS, R, D>(b, W, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in, out, ybuf, dl, wave, lane, active);
   __threadfence_block();
   __syncthreads();
-  bjw_sweep<TS, R, (R * TS >= 16 ? 4 : 8)>(b, W, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, ybuf, wave, lane, active);
+  bjw_sweep<TS, R, D>(b, W, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, ybuf, dl, wave, lane, active);
 }
 
 inline int grid_rows(int m, int per_thread_rows = 1) {
@@ -1245,22 +1361,42 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
   return bj_launch_ch<TS, 8>(pl, R, wmax, list, count, in, out);
 }
 
+// R = register sets per lane (1 / 2 / 4 for windows up to 1024 / 2048 / 4096 rows)
 template <int TS, int R>
-static int bj_launch_wide(const pa_bj_plan_t* pl, int wmax, const int* list, int count,
-                          const double* in, double* out) {
-  const int W = (wmax + 64 + 255) & ~255;
-  const int nw = W / (64 * R);
-  if (nw > 16) {
+static int bj_launch_wide(const pa_bj_plan_t* pl, int wmax, const int* list, int count, const double* in,
+                          double* out) {
+  const int W = bjw_window(wmax);
+  const int nw = (W + 64 * R - 1) / (64 * R);
+  if (nw > 16 || TS * R > 16) {
     snprintf(g_kerr, sizeof(g_kerr),
-             "block-Jacobi: bandwidth %d needs %d wavefronts at panel stride %d (limit 16); use more subdomains",
-             wmax, nw, TS);
+             "block-Jacobi: bandwidth %d is too wide for panel stride %d (window %d rows); use more subdomains",
+             wmax, TS, W);
     fprintf(stderr, "[prealps_hip] %s\n", g_kerr);
     return 1;
   }
-  hipLaunchKernelGGL((k_bj_wide<TS, R>), dim3(count), dim3(64 * nw), 0, cur_stream(), list, count, pl->row0,
-                     pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
-                     pl->invd_b, in, out);
+  if constexpr (TS * R <= 16) {
+    if (nw <= 12)
+      hipLaunchKernelGGL((k_bj_wide<TS, R, 768>), dim3(count), dim3(64 * nw), 0, cur_stream(), list, count,
+                         pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb,
+                         pl->invd_f, pl->invd_b, in, out);
+    else
+      hipLaunchKernelGGL((k_bj_wide<TS, R, 1024>), dim3(count), dim3(64 * nw), 0, cur_stream(), list, count,
+                         pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb,
+                         pl->invd_f, pl->invd_b, in, out);
+  }
   return kfail("k_bj_wide");
+}
+
+template <int R>
+static int bj_wide_dispatch(const pa_bj_plan_t* pl, int ts, int wmax, const int* list, int count,
+                            const double* in, double* out) {
+  switch (ts) {
+    case 2: return bj_launch_wide<2, R>(pl, wmax, list, count, in, out);
+    case 4: return bj_launch_wide<4, R>(pl, wmax, list, count, in, out);
+    case 8: return bj_launch_wide<8, R>(pl, wmax, list, count, in, out);
+    case 16: return bj_launch_wide<16, R>(pl, wmax, list, count, in, out);
+    default: return 1;
+  }
 }
 
 extern "C" {
@@ -1285,6 +1421,13 @@ int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendb
   TS_DISPATCH(ts, hipLaunchKernelGGL((k_pack_rows<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), n,
                                      idx, X, sendbuf));
   return kfail("k_pack_rows");
+}
+
+int pa_k_probe(int which, size_t bytes, const double* src, double* dst) {
+  const size_t n2 = bytes / 16;
+  if (which == 0) hipLaunchKernelGGL(k_probe_copy, dim3(8192), dim3(WG), 0, cur_stream(), n2, (const double2*)src, (double2*)dst);
+  else hipLaunchKernelGGL(k_probe_read, dim3(8192), dim3(WG), 0, cur_stream(), n2, (const double2*)src, dst);
+  return kfail("k_probe");
 }
 
 int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B, double* partials,
@@ -1437,14 +1580,11 @@ int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out)
   for (int c = 0; c < pl->nclass; ++c) {
     if (pl->class_count[c] <= 0) continue;
     int rc = 1;
-    if (pl->class_R[c] == 0) {   /* wide bands: one workgroup per subdomain */
-      switch (ts) {
-        case 2: rc = bj_launch_wide<2, 4>(pl, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out); break;
-        case 4: rc = bj_launch_wide<4, 4>(pl, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out); break;
-        case 8: rc = bj_launch_wide<8, 2>(pl, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out); break;
-        case 16: rc = bj_launch_wide<16, 1>(pl, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out); break;
-        default: rc = 1;
-      }
+    if (pl->class_R[c] < 0) {   /* wide bands: one workgroup per subdomain, -class_R register sets */
+      const int Rw = -pl->class_R[c];
+      if (Rw == 1) rc = bj_wide_dispatch<1>(pl, ts, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out);
+      else if (Rw == 2) rc = bj_wide_dispatch<2>(pl, ts, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out);
+      else rc = bj_wide_dispatch<4>(pl, ts, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out);
       if (rc) return rc;
       continue;
     }

@@ -89,6 +89,9 @@ int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* X
 /* sendbuf[i*ts + c] = X[idx[i]*ts + c] */
 int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendbuf);
 
+/* HBM calibration: which = 0 copy src -> dst, 1 read src (dst receives nothing). */
+int pa_k_probe(int which, size_t bytes, const double* src, double* dst);
+
 /* ---- tall-skinny kernels (ecg.c:250,311,330,347,425,438,510 K2; K3; K4) -- */
 /* Partial Gram blocks C = [A0 | A1]^T B over the local rows, one (npan*ts) x ts
  * column-major block per workgroup into `partials`; returns the number of
@@ -169,7 +172,7 @@ typedef struct {
   const double* invd_b;    /* ... in backward step order */
   int nclass;              /* parts grouped by register sets R = ceil((w+64)/64); R = 0: wide band,
                               one workgroup per part, records of roundup(w+64, 256) doubles in slot order */
-  const int* class_R;      /* host array, nclass */
+  const int* class_R;      /* host array, nclass: register sets per lane; < 0: wide class (workgroup per block) */
   const int* class_count;  /* host array */
   const int* class_wmax;   /* host array: widest band in the class (sizes the LDS chunks) */
   const int* const* class_list; /* host array of device pointers to part ids */
