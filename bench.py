@@ -98,6 +98,7 @@ def main():
                                   distributed=distributed)
     L = prob.L
     prob.create_block_jacobi()
+    check(L.preAlps_hip_prepare_operator(a.t), "prepare_operator")   # the SpMM plan is part of the setup
     t_setup = time.perf_counter() - t_setup
     rhs = prob.reference_rhs()
     alg = {"odir": pl.ORTHODIR, "omin": pl.ORTHOMIN, "fused": pl.ORTHODIR_FUSED}[a.alg]
@@ -184,6 +185,7 @@ def main():
                    "comm": prob.comm_kind,
                    "restarts_in_timed_region": state["restarts"],
                    "iterations_to_converge": state["last_iters"], "setup_seconds": t_setup,
+                   "setup_breakdown_s": {k: prob.stat("setup_" + k + "_s") for k in ("build", "plan", "bj_factor", "bj_layout")},
                    "bj_max_bandwidth": int(prob.stat("bj_max_bandwidth")),
                    "spmm_blocks": int(prob.stat("spmm_blocks"))},
         "roofline": {"kernel": "k_spmm_runs" if prob.stat("spmm_runs") else ("k_spmm_staged" if prob.stat("spmm_staged") else "k_spmm"), "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,

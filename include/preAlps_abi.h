@@ -187,6 +187,23 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos,
 int preAlps_BlockJacobiApply(CPLM_Mat_Dense_t* A_in, CPLM_Mat_Dense_t* B_out);
 void preAlps_BlockJacobiFree(void);
 
+/* ---- generic preconditioner handle of the ECG drivers --------------------
+ * (src/preconditioners/preAlps_preconditioner_struct.h:13-33, preAlps_preconditioner.h:18-25,
+ * preAlps_preconditioner.c:20-76).  PREALPS_NOPREC copies the panel, PREALPS_BLOCKJACOBI
+ * calls preAlps_BlockJacobiApply; LORASC and PRESC are outside this library and abort like
+ * the reference's "Unknown preconditioner". */
+typedef enum { LEFT_PREC, SPLIT_PREC } Prec_Side_t;
+typedef enum { PREALPS_NOPREC, PREALPS_BLOCKJACOBI, PREALPS_LORASC, PREALPS_PRESC } Prec_Type_t;
+typedef struct {
+  Prec_Side_t side;
+  Prec_Type_t type;
+  void* data;
+} PreAlps_preconditioner_t;
+int preAlps_PreconditionerCreate(PreAlps_preconditioner_t** precond, Prec_Type_t precond_type, void* data);
+int preAlps_PreconditionerDestroy(PreAlps_preconditioner_t** precond);
+int preAlps_PreconditionerMatApply(PreAlps_preconditioner_t* precond, CPLM_Mat_Dense_t* A_in,
+                                   CPLM_Mat_Dense_t* B_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ static int bj_wide_window(int w) {
 }
 
 static pa_bj_t g_bj;
+static double g_bj_setup_s[2];
+double pa_bj_setup_seconds(int which) { return g_bj_setup_s[which ? 1 : 0]; }
 
 double pa_bj_factor_bytes(void) { return g_bj.created ? g_bj.factor_bytes : 0.0; }
 int pa_bj_max_bandwidth(void) { return g_bj.created ? g_bj.max_bw : 0; }
@@ -150,6 +152,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   int fail_row = -1;
   for (int q = 0; q < np; ++q) { row0[q] = rowPos[op->part0 + q] - row_off; nrows[q] = rowPos[op->part0 + q + 1] - rowPos[op->part0 + q]; }
 
+  double t_setup0 = pa_wtime();
   /* pass 1 (parallel over blocks): RCM order, bandwidth, band Cholesky */
 #pragma omp parallel for schedule(dynamic, 1)
   for (int q = 0; q < np; ++q) {
@@ -221,6 +224,8 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     free(xadj); free(adj); free(deg); free(order); free(pos); free(queue); free(level);
   }
   int rc = 0;
+  g_bj_setup_s[0] = pa_wtime() - t_setup0;
+  t_setup0 = pa_wtime();
   if (fail_row >= 0) rc = PA_FAIL("diagonal block is not SPD (global row %d)", fail_row);
   /* pass 2: sweep layouts */
   off[0] = 0;
@@ -345,6 +350,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   pl->class_wmax = s->class_wmax;
   pl->class_list = s->class_list_c;
   s->created = 1;
+  g_bj_setup_s[1] = pa_wtime() - t_setup0;
   return 0;
 }
 
@@ -363,4 +369,37 @@ int preAlps_BlockJacobiApply(CPLM_Mat_Dense_t* A_in, CPLM_Mat_Dense_t* B_out) {
   if (pa_k_bj_apply(&s->plan, ts, A_in->val, B_out->val)) return PA_FAIL("block-Jacobi kernel launch failed");
   pa_time_end(PA_T_PRECOND);
   return 0;
+}
+
+/* ---- generic handle (preAlps_preconditioner.c:20-76) ---------------------- */
+int preAlps_PreconditionerCreate(PreAlps_preconditioner_t** precond, Prec_Type_t precond_type, void* data) {
+  if (!precond) return PA_FAIL(" wrong test 'precond != NULL'");
+  *precond = (PreAlps_preconditioner_t*)malloc(sizeof(PreAlps_preconditioner_t));
+  if (!*precond) return PA_FAIL("Malloc fails for precond[].");
+  (*precond)->side = LEFT_PREC;
+  (*precond)->type = precond_type;
+  (*precond)->data = data;
+  return 0;
+}
+
+int preAlps_PreconditionerDestroy(PreAlps_preconditioner_t** precond) {
+  if (precond && *precond) { free(*precond); *precond = NULL; }
+  return 0;
+}
+
+int preAlps_PreconditionerMatApply(PreAlps_preconditioner_t* precond, CPLM_Mat_Dense_t* A_in,
+                                   CPLM_Mat_Dense_t* B_out) {
+  if (!precond) return PA_FAIL(" wrong test 'precond != NULL'");
+  if (precond->type == PREALPS_BLOCKJACOBI) return preAlps_BlockJacobiApply(A_in, B_out);
+  if (precond->type == PREALPS_NOPREC) {   /* CPLM_MatDenseCopy: B_out takes A_in's shape and values */
+    if (!A_in || !B_out || !A_in->val || !B_out->val) return PA_FAIL(" wrong test 'A_in->val != NULL && B_out->val != NULL'");
+    int ts = pa_desc_stride(A_in);
+    if (pa_desc_stride(B_out) != ts || A_in->info.m != B_out->info.m)
+      return PA_FAIL("panel shapes do not match (m %d vs %d)", A_in->info.m, B_out->info.m);
+    B_out->info.n = A_in->info.n; B_out->info.N = A_in->info.N;
+    B_out->info.nval = B_out->info.m * B_out->info.n;
+    if (pa_rt_d2d(B_out->val, A_in->val, (size_t)A_in->info.m * ts * sizeof(double))) return PA_FAIL("%s", pa_rt_error());
+    return 0;
+  }
+  return PA_FAIL("Unknown preconditioner: %d (LORASC / PRESC are not part of this library)", (int)precond->type);
 }

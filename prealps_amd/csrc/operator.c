@@ -61,6 +61,7 @@ typedef struct {
 } pa_operator_t;
 
 static pa_operator_t g_op;
+static double g_setup_build_s, g_setup_plan_s;   /* host seconds: scale/permute/halo lists, SpMM plan */
 
 const pa_operator_info_t* pa_operator_info(void) { return g_op.info.built ? &g_op.info : NULL; }
 
@@ -427,27 +428,39 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
                                  int nparts, const int* part, int scale) {
   if (!g_plan_only) PA_REQUIRE_GPU();
   if (g_op.info.built) preAlps_OperatorFree();
+  double t_build0 = pa_wtime();
   pa_operator_t* o = &g_op;
   pa_operator_info_t* in = &o->info;
   int rank = pa_world_rank(), size = pa_world_size();
   if (N < 1 || nparts < 1 || nparts > N) return PA_FAIL("invalid sizes N=%d nparts=%d", N, nparts);
   if (nparts < size)
     return PA_FAIL("Each process needs at least one block (nparts = %d < %d = processes)", nparts, size);
-  for (int i = 0; i < N; ++i) {
-    int seen = 0;
-    for (int k = rowPtr[i]; k < rowPtr[i + 1] && !seen; ++k) seen = colInd[k] == i;
-    if (!seen) return PA_FAIL("Diagonal is not set correctly (row %d)", i);
+  {
+    int bad_row = -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+      int seen = 0;
+      for (int k = rowPtr[i]; k < rowPtr[i + 1] && !seen; ++k) seen = colInd[k] == i;
+      if (!seen) {
+#pragma omp critical
+        { if (bad_row < 0 || i < bad_row) bad_row = i; }
+      }
+    }
+    if (bad_row >= 0) return PA_FAIL("Diagonal is not set correctly (row %d)", bad_row);
   }
   /* 1. SymRACScaling: d_i = 1/sqrt(max_j |a_ij|) */
   double* d = NULL;
   if (scale) {
     d = (double*)malloc((size_t)N * sizeof(double));
+    int zero_row = 0;
+#pragma omp parallel for schedule(static) reduction(|| : zero_row)
     for (int i = 0; i < N; ++i) {
       double mx = 0.0;
       for (int k = rowPtr[i]; k < rowPtr[i + 1]; ++k) { double a = fabs(val[k]); if (a > mx) mx = a; }
-      if (mx == 0.0) { free(d); return PA_FAIL("Impossible to scale the matrix, rcmin=0"); }
-      d[i] = sqrt(1.0 / mx);
+      if (mx == 0.0) zero_row = 1;
+      d[i] = mx > 0.0 ? sqrt(1.0 / mx) : 0.0;
     }
+    if (zero_row) { free(d); return PA_FAIL("Impossible to scale the matrix, rcmin=0"); }
   }
   /* 2. ordering: rows grouped part by part, original order inside a part */
   in->N = N; in->nparts = nparts;
@@ -489,21 +502,30 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   A->rowPtr[0] = 0;
   {
     int maxlen = 0;
-    for (int i = 0; i < m; ++i) { int old = in->perm[in->row_off + i]; int l = rowPtr[old + 1] - rowPtr[old]; if (l > maxlen) maxlen = l; }
-    cv_t* buf = (cv_t*)malloc((maxlen ? maxlen : 1) * sizeof(cv_t));
     for (int i = 0; i < m; ++i) {
-      int old = in->perm[in->row_off + i];
-      int l = 0;
-      for (int k = rowPtr[old]; k < rowPtr[old + 1]; ++k, ++l) {
-        buf[l].c = iperm[colInd[k]];
-        buf[l].v = d ? d[old] * val[k] * d[colInd[k]] : val[k];
-      }
-      qsort(buf, l, sizeof(cv_t), cmp_cv);
-      int base = A->rowPtr[i];
-      for (int q = 0; q < l; ++q) { A->colInd[base + q] = buf[q].c; A->val[base + q] = buf[q].v; }
-      A->rowPtr[i + 1] = base + l;
+      int old = in->perm[in->row_off + i]; int l = rowPtr[old + 1] - rowPtr[old];
+      if (l > maxlen) maxlen = l;
+      A->rowPtr[i + 1] = A->rowPtr[i] + l;
     }
-    free(buf);
+    /* rows are independent: scale, renumber the columns and sort each one (threads as available) */
+#pragma omp parallel
+    {
+      cv_t* buf = (cv_t*)malloc((maxlen ? maxlen : 1) * sizeof(cv_t));
+#pragma omp for schedule(static)
+      for (int i = 0; i < m; ++i) {
+        int old = in->perm[in->row_off + i];
+        int l = 0, sorted = 1;
+        for (int k = rowPtr[old]; k < rowPtr[old + 1]; ++k, ++l) {
+          buf[l].c = iperm[colInd[k]];
+          buf[l].v = d ? d[old] * val[k] * d[colInd[k]] : val[k];
+          if (l > 0 && buf[l].c < buf[l - 1].c) sorted = 0;
+        }
+        if (!sorted) qsort(buf, l, sizeof(cv_t), cmp_cv);
+        int base = A->rowPtr[i];
+        for (int q = 0; q < l; ++q) { A->colInd[base + q] = buf[q].c; A->val[base + q] = buf[q].v; }
+      }
+      free(buf);
+    }
   }
   free(d); free(iperm);
   A->info.M = N; A->info.N = N; A->info.nnz = rowPtr[N]; A->info.m = m; A->info.n = N;
@@ -555,7 +577,8 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   free(recv_by_proc);
   /* 5. device CSR with local column ids */
   int* lcol = (int*)malloc((lnnz + 8) * sizeof(int));
-  for (size_t k = 0; k < lnnz; ++k) { int c = A->colInd[k]; lcol[k] = (c >= lo && c < hi) ? c - lo : m + mark[c] - 1; }
+#pragma omp parallel for schedule(static)
+  for (long long k = 0; k < (long long)lnnz; ++k) { int c = A->colInd[k]; lcol[k] = (c >= lo && c < hi) ? c - lo : m + mark[c] - 1; }
   for (size_t k = lnnz; k < lnnz + 8; ++k) lcol[k] = 0;
   free(mark);
   o->halo_cols = halo_cols;
@@ -569,6 +592,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   }
   if (rc) return PA_FAIL("uploading the operator failed: %s", pa_rt_error());
   in->built = 1;
+  g_setup_build_s = pa_wtime() - t_build0;
   return 0;
 }
 
@@ -730,7 +754,9 @@ int preAlps_hip_prepare_operator(int enlFac) {
   if (!o->info.built) return PA_FAIL("operator not built");
   if (g_plan_only) return 0;
   int ts = pa_panel_stride(enlFac);
+  double t0 = pa_wtime();
   if (o->plan_ts != ts && build_plan(o, ts)) return 1;
+  g_setup_plan_s = pa_wtime() - t0;
   return 0;
 }
 
@@ -789,6 +815,10 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "spmm_runs")) *value = o->plan.runs;
   else if (!strcmp(key, "spmm_stage_rows")) *value = o->plan.stage_cap;
   else if (!strcmp(key, "spmm_interior_blocks")) *value = o->plan.n_interior;
+  else if (!strcmp(key, "setup_build_s")) *value = g_setup_build_s;
+  else if (!strcmp(key, "setup_plan_s")) *value = g_setup_plan_s;
+  else if (!strcmp(key, "setup_bj_factor_s")) *value = pa_bj_setup_seconds(0);
+  else if (!strcmp(key, "setup_bj_layout_s")) *value = pa_bj_setup_seconds(1);
   else if (!strcmp(key, "bj_factor_bytes")) *value = pa_bj_factor_bytes();
   else if (!strcmp(key, "bj_max_bandwidth")) *value = pa_bj_max_bandwidth();
   else if (!strcmp(key, "bj_parts_local")) *value = pa_bj_nparts();

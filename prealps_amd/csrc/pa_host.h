@@ -59,6 +59,7 @@ void pa_set_desc(CPLM_Mat_Dense_t* A, int M, int N, int m, int n, int ts);
 
 double pa_bj_factor_bytes(void);
 int pa_bj_max_bandwidth(void);
+double pa_bj_setup_seconds(int which);   /* 0: ordering + band Cholesky, 1: sweep layouts + upload */
 int pa_bj_nparts(void);
 
 #endif

@@ -66,6 +66,7 @@ EXPORTS = [
     "preAlps_BlockOperator", "preAlps_OperatorGetA", "preAlps_OperatorGetRowPosPtr",
     "preAlps_OperatorGetColPosPtr", "preAlps_OperatorGetDepPtr",
     "preAlps_BlockJacobiCreate", "preAlps_BlockJacobiApply", "preAlps_BlockJacobiFree",
+    "preAlps_PreconditionerCreate", "preAlps_PreconditionerDestroy", "preAlps_PreconditionerMatApply",
     "preAlps_hip_init", "preAlps_hip_shutdown", "preAlps_hip_set_stream", "preAlps_hip_get_stream",
     "preAlps_hip_sync", "preAlps_hip_set_abort_mode", "preAlps_hip_last_error", "preAlps_hip_panel_stride",
     "preAlps_hip_set_world", "preAlps_hip_set_comm", "preAlps_hip_rccl_unique_id", "preAlps_hip_rccl_init", "preAlps_hip_comm_selftest", "preAlps_OperatorBuildFromCSR",
@@ -110,6 +111,9 @@ def load():
     L._preAlps_ECGReset.argtypes = [pe, pd, pi]
     L.preAlps_BlockOperator.argtypes = [_PD, _PD]
     L.preAlps_BlockJacobiApply.argtypes = [_PD, _PD]
+    L.preAlps_PreconditionerCreate.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+    L.preAlps_PreconditionerDestroy.argtypes = [C.POINTER(C.c_void_p)]
+    L.preAlps_PreconditionerMatApply.argtypes = [C.c_void_p, _PD, _PD]
     L.preAlps_BlockJacobiCreate.argtypes = [C.POINTER(CPLM_Mat_CSR_t), pi, C.c_int, pi, C.c_int]
     L.preAlps_OperatorBuild.argtypes = [C.c_char_p, C.c_int]
     L.preAlps_OperatorBuildFromCSR.argtypes = [C.c_int, pi, pi, pd, C.c_int, pi, C.c_int]

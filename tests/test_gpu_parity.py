@@ -312,3 +312,37 @@ def test_wide_band_blocks_few_large_subdomains(t):
             np.testing.assert_allclose(got.res, ref["res"], rtol=RTOL_HIST)
     finally:
         prob.close()
+
+
+def test_generic_preconditioner_handle(poisson24):
+    """preAlps_PreconditionerCreate / MatApply / Destroy (preAlps_preconditioner.c:20-76):
+    NOPREC copies, BLOCKJACOBI is the block solve, the others are refused loudly."""
+    import ctypes as C
+    import prealps_amd as pa
+    from oracle import oracle as O
+    prob, B, rowpos = poisson24
+    prob.create_block_jacobi()
+    L = prob.L
+    X = np.random.default_rng(8).standard_normal((B.shape[0], 4))
+    for kind, ref in ((0, X), (1, O.BlockJacobi(B, rowpos).apply(X))):
+        h = C.c_void_p()
+        assert L.preAlps_PreconditionerCreate(C.byref(h), kind, None) == 0
+        dx, dy = prob.panel(4, 4), prob.panel(4, 4)
+        try:
+            prob.to_device(dx, X, 4)
+            assert L.preAlps_PreconditionerMatApply(h, C.byref(dx), C.byref(dy)) == 0
+            np.testing.assert_allclose(prob.to_host(dy, 4), ref, rtol=1e-9, atol=1e-10 * np.abs(ref).max())
+        finally:
+            prob.panel_free(dx)
+            prob.panel_free(dy)
+        assert L.preAlps_PreconditionerDestroy(C.byref(h)) == 0 and not h.value
+    h = C.c_void_p()
+    assert L.preAlps_PreconditionerCreate(C.byref(h), 2, None) == 0     # PREALPS_LORASC
+    dx, dy = prob.panel(4, 4), prob.panel(4, 4)
+    try:
+        assert L.preAlps_PreconditionerMatApply(h, C.byref(dx), C.byref(dy)) != 0
+        assert b"Unknown preconditioner" in L.preAlps_hip_last_error()
+    finally:
+        prob.panel_free(dx)
+        prob.panel_free(dy)
+        L.preAlps_PreconditionerDestroy(C.byref(h))
