@@ -346,3 +346,49 @@ def test_generic_preconditioner_handle(poisson24):
         prob.panel_free(dx)
         prob.panel_free(dy)
         L.preAlps_PreconditionerDestroy(C.byref(h))
+
+
+def test_full_size_properties_of_the_headline_workload():
+    """BASELINE.json's metric workload at full size (Q1 elasticity 70^3 nodes, 1.03 M dofs, 81 M
+    nonzeros, t = 4, the bench's partition): too large for the oracle's solver in test time, so
+    checked through size-independent properties against scipy on the host:
+      SpMM                     A X equals the CSR product               (1e-12)
+      block solve              blockdiag(A)^-1 (blockdiag(A) X) = X     (1e-8)
+      SpMM linearity           A (aX + bY) = a AX + b AY                (1e-12)
+      ECG                      the returned iterate satisfies ||b - A x|| <= 2 res, res <= tol ||b||,
+                               the residual history decreases to it, and the iteration count is the
+                               recorded one of this configuration (828 +- 3)."""
+    from oracle import oracle as O
+    from prealps_amd import gen
+    nn, t = 70, 4
+    rp, ci, v = gen.elasticity3d_csr(nn)
+    part, nparts = gen.box_partition_nodes(nn, (2, 4, 8))
+    N = 3 * nn ** 3
+    A = sp.csr_matrix((v, ci, rp), shape=(N, N))
+    prob, B, rowpos = _problem(A, nparts, part)
+    try:
+        assert prob.stat("rows_local") == N and B.nnz == 80990208
+        rng = np.random.default_rng(70)
+        X, Y = rng.standard_normal((N, t)), rng.standard_normal((N, t))
+        AX, AY = prob.block_operator(X, t), prob.block_operator(Y, t)
+        ref = B @ X
+        np.testing.assert_allclose(AX, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+        assert prob.stat("spmm_runs") == 1.0
+        lin = prob.block_operator(0.5 * X - 2.0 * Y, t)
+        np.testing.assert_allclose(lin, 0.5 * AX - 2.0 * AY, rtol=1e-12, atol=1e-11 * np.abs(AX).max())
+        pid = np.repeat(np.arange(nparts), np.diff(rowpos))
+        coo = B.tocoo()
+        keep = pid[coo.row] == pid[coo.col]
+        D = sp.csr_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=B.shape)
+        back = prob.block_jacobi_apply(D @ X, t)
+        np.testing.assert_allclose(back, X, rtol=1e-8, atol=1e-8 * np.abs(X).max())
+        rhs = prob.reference_rhs()
+        np.testing.assert_array_equal(rhs, O.reference_rhs(rowpos))
+        got = prob.solve(rhs, t, max_iter=2000)
+        assert abs(got.iters - 828) <= 3, got.iters
+        assert got.final_res <= 1e-5 * got.normb
+        r = rhs - B @ got.x
+        assert np.linalg.norm(r) <= 2.0001 * got.final_res
+        assert got.res[-1] == got.final_res and got.res[0] > 1e3 * got.final_res
+    finally:
+        prob.close()
