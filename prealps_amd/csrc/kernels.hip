@@ -53,6 +53,25 @@ __device__ __forceinline__ void store_row(double* __restrict__ p, size_t row, co
   for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(r[2 * i], r[2 * i + 1]);
 }
 
+// The same for TS columns of a panel whose rows are XS doubles apart (p already points at the
+// first of those columns).
+template <int TS, int XS>
+__device__ __forceinline__ void load_row_s(const double* __restrict__ p, size_t row, double (&r)[TS]) {
+  const double2* q = reinterpret_cast<const double2*>(p + row * XS);
+#pragma unroll
+  for (int i = 0; i < TS / 2; ++i) {
+    double2 v = q[i];
+    r[2 * i] = v.x;
+    r[2 * i + 1] = v.y;
+  }
+}
+template <int TS, int XS>
+__device__ __forceinline__ void store_row_s(double* __restrict__ p, size_t row, const double (&r)[TS]) {
+  double2* q = reinterpret_cast<double2*>(p + row * XS);
+#pragma unroll
+  for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(r[2 * i], r[2 * i + 1]);
+}
+
 // ---------------------------------------------------------------- SpMM ----
 // SELL-64 SpMM.  One workgroup per block of slices of one subdomain; the
 // subdomain's own X rows (where ~90 % of the nonzeros of a box partition
@@ -181,7 +200,10 @@ __global__ __launch_bounds__(WG) void k_spmm_staged(
 // coalesced 8-B values and 3*TS/2 ds_read_b128 off one address -- 8.67 B of matrix stream
 // per nonzero instead of 10 and a third of the index arithmetic.  The staging area is
 // [external rows below | own rows | external rows above | two zero rows].
-template <int TS>
+// XS = panel stride in doubles.  XS = 2 TS splits a wide panel by columns: two workgroups per
+// block (neighbours in the dispatch order of one XCD, so the second one finds the matrix slice
+// in that XCD's L2), each staging and computing TS of the XS columns.
+template <int TS, int XS>
 __global__ __launch_bounds__(WG) void k_spmm_runs(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -191,25 +213,30 @@ __global__ __launch_bounds__(WG) void k_spmm_runs(
     const int* __restrict__ order, int nlist, const double* __restrict__ X,
     const double* __restrict__ Xh, double* __restrict__ Y) {
   extern __shared__ double sx[];
+  constexpr int NS = XS / TS;
   const int cpx = (nlist + 7) >> 3;
-  const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  const int idx = blockIdx.x >> 3;
+  const int logical = (blockIdx.x & 7) * cpx + idx / NS;
   if (logical >= nlist) return;
+  const int coff = (idx % NS) * TS;
   const int b = order[logical];
   const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
   const int r0 = sl_row0[s0];
   const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
   const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0, nlow = blk_nlow[b];
   const int tid = threadIdx.x;
-  constexpr int H = TS / 2;  // double2 per row
+  constexpr int H = TS / 2;  // double2 per staged row
   {
-    const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)r0 * TS);
     double2* dst = reinterpret_cast<double2*>(sx);
-    for (int i = tid; i < nown * H; i += WG) dst[(size_t)nlow * H + i] = xsrc[i];
+    for (int q = tid; q < nown * H; q += WG) {
+      const int i = q / H, j = q - i * H;
+      dst[(size_t)(nlow + i) * H + j] = reinterpret_cast<const double2*>(X + (size_t)(r0 + i) * XS + coff)[j];
+    }
     for (int q = tid; q < next * H; q += WG) {
       const int i = q / H, j = q - i * H;
       const int id = ext_rows[e0 + i];
-      const double2* src = reinterpret_cast<const double2*>(id < m ? X + (size_t)id * TS
-                                                                     : Xh + (size_t)(id - m) * TS);
+      const double2* src = reinterpret_cast<const double2*>((id < m ? X + (size_t)id * XS
+                                                                      : Xh + (size_t)(id - m) * XS) + coff);
       dst[(size_t)(i < nlow ? i : nown + i) * H + j] = src[j];
     }
     if (tid < 2 * H) dst[(size_t)(nown + next) * H + tid] = make_double2(0.0, 0.0);
@@ -235,7 +262,11 @@ __global__ __launch_bounds__(WG) void k_spmm_runs(
       spmm_fma_row<TS>(acc, v1, xr + TS);
       spmm_fma_row<TS>(acc, v2, xr + 2 * TS);
     }
-    if (lane < sl_nrows[s]) store_row<TS>(Y, (size_t)(sl_row0[s] + lane), acc);
+    if (lane < sl_nrows[s]) {
+      double2* q = reinterpret_cast<double2*>(Y + (size_t)(sl_row0[s] + lane) * XS + coff);
+#pragma unroll
+      for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
+    }
   }
 }
 
@@ -924,7 +955,7 @@ __device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chu
   }
 }
 
-template <int TS, int R, int CH, int K>
+template <int TS, int R, int CH, int K, int XS>
 __device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R], int jb, int& chunk, int b,
                                           int w, int wr, const double* __restrict__ rec,
                                           const double* __restrict__ invd,
@@ -940,7 +971,7 @@ __device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R],
       int nrow = 0;
       const int jn = j0 + W + lane;
       if (j0 + lane < b) idl = invd[j0 + lane];
-      if (jn < b) { nrow = iomap[jn]; load_row<TS>(src, rowbase + nrow, nxt); }
+      if (jn < b) { nrow = iomap[jn]; load_row_s<TS, XS>(src, rowbase + nrow, nxt); }
       else
 #pragma unroll
         for (int c = 0; c < TS; ++c) nxt[c] = 0.0;
@@ -950,18 +981,18 @@ __device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R],
         double y[TS];
 #pragma unroll
         for (int c = 0; c < TS; ++c) y[c] = acc[K][c] * idl;
-        store_row<TS>(dst, rowbase + rowid[K], y);
+        store_row_s<TS, XS>(dst, rowbase + rowid[K], y);
       }
 #pragma unroll
       for (int c = 0; c < TS; ++c) acc[K][c] = nxt[c];
       rowid[K] = nrow;
     }
-    bj_blocks<TS, R, CH, K + 1>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0,
+    bj_blocks<TS, R, CH, K + 1, XS>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0,
                                 lds1, lane);
   }
 }
 
-template <int TS, int R, int CH>
+template <int TS, int R, int CH, int XS>
 __device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __restrict__ rec,
                                          const double* __restrict__ invd,
                                          const int* __restrict__ iomap, size_t rowbase,
@@ -974,7 +1005,7 @@ __device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __r
   for (int k = 0; k < R; ++k) {
     const int j = k * 64 + lane;
     rowid[k] = 0;
-    if (j < b) { rowid[k] = iomap[j]; load_row<TS>(src, rowbase + rowid[k], acc[k]); }
+    if (j < b) { rowid[k] = iomap[j]; load_row_s<TS, XS>(src, rowbase + rowid[k], acc[k]); }
     else
 #pragma unroll
       for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
@@ -982,12 +1013,14 @@ __device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __r
   bj_issue_chunk<CH>(rec, wr, 0, lds0, lane);
   int chunk = 0;
   for (int jb = 0; jb < b; jb += W)
-    bj_blocks<TS, R, CH, 0>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lds1,
+    bj_blocks<TS, R, CH, 0, XS>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lds1,
                             lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int TS, int R, int CH>
+// XS = panel stride: XS = TS, or a multiple of it when the panel is split by columns among XS/TS
+// wavefronts (opt-in, see bj_launch).
+template <int TS, int R, int CH, int XS>
 __global__ void k_bj_apply(
     const int* __restrict__ list, int count, const int* __restrict__ row0,
     const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off,
@@ -997,8 +1030,11 @@ __global__ void k_bj_apply(
     double* __restrict__ out) {
   extern __shared__ double smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int pi = blockIdx.x * (blockDim.x >> 6) + wave;
+  constexpr int NS = XS / TS;
+  const int unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  const int pi = unit / NS;
   if (pi >= count) return;
+  const int coff = (unit % NS) * TS;
   // everything that steers the sweep is wave-uniform: keep it in SGPRs
   const int p = __builtin_amdgcn_readfirstlane(list[pi]);
   const int r0 = __builtin_amdgcn_readfirstlane(row0[p]);
@@ -1011,9 +1047,9 @@ __global__ void k_bj_apply(
   double* lds0 = smem + (size_t)wave * lds_per_wave;
   double* lds1 = lds0 + (lds_per_wave >> 1);
   // forward: L y = x (y goes to `out`), backward: L^T z = y in place
-  bj_sweep<TS, R, CH>(b, w, wr, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in, out, lds0, lds1, lane);
+  bj_sweep<TS, R, CH, XS>(b, w, wr, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in + coff, out + coff, lds0, lds1, lane);
   __threadfence_block();
-  bj_sweep<TS, R, CH>(b, w, wr, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, lds0, lds1, lane);
+  bj_sweep<TS, R, CH, XS>(b, w, wr, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out + coff, out + coff, lds0, lds1, lane);
 }
 
 // Wide bands (RCM bandwidth > 448: few, large subdomains).  One workgroup of up to 16
@@ -1272,16 +1308,19 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
                        const double* Xh, double* Y) {
   if (nlist <= 0) return 0;
   if (pl->runs) {
-    const size_t lds = (size_t)pl->stage_cap * TS * 8;
+    // a plan cut for half the panel stride: two workgroups per block, 8 of the 16 columns each
+    constexpr int TC = TS >= 16 ? TS / 2 : TS;
+    const int ns = TS / TC;
+    const size_t lds = (size_t)pl->stage_cap * TC * 8;
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TS>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TC, TS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return kfail("hipFuncSetAttribute(k_spmm_runs)");
       configured = lds;
     }
     const int cpx = (nlist + 7) / 8;
-    hipLaunchKernelGGL((k_spmm_runs<TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+    hipLaunchKernelGGL((k_spmm_runs<TC, TS>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
                        pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
                        pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
     return kfail("k_spmm_runs");
@@ -1319,7 +1358,7 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
   return kfail("k_spmm");
 }
 
-template <int TS, int CH>
+template <int TS, int CH, int XS>
 static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, int count,
                         const double* in, double* out) {
   // LDS per wave: two chunk buffers of CH records of the widest band in this class
@@ -1329,17 +1368,18 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
   if (waves > 4) waves = 4;
   if (waves < 1) { snprintf(g_kerr, sizeof(g_kerr), "block-Jacobi band too wide for LDS (R=%d)", R); return 1; }
   const size_t lds = (size_t)waves * per_wave * 8;
-  const int blocks = (count + waves - 1) / waves;
+  const int units = count * (XS / TS);   // one wavefront per (subdomain, column group)
+  const int blocks = (units + waves - 1) / waves;
 #define BJ_CASE(RR)                                                                               \
   case RR: {                                                                                      \
     static size_t configured = 0;                                                                 \
     if (lds > 64 * 1024 && lds > configured) {                                                    \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply<TS, RR, CH>),             \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply<TS, RR, CH, XS>),             \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return kfail("hipFuncSetAttribute(k_bj_apply)");                                          \
       configured = lds;                                                                           \
     }                                                                                             \
-    hipLaunchKernelGGL((k_bj_apply<TS, RR, CH>), dim3(blocks), dim3(64 * waves), lds,             \
+    hipLaunchKernelGGL((k_bj_apply<TS, RR, CH, XS>), dim3(blocks), dim3(64 * waves), lds,             \
                        cur_stream(), list, count, pl->row0, pl->nrows, pl->bw, pl->off,           \
                        pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, per_wave, in, out); \
   } break;
@@ -1358,7 +1398,15 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
                      const double* in, double* out) {
   // chunks of 8 steps: measured equal or better than 16 and 32 (smaller LDS footprint,
   // more workgroups per CU)
-  return bj_launch_ch<TS, 8>(pl, R, wmax, list, count, in, out);
+  // PREALPS_BJ_SPLIT=1: panels of 8 / 16 columns as 2 / 4 wavefronts of 4 columns each per
+  // subdomain.  Measured slower (each wavefront streams the factor again through L2: 257 vs
+  // 243 us at 8 columns, 485 vs 434 us at 16), so one wavefront carries all columns by default.
+  static int split = -1;
+  if (split < 0) { const char* e = getenv("PREALPS_BJ_SPLIT"); split = e ? atoi(e) : 0; }
+  if constexpr (TS >= 8) {
+    if (split) return bj_launch_ch<4, 8, TS>(pl, R, wmax, list, count, in, out);
+  }
+  return bj_launch_ch<TS, 8, TS>(pl, R, wmax, list, count, in, out);
 }
 
 // R = register sets per lane (1 / 2 / 4 for windows up to 1024 / 2048 / 4096 rows)

@@ -139,7 +139,6 @@ static int build_plan(pa_operator_t* o, int ts) {
   /* -1 (default): stage when the external rows a block copies are small next to its matrix
    * slice (long rows: elasticity); short rows (7-point stencils) gather through L2 instead */
   int want = env_int("PREALPS_SPMM_STAGED", -1);
-  if (want < 0 && ts >= 16) want = 0; /* wide panels: the 128-B X rows gather well from L2 (measured) */
   if (want != 0 && env_int("PREALPS_SPMM_RUNS", 1)) {
     /* rows whose nonzeros come in runs of consecutive columns (vector problems: 3 dofs per
      * node) share one LDS slot per run of three: 8.67 B per nonzero instead of 10 */
@@ -148,6 +147,7 @@ static int build_plan(pa_operator_t* o, int ts) {
     if (rc == 0) { o->plan_ts = ts; return 0; }
     free_plan(o);
   }
+  if (want < 0 && ts >= 16) want = 0; /* wide panels: the 128-B X rows gather well from L2 (measured) */
   if (want != 0) {
     int rc = build_plan_staged(o, ts);
     if (rc < 0) return 1;
@@ -867,6 +867,9 @@ static int build_plan_runs(pa_operator_t* o, int ts) {
   const int* colind = o->lcol;
   const double* val = in->A.val;
   int m = in->m, ncols = m + in->halo;
+  /* panels of 16 columns are handled as two halves of 8 (two workgroups per block, kernels.hip),
+   * so the staging area and the pay-off test are those of stride 8 */
+  if (ts >= 16) ts /= 2;
   int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", ts <= 4 ? 32768 : 65536) / (ts * 8) - 2;
   if (cap_rows > 65533) cap_rows = 65533;
   int blk_rows = env_int("PREALPS_SPMM_BLOCK_ROWS", 256);

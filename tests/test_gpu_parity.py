@@ -92,7 +92,7 @@ def test_spmm_and_block_solve_on_ragged_rows():
         prob.close()
 
 
-@pytest.mark.parametrize("t", [2, 4, 8])
+@pytest.mark.parametrize("t", [2, 4, 8, 16])
 @pytest.mark.parametrize("kind", ["random", "poisson", "elasticity_cut"])
 def test_spmm_run_plan_on_irregular_patterns(kind, t, monkeypatch):
     """The run plan (one slot per three consecutive staging slots) forced onto patterns it
