@@ -231,13 +231,13 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   off[0] = 0;
   int maxw = 0;
   /* narrow bands (one wavefront per block): one record of wr doubles per step,
-   * [1/L(j,j) | row id | 0 | L(j+1..j+w, j) | 0], wr even.  Wide bands (one workgroup per
+   * [L(j+1..j+w, j) / L(j,j) | 0], wr = w + 1 rounded up to even.  Wide bands (one workgroup per
    * block): records of W = bj_wide_window(w) >= w + 64 doubles in window-slot order, the value
    * for target row i at column i mod W. */
   int maxR = pa_bj_max_R();
   for (int q = 0; q < np; ++q) {
     int wide = (bw[q] + 127) / 64 > maxR;
-    long long reclen = wide ? bj_wide_window(bw[q]) : ((bw[q] + 5) & ~1);
+    long long reclen = wide ? bj_wide_window(bw[q]) : ((bw[q] + 2) & ~1);
     off[q + 1] = off[q] + (long long)nrows[q] * reclen;
     if (bw[q] > maxw) maxw = bw[q];
   }
@@ -257,7 +257,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
 #pragma omp parallel for schedule(dynamic, 1)
     for (int q = 0; q < np; ++q) {
       int b = nrows[q], w = bw[q], r0 = row0[q];
-      size_t ld = (size_t)w + 1, wr = (size_t)((w + 5) & ~1);
+      size_t ld = (size_t)w + 1, wr = (size_t)((w + 2) & ~1);
       const double* band = bands[q];
       double* f = Lf + off[q];
       double* g = Lb + off[q];
@@ -276,15 +276,12 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       }
       for (int j = 0; j < b; ++j) {
         int jr = b - 1 - j;
-        long long idf = map_f[r0 + j], idb = map_b[r0 + j];
-        f[(size_t)j * wr] = invd_f[r0 + j] = 1.0 / band[(size_t)j * ld];
-        g[(size_t)j * wr] = invd_b[r0 + j] = 1.0 / band[(size_t)jr * ld];
-        memcpy(&f[(size_t)j * wr + 1], &idf, sizeof(double));
-        memcpy(&g[(size_t)j * wr + 1], &idb, sizeof(double));
+        invd_f[r0 + j] = 1.0 / band[(size_t)j * ld];
+        invd_b[r0 + j] = 1.0 / band[(size_t)jr * ld];
         for (int dd = 1; dd <= w; ++dd) {
-          /* pre-divided by the pivot of the step (see kernels.hip: bj_block) */
-          f[(size_t)j * wr + 2 + dd] = (j + dd < b) ? band[(size_t)(j + dd) * ld + dd] * invd_f[r0 + j] : 0.0;
-          g[(size_t)j * wr + 2 + dd] = (jr - dd >= 0) ? band[(size_t)jr * ld + dd] * invd_b[r0 + j] : 0.0;
+          /* pre-divided by the pivot of the step (see kernels.hip: bj_block); slot w stays 0 */
+          f[(size_t)j * wr + dd - 1] = (j + dd < b) ? band[(size_t)(j + dd) * ld + dd] * invd_f[r0 + j] : 0.0;
+          g[(size_t)j * wr + dd - 1] = (jr - dd >= 0) ? band[(size_t)jr * ld + dd] * invd_b[r0 + j] : 0.0;
         }
       }
     }

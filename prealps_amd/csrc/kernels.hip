@@ -876,7 +876,7 @@ __global__ __launch_bounds__(WG) void k_rowsum(int m, int nc, const double* __re
 // v_readlane and every lane updates the rows j+1..j+w it holds.
 //
 // The band is the only large operand and it is read exactly once per sweep:
-// step j needs the record [1/L(j,j) | row id | L(j+1..j+w, j)] (wr doubles).
+// step j needs the record [L(j+1..j+w, j) / L(j,j) | 0] (wr doubles).
 // Records are streamed HBM -> LDS in chunks of CH steps with LDS-DMA
 // (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPRs), double
 // buffered per wave so chunk c+1 is in flight while chunk c is consumed.
@@ -893,15 +893,14 @@ __device__ __forceinline__ void bj_issue_chunk(const double* __restrict__ rec, i
     __builtin_amdgcn_global_load_lds((glb_void_ptr)(g + o), (lds_void_ptr)(l + o), 16, 0, 0);
 }
 
-// Record of step j (wr = (w+5)&~1 doubles):
-//   r[0] = 1/L(j,j)   r[1] = row id (both unused by the kernel)   r[2] = 0
-//   r[2+d] = L(j+d, j) / L(j, j), d = 1..w   r[w+3] = 0
+// Record of step j (wr = w + 1 rounded up to even, doubles):
+//   r[d-1] = L(j+d, j) / L(j, j), d = 1..w      r[w] = 0
 // The band is pre-divided by its pivot, so a step is a_i -= (L_ij / L_jj) a_j
 // with a_j read straight from its lane (no multiply on the critical path);
 // y_j = a_j / L_jj is formed once per row when its block of 64 is stored.
-// A lane that holds row j+d reads r[2 + min(d, w+1)] (d taken as unsigned): rows
+// A lane that holds row j+d reads r[min(d-1, w)] (d-1 taken as unsigned): rows
 // outside the band, the pivot row itself (d = 0) and rows already solved
-// (d < 0) all land on a zero, so the update needs no branch.  A solved row is
+// (d < 0) all land on the zero, so the update needs no branch.  A solved row is
 // never touched again, so the block's 64 results stay in their lanes and are
 // scaled and stored together when the block is done.
 template <int R>
@@ -917,9 +916,9 @@ __device__ __forceinline__ void bj_load_step(const double* __restrict__ r, int l
     const int rel = (k2 - K + R) % R;
     v.lv[k2] = 0.0;
     if (rel == 0 || l >= rel * 64 - w) {       // wave-uniform: does set k2 touch the band at all?
-      const unsigned d = (unsigned)(rel * 64 + lane - l);
-      const unsigned idx = min(d, (unsigned)(w + 1));
-      v.lv[k2] = r[2 + idx];
+      const unsigned d1 = (unsigned)(rel * 64 + lane - l - 1);
+      const unsigned idx = min(d1, (unsigned)w);
+      v.lv[k2] = r[idx];
     }
   }
 }
@@ -1040,7 +1039,7 @@ __global__ void k_bj_apply(
   const int r0 = __builtin_amdgcn_readfirstlane(row0[p]);
   const int b = __builtin_amdgcn_readfirstlane(nrows[p]);
   const int w = __builtin_amdgcn_readfirstlane(bw[p]);
-  const int wr = (w + 5) & ~1;
+  const int wr = (w + 2) & ~1;
   const long long o64 = off[p];
   const size_t o = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(o64 >> 32)) << 32) |
                    (unsigned)__builtin_amdgcn_readfirstlane((int)o64);
@@ -1362,7 +1361,7 @@ template <int TS, int CH, int XS>
 static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, int count,
                         const double* in, double* out) {
   // LDS per wave: two chunk buffers of CH records of the widest band in this class
-  const int wr = (wmax + 5) & ~1;
+  const int wr = (wmax + 2) & ~1;
   int per_wave = 2 * ((CH * wr + 127) & ~127);  // doubles, each buffer a multiple of 1 KiB
   int waves = (160 * 1024) / (per_wave * 8);
   if (waves > 4) waves = 4;
