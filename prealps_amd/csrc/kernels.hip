@@ -923,6 +923,36 @@ __device__ __forceinline__ void bj_load_step(const double* __restrict__ r, int l
   }
 }
 
+// A full chunk of CH steps with the first NA register sets (counted from the pivots' own set)
+// inside the band: straight-line code, all CH*NA band values read from LDS up front, no branch
+// and no scalar bookkeeping per step.  (Sets beyond NA would only meet the zero slot.)
+template <int TS, int R, int CH, int K, int NA>
+__device__ __forceinline__ void bj_chunk_fast(double (&acc)[R][TS], const double* cur, int lc, int w,
+                                              int wr, int lane) {
+  double cf[CH][NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    const int a0 = a * 64 + lane - lc - 1;          // d - 1 of step 0 for this set
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      const unsigned idx = min((unsigned)(a0 - s), (unsigned)w);
+      cf[s][a] = cur[s * wr + idx];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < CH; ++s) {
+    double y[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) y[c] = readlane_f64(acc[K][c], lc + s);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const int k2 = (K + a) % R;
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[k2][c] = fma(-cf[s][a], y[c], acc[k2][c]);
+    }
+  }
+}
+
 template <int TS, int R, int CH, int K>
 __device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chunk, int b, int w, int wr,
                                          const double* __restrict__ rec, double* lds0, double* lds1,
@@ -933,6 +963,17 @@ __device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chu
     const double* cur = (chunk & 1) ? lds1 : lds0;
     if ((chunk + 1) * CH < b) bj_issue_chunk<CH>(rec, wr, chunk + 1, (chunk & 1) ? lds0 : lds1, lane);
     const int send = (lim - lc) < CH ? (lim - lc) : CH;
+    if constexpr (R <= 3) {
+      if (send == CH) {
+        // sets the last step of the chunk reaches (wave-uniform): rel is inside the band from
+        // step l >= rel*64 - w on
+        const int lmax = lc + CH - 1;
+        if (R >= 3 && lmax >= 128 - w) bj_chunk_fast<TS, R, CH, K, (R >= 3 ? 3 : 1)>(acc, cur, lc, w, wr, lane);
+        else if (R >= 2 && lmax >= 64 - w) bj_chunk_fast<TS, R, CH, K, (R >= 2 ? 2 : 1)>(acc, cur, lc, w, wr, lane);
+        else bj_chunk_fast<TS, R, CH, K, 1>(acc, cur, lc, w, wr, lane);
+        continue;
+      }
+    }
     bj_vals<R> nv;
     bj_load_step<R, K>(cur, lc, w, lane, nv);
     for (int s = 0; s < send; ++s) {
