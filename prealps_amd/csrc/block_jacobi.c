@@ -50,6 +50,12 @@ static int bj_wide_window(int w) {
   return (w + 64 + 255) & ~255;
 }
 
+/* block that holds local (factor-order) position `pos` */
+static int part_of_local_row(const int* row0, const int* nrows, int np, int pos) {
+  for (int q = 0; q < np; ++q) if (pos >= row0[q] && pos < row0[q] + nrows[q]) return q;
+  return 0;
+}
+
 static pa_bj_t g_bj;
 static double g_bj_setup_s[2];
 double pa_bj_setup_seconds(int which) { return g_bj_setup_s[which ? 1 : 0]; }
@@ -153,7 +159,10 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   for (int q = 0; q < np; ++q) { row0[q] = rowPos[op->part0 + q] - row_off; nrows[q] = rowPos[op->part0 + q + 1] - rowPos[op->part0 + q]; }
 
   double t_setup0 = pa_wtime();
-  /* pass 1 (parallel over blocks): RCM order, bandwidth, band Cholesky */
+  /* PREALPS_BJ_FACTOR=host keeps every factorisation on the host threads */
+  const char* fenv = getenv("PREALPS_BJ_FACTOR");
+  const int dev_factor = !(fenv && !strcmp(fenv, "host")), dev_wmax = pa_bj_factor_wmax();
+  /* pass 1 (parallel over blocks): RCM order, bandwidth, band assembly, host band Cholesky */
 #pragma omp parallel for schedule(dynamic, 1)
   for (int q = 0; q < np; ++q) {
     int r0 = row0[q], b = nrows[q];
@@ -197,7 +206,8 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       }
     }
     size_t ld = (size_t)w + 1;
-    for (int i = 0; i < b; ++i) {
+    /* narrow bands are factored on the device (k_bj_factor); wider ones here */
+    for (int i = 0; i < b && !(dev_factor && w <= dev_wmax); ++i) {
       double* Li = band + (size_t)i * ld; /* Li[d] = L(i, i-d) */
       int jlo = i - w > 0 ? i - w : 0;
       for (int j = jlo; j < i; ++j) {
@@ -247,47 +257,85 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
                  "solve supports up to 4032 -- use more (smaller) subdomains", maxw);
   size_t tot = (size_t)off[np];
   const size_t pad = 256; /* the last LDS-DMA piece of a chunk may read up to 1 KiB past it */
-  double* Lf = NULL; double* Lb = NULL;
+  /* device arrays first: the factors are written in place, by the factorisation kernel for
+   * the narrow blocks and by per-block uploads for the ones factored on the host */
   if (!rc) {
-    Lf = (double*)calloc(tot + pad, sizeof(double));
-    Lb = (double*)calloc(tot + pad, sizeof(double));
-    if (!Lf || !Lb) rc = PA_FAIL("out of host memory for %zu factor entries", tot);
+    s->d_invd_f = (double*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(double));
+    s->d_invd_b = (double*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(double));
+    s->d_Lf = (double*)pa_rt_malloc((tot + pad) * sizeof(double));
+    s->d_Lb = (double*)pa_rt_malloc((tot + pad) * sizeof(double));
+    if (!s->d_Lf || !s->d_Lb || !s->d_invd_f || !s->d_invd_b ||
+        pa_rt_memset(s->d_Lf, 0, (tot + pad) * sizeof(double)) || pa_rt_memset(s->d_Lb, 0, (tot + pad) * sizeof(double)))
+      rc = PA_FAIL("allocating %zu factor entries on the device failed: %s", tot, pa_rt_error());
   }
-  if (!rc) {
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int q = 0; q < np; ++q) {
-      int b = nrows[q], w = bw[q], r0 = row0[q];
-      size_t ld = (size_t)w + 1, wr = (size_t)((w + 2) & ~1);
-      const double* band = bands[q];
-      double* f = Lf + off[q];
-      double* g = Lb + off[q];
-      if ((w + 127) / 64 > maxR) { /* wide: window-slot order, pre-divided by the pivot */
-        size_t W = (size_t)bj_wide_window(w);
-        for (int j = 0; j < b; ++j) {
+  int ndev = 0;
+  for (int q = 0; q < np; ++q) if (dev_factor && bw[q] <= dev_wmax) ++ndev;
+  if (!rc && ndev < np) {
+    /* host-factored blocks: runs of consecutive blocks (up to 64 MiB of records) are laid out
+     * by the host threads into a staging buffer (256 MiB, or one block if larger) and go to
+     * the device in one copy each */
+    const size_t cap = (size_t)32 << 20;                   /* doubles: 256 MiB per staging buffer */
+    size_t sf_cap = 0;
+    double* sf = NULL; double* sg = NULL;
+    int q = 0;
+    while (q < np && !rc) {
+      if (dev_factor && bw[q] <= dev_wmax) { ++q; continue; }
+      int q1 = q;
+      while (q1 < np && !(dev_factor && bw[q1] <= dev_wmax) && (q1 == q || (size_t)(off[q1 + 1] - off[q]) <= cap)) ++q1;
+      size_t len = (size_t)(off[q1] - off[q]);
+      if (len > sf_cap) {
+        sf_cap = len;
+        sf = (double*)realloc(sf, sf_cap * sizeof(double));
+        sg = (double*)realloc(sg, sf_cap * sizeof(double));
+        if (!sf || !sg) { rc = PA_FAIL("out of host memory for %zu factor entries", sf_cap); break; }
+      }
+      memset(sf, 0, len * sizeof(double));
+      memset(sg, 0, len * sizeof(double));
+      /* work items = slabs of 256 steps of one block, so that a run of few large blocks
+       * still keeps every host thread busy */
+      int nitem = 0;
+      for (int x = q; x < q1; ++x) nitem += (nrows[x] + 255) / 256;
+      int* item_part = (int*)malloc((nitem ? nitem : 1) * sizeof(int));
+      int* item_j0 = (int*)malloc((nitem ? nitem : 1) * sizeof(int));
+      nitem = 0;
+      for (int x = q; x < q1; ++x)
+        for (int j0 = 0; j0 < nrows[x]; j0 += 256) { item_part[nitem] = x; item_j0[nitem++] = j0; }
+#pragma omp parallel for schedule(dynamic, 4)
+      for (int it = 0; it < nitem; ++it) {
+        int x = item_part[it];
+        int b = nrows[x], w = bw[x], r0 = row0[x];
+        size_t ld = (size_t)w + 1;
+        int wide = (w + 127) / 64 > maxR;
+        size_t reclen = wide ? (size_t)bj_wide_window(w) : (size_t)((w + 2) & ~1);
+        const double* band = bands[x];
+        double* f = sf + (off[x] - off[q]);
+        double* g = sg + (off[x] - off[q]);
+        int j1 = item_j0[it] + 256 < b ? item_j0[it] + 256 : b;
+        for (int j = item_j0[it]; j < j1; ++j) {
           int jr = b - 1 - j;
           invd_f[r0 + j] = 1.0 / band[(size_t)j * ld];
           invd_b[r0 + j] = 1.0 / band[(size_t)jr * ld];
           for (int dd = 1; dd <= w; ++dd) {
-            if (j + dd < b) f[(size_t)j * W + (size_t)(j + dd) % W] = band[(size_t)(j + dd) * ld + dd] * invd_f[r0 + j];
-            if (jr - dd >= 0) g[(size_t)j * W + (size_t)(j + dd) % W] = band[(size_t)jr * ld + dd] * invd_b[r0 + j];
+            if (wide) { /* window-slot order, pre-divided by the pivot */
+              if (j + dd < b) f[(size_t)j * reclen + (size_t)(j + dd) % reclen] = band[(size_t)(j + dd) * ld + dd] * invd_f[r0 + j];
+              if (jr - dd >= 0) g[(size_t)j * reclen + (size_t)(j + dd) % reclen] = band[(size_t)jr * ld + dd] * invd_b[r0 + j];
+            } else {    /* [L(j+1..j+w, j) / L(j,j) | 0] (see kernels.hip: bj_block) */
+              f[(size_t)j * reclen + dd - 1] = (j + dd < b) ? band[(size_t)(j + dd) * ld + dd] * invd_f[r0 + j] : 0.0;
+              g[(size_t)j * reclen + dd - 1] = (jr - dd >= 0) ? band[(size_t)jr * ld + dd] * invd_b[r0 + j] : 0.0;
+            }
           }
         }
-        continue;
       }
-      for (int j = 0; j < b; ++j) {
-        int jr = b - 1 - j;
-        invd_f[r0 + j] = 1.0 / band[(size_t)j * ld];
-        invd_b[r0 + j] = 1.0 / band[(size_t)jr * ld];
-        for (int dd = 1; dd <= w; ++dd) {
-          /* pre-divided by the pivot of the step (see kernels.hip: bj_block); slot w stays 0 */
-          f[(size_t)j * wr + dd - 1] = (j + dd < b) ? band[(size_t)(j + dd) * ld + dd] * invd_f[r0 + j] : 0.0;
-          g[(size_t)j * wr + dd - 1] = (jr - dd >= 0) ? band[(size_t)jr * ld + dd] * invd_b[r0 + j] : 0.0;
-        }
-      }
+      free(item_part); free(item_j0);
+      if (pa_rt_h2d(s->d_Lf + off[q], sf, len * sizeof(double)) || pa_rt_h2d(s->d_Lb + off[q], sg, len * sizeof(double)))
+        rc = PA_FAIL("uploading the block factors failed: %s", pa_rt_error());
+      q = q1;
     }
+    free(sf); free(sg);
   }
-  for (int q = 0; q < np; ++q) free(bands[q]);
-  free(bands);
+  if (!rc && (pa_rt_h2d(s->d_invd_f, invd_f, (size_t)m * sizeof(double)) ||
+              pa_rt_h2d(s->d_invd_b, invd_b, (size_t)m * sizeof(double))))
+    rc = PA_FAIL("uploading the block factors failed: %s", pa_rt_error());
   /* classes */
   if (!rc) {
     int* cls = (int*)malloc(np * sizeof(int));
@@ -322,20 +370,51 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     s->d_off = (long long*)pa_rt_malloc((np + 1) * sizeof(long long));
     s->d_map_f = (int*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(int));
     s->d_map_b = (int*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(int));
-    s->d_invd_f = (double*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(double));
-    s->d_invd_b = (double*)pa_rt_malloc((size_t)(m ? m : 1) * sizeof(double));
-    s->d_Lf = (double*)pa_rt_malloc((tot + pad) * sizeof(double));
-    s->d_Lb = (double*)pa_rt_malloc((tot + pad) * sizeof(double));
-    int bad = !s->d_row0 || !s->d_nrows || !s->d_bw || !s->d_off || !s->d_map_f || !s->d_map_b ||
-              !s->d_Lf || !s->d_Lb || !s->d_invd_f || !s->d_invd_b;
+    int bad = !s->d_row0 || !s->d_nrows || !s->d_bw || !s->d_off || !s->d_map_f || !s->d_map_b;
     bad = bad || pa_rt_h2d(s->d_row0, row0, np * sizeof(int)) || pa_rt_h2d(s->d_nrows, nrows, np * sizeof(int)) ||
           pa_rt_h2d(s->d_bw, bw, np * sizeof(int)) || pa_rt_h2d(s->d_off, off, (np + 1) * sizeof(long long)) ||
-          pa_rt_h2d(s->d_map_f, map_f, (size_t)m * sizeof(int)) || pa_rt_h2d(s->d_map_b, map_b, (size_t)m * sizeof(int)) ||
-          pa_rt_h2d(s->d_invd_f, invd_f, (size_t)m * sizeof(double)) || pa_rt_h2d(s->d_invd_b, invd_b, (size_t)m * sizeof(double)) ||
-          pa_rt_h2d(s->d_Lf, Lf, (tot + pad) * sizeof(double)) || pa_rt_h2d(s->d_Lb, Lb, (tot + pad) * sizeof(double));
+          pa_rt_h2d(s->d_map_f, map_f, (size_t)m * sizeof(int)) || pa_rt_h2d(s->d_map_b, map_b, (size_t)m * sizeof(int));
     if (bad) rc = PA_FAIL("uploading the block factors failed: %s", pa_rt_error());
   }
-  free(Lf); free(Lb);
+  if (!rc && ndev > 0) {
+    /* narrow blocks: ship the assembled bands, factor and lay out on the device */
+    long long* boff = (long long*)malloc((np + 1) * sizeof(long long));
+    int* dlist = (int*)malloc(ndev * sizeof(int));
+    size_t btot = 0;
+    int nd = 0, wdev = 0;
+    for (int q = 0; q < np; ++q) {
+      boff[q] = (long long)btot;
+      if (bw[q] <= dev_wmax) { dlist[nd++] = q; btot += (size_t)nrows[q] * (bw[q] + 1); if (bw[q] > wdev) wdev = bw[q]; }
+    }
+    boff[np] = (long long)btot;
+    double* hb = (double*)malloc((btot ? btot : 1) * sizeof(double));   /* one upload instead of one per block */
+    double* d_band = (double*)pa_rt_malloc((btot ? btot : 1) * sizeof(double));
+    long long* d_boff = (long long*)pa_rt_malloc((np + 1) * sizeof(long long));
+    int* d_list = (int*)pa_rt_malloc(ndev * sizeof(int));
+    int* d_fail = (int*)pa_rt_malloc(sizeof(int));
+    int fail = 0;
+    if (!hb || !d_band || !d_boff || !d_list || !d_fail) rc = PA_FAIL("allocating the band staging failed: %s", pa_rt_error());
+    if (!rc) {
+#pragma omp parallel for schedule(dynamic, 16)
+      for (int x = 0; x < nd; ++x) {
+        int q = dlist[x];
+        memcpy(hb + boff[q], bands[q], (size_t)nrows[q] * (bw[q] + 1) * sizeof(double));
+      }
+      if (pa_rt_h2d(d_band, hb, btot * sizeof(double)) || pa_rt_h2d(d_boff, boff, (np + 1) * sizeof(long long)) ||
+          pa_rt_h2d(d_list, dlist, ndev * sizeof(int)) || pa_rt_h2d(d_fail, &fail, sizeof(int)) ||
+          pa_k_bj_factor(d_list, ndev, wdev, s->d_row0, s->d_nrows, s->d_bw, s->d_off, d_boff, d_band, s->d_Lf,
+                         s->d_Lb, s->d_invd_f, s->d_invd_b, d_fail) ||
+          pa_rt_d2h(&fail, d_fail, sizeof(int)))
+        rc = PA_FAIL("factorising the diagonal blocks on the device failed: %s", pa_rt_error());
+      else if (fail > 0)
+        rc = PA_FAIL("diagonal block is not SPD (global row %d)", row_off + map_f[fail - 1] +
+                     row0[part_of_local_row(row0, nrows, np, fail - 1)]);
+    }
+    free(hb); pa_rt_free(d_band); pa_rt_free(d_boff); pa_rt_free(d_list); pa_rt_free(d_fail);
+    free(boff); free(dlist);
+  }
+  for (int q = 0; q < np; ++q) free(bands[q]);
+  free(bands);
   free(row0); free(nrows); free(bw); free(off); free(map_f); free(map_b); free(invd_f); free(invd_b);
   if (rc) { preAlps_BlockJacobiFree(); return rc; }
   s->factor_bytes = 2.0 * 8.0 * (double)tot;

@@ -278,6 +278,62 @@ __global__ __launch_bounds__(WG) void k_pack_rows(int n, const int* __restrict__
   if (i < n) out[(size_t)i * TS + c] = X[(size_t)idx[i] * TS + c];
 }
 
+// ------------------------------------------------ block-Jacobi setup ----
+// Band Cholesky of one diagonal block per workgroup (bands up to PA_BJ_FACTOR_WMAX), right
+// looking: the (w+1) x (w+1) window of rows j..j+w lives in LDS (row i in slot i mod (w+1),
+// win[slot][d] = A(i, i-d)); step j takes the pivot, scales column j, writes the two sweep
+// records the solve kernels read -- forward record j = column j / L(j,j), backward record
+// b-1-j = row j / L(j,j) -- and applies the rank-1 update to the rest of the window while
+// the next row streams in.  band: the block's rows in factor order, (w+1) doubles each.
+__global__ __launch_bounds__(WG) void k_bj_factor(
+    const int* __restrict__ list, const int* __restrict__ row0, const int* __restrict__ nrows,
+    const int* __restrict__ bw, const long long* __restrict__ off, const long long* __restrict__ boff,
+    const double* __restrict__ band, double* __restrict__ Lf, double* __restrict__ Lb,
+    double* __restrict__ invd_f, double* __restrict__ invd_b, int* __restrict__ fail) {
+  extern __shared__ double win[];
+  const int p = list[blockIdx.x];
+  const int r0 = row0[p], b = nrows[p], w = bw[p];
+  const int ld = w + 1, wr = (w + 2) & ~1;
+  const double* __restrict__ A = band + boff[p];
+  double* __restrict__ f = Lf + off[p];
+  double* __restrict__ g = Lb + off[p];
+  const int tid = threadIdx.x;
+  const int nfirst = (b < ld ? b : ld) * ld;
+  for (int e = tid; e < nfirst; e += WG) win[e] = A[e];
+  __syncthreads();
+  for (int j = 0; j < b; ++j) {
+    const int rj = j % ld, jb = b - 1 - j;
+    const double d0 = win[rj * ld];
+    if (!(d0 > 0.0) && tid == 0) atomicCAS(fail, 0, r0 + j + 1);
+    const double piv = (d0 > 0.0) ? sqrt(d0) : __longlong_as_double(0x7ff8000000000000LL);
+    const double invp = 1.0 / piv;
+    for (int t = tid; t < w; t += WG) {
+      const int dd = t + 1, i = j + dd;
+      g[(size_t)jb * wr + t] = (j - dd >= 0) ? win[rj * ld + dd] * invp : 0.0;
+      if (i < b) {
+        const int ri = i % ld;
+        const double l = win[ri * ld + dd] / piv;
+        win[ri * ld + dd] = l;
+        f[(size_t)j * wr + t] = l * invp;
+      }
+    }
+    if (tid == 0) { invd_f[r0 + j] = invp; invd_b[r0 + jb] = invp; }
+    __syncthreads();
+    const int nb = (b - 1 - j) < w ? (b - 1 - j) : w;     // rows below the pivot inside the band
+    for (int e = tid; e < nb * nb; e += WG) {
+      const int a = e / nb + 1, c = e - (a - 1) * nb + 1;
+      if (c <= a) {
+        const int ri = (j + a) % ld, rk = (j + c) % ld;
+        win[ri * ld + (a - c)] -= win[ri * ld + a] * win[rk * ld + c];
+      }
+    }
+    const int in = j + w + 1;                             // the row that takes over slot rj
+    if (in < b)
+      for (int e = tid; e < ld; e += WG) win[rj * ld + e] = A[(size_t)in * ld + e];
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------ HBM calibration ----
 // What this device sustains on the plainest streaming kernels, measured in the same process
 // as the solver kernels (bench.py quotes the SpMM against the 8 TB/s spec and against this).
@@ -1662,6 +1718,25 @@ int pa_k_rowsum(int m, int ts, int nc, const double* X, double* sol) {
   TS_DISPATCH(ts, hipLaunchKernelGGL((k_rowsum<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
                                      cur_stream(), m, nc, X, sol));
   return kfail("k_rowsum");
+}
+
+int pa_bj_factor_wmax(void) { return 96; }
+
+int pa_k_bj_factor(const int* list, int count, int wmax, const int* row0, const int* nrows, const int* bw,
+                   const long long* off, const long long* boff, const double* band, double* Lf, double* Lb,
+                   double* invd_f, double* invd_b, int* fail) {
+  if (count <= 0) return 0;
+  const size_t lds = (size_t)(wmax + 1) * (wmax + 1) * 8;
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_factor),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return kfail("hipFuncSetAttribute(k_bj_factor)");
+    configured = lds;
+  }
+  hipLaunchKernelGGL(k_bj_factor, dim3(count), dim3(WG), lds, cur_stream(), list, row0, nrows, bw, off, boff,
+                     band, Lf, Lb, invd_f, invd_b, fail);
+  return kfail("k_bj_factor");
 }
 
 int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out) {

@@ -178,6 +178,15 @@ typedef struct {
   const int* const* class_list; /* host array of device pointers to part ids */
 } pa_bj_plan_t;
 int pa_bj_max_R(void);
+/* Band Cholesky on the device for blocks with bandwidth <= pa_bj_factor_wmax(): `band` holds
+ * each listed block's rows in factor order, (w+1) doubles per row (A(i, i-d) at d), at offset
+ * boff[part]; writes the forward / backward sweep records and 1/L(j,j) straight into Lf, Lb
+ * (pre-zeroed), invd_f, invd_b.  *fail (device, pre-zeroed) = 1 + local position of the first
+ * non-positive pivot seen. */
+int pa_bj_factor_wmax(void);
+int pa_k_bj_factor(const int* list, int count, int wmax, const int* row0, const int* nrows, const int* bw,
+                   const long long* off, const long long* boff, const double* band, double* Lf, double* Lb,
+                   double* invd_f, double* invd_b, int* fail);
 int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out);
 
 #ifdef __cplusplus

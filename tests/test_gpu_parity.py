@@ -356,8 +356,10 @@ def test_full_size_properties_of_the_headline_workload():
       block solve              blockdiag(A)^-1 (blockdiag(A) X) = X     (1e-8)
       SpMM linearity           A (aX + bY) = a AX + b AY                (1e-12)
       ECG                      the returned iterate satisfies ||b - A x|| <= 2 res, res <= tol ||b||,
-                               the residual history decreases to it, and the iteration count is the
-                               recorded one of this configuration (828 +- 3)."""
+                               the residual history decreases to it, and the iteration count stays in
+                               the band this configuration has shown (828 with the block factors
+                               computed on the host, 852 on the device: the stiff / soft inclusions
+                               make the late iterations sensitive to the factor's rounding)."""
     from oracle import oracle as O
     from prealps_amd import gen
     nn, t = 70, 4
@@ -385,10 +387,47 @@ def test_full_size_properties_of_the_headline_workload():
         rhs = prob.reference_rhs()
         np.testing.assert_array_equal(rhs, O.reference_rhs(rowpos))
         got = prob.solve(rhs, t, max_iter=2000)
-        assert abs(got.iters - 828) <= 3, got.iters
+        assert 800 <= got.iters <= 880, got.iters
         assert got.final_res <= 1e-5 * got.normb
         r = rhs - B @ got.x
         assert np.linalg.norm(r) <= 2.0001 * got.final_res
         assert got.res[-1] == got.final_res and got.res[0] > 1e3 * got.final_res
+    finally:
+        prob.close()
+
+
+def test_block_factorisation_on_device_matches_host(monkeypatch):
+    """Band Cholesky of the diagonal blocks on the device (k_bj_factor, bands up to 96) against the
+    host factorisation of the same blocks: the block solves agree to rounding, both invert
+    blockdiag(A), and an indefinite block is reported with its global row."""
+    import prealps_amd as pa
+    from oracle import oracle as O
+    from prealps_amd import gen
+    nn = 9
+    rp, ci, v = gen.elasticity3d_csr(nn)
+    part, nparts = gen.box_partition_nodes(nn, (3, 3, 3))
+    A = sp.csr_matrix((v, ci, rp), shape=(3 * nn ** 3, 3 * nn ** 3))
+    X = np.random.default_rng(12).standard_normal((A.shape[0], 4))
+    out = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("PREALPS_BJ_FACTOR", mode)
+        prob, B, rowpos = _problem(A, nparts, part)
+        try:
+            out[mode] = prob.block_jacobi_apply(X, 4)
+            assert 0 < prob.stat("bj_max_bandwidth") <= 96
+        finally:
+            prob.close()
+    zr = O.BlockJacobi(B, rowpos).apply(X)
+    for mode in out:
+        np.testing.assert_allclose(out[mode], zr, rtol=1e-8, atol=1e-9 * np.abs(zr).max())
+    np.testing.assert_allclose(out["device"], out["host"], rtol=1e-9, atol=1e-10 * np.abs(zr).max())
+    # an indefinite diagonal block
+    monkeypatch.setenv("PREALPS_BJ_FACTOR", "device")
+    Ab = sp.lil_matrix(O.poisson3d(8))
+    Ab[100, 100] = -5.0
+    prob, B, rowpos = _problem(sp.csr_matrix(Ab), 8)
+    try:
+        with pytest.raises(pa.PreAlpsError, match="not SPD"):
+            prob.create_block_jacobi()
     finally:
         prob.close()
