@@ -22,6 +22,7 @@
 #include <ctype.h>
 #include <math.h>
 #include <stdio.h>
+#include <sys/mman.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
@@ -66,6 +67,16 @@ static double g_setup_build_s, g_setup_plan_s;   /* host seconds: scale/permute/
 const pa_operator_info_t* pa_operator_info(void) { return g_op.info.built ? &g_op.info : NULL; }
 
 /* ------------------------------------------------------------------ utils */
+/* Large host arrays (hundreds of MB, written once): 2 MiB alignment + a transparent-huge-page
+ * hint, so that filling them is not dominated by 4 KiB page faults.  Release with free(). */
+static void* big_alloc(size_t bytes) {
+  void* p = NULL;
+  if (bytes < ((size_t)8 << 20)) return malloc(bytes ? bytes : 1);
+  if (posix_memalign(&p, (size_t)2 << 20, bytes)) return NULL;
+  (void)madvise(p, bytes, MADV_HUGEPAGE);
+  return p;
+}
+
 static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return (s && *s) ? atoi(s) : dflt;
@@ -448,6 +459,9 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     }
     if (bad_row >= 0) return PA_FAIL("Diagonal is not set correctly (row %d)", bad_row);
   }
+  double t_tr = pa_wtime(); const int tr = getenv("PREALPS_SETUP_TRACE") != NULL;
+#define TRACE(what) do { if (tr) { double n_ = pa_wtime(); fprintf(stderr, "[setup] %-28s %.3f s\n", what, n_ - t_tr); t_tr = n_; } } while (0)
+  TRACE("diagonal check");
   /* 1. SymRACScaling: d_i = 1/sqrt(max_j |a_ij|) */
   double* d = NULL;
   if (scale) {
@@ -462,6 +476,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     }
     if (zero_row) { free(d); return PA_FAIL("Impossible to scale the matrix, rcmin=0"); }
   }
+  TRACE("scaling");
   /* 2. ordering: rows grouped part by part, original order inside a part */
   in->N = N; in->nparts = nparts;
   in->rowPos = (int*)calloc(nparts + 1, sizeof(int));
@@ -486,6 +501,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     }
     free(fill);
   }
+  TRACE("ordering");
   /* 3. the row panel of this process */
   in->part0 = (int)((long long)rank * nparts / size);
   in->part1 = (int)((long long)(rank + 1) * nparts / size);
@@ -497,8 +513,8 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   if (lnnz > 2147483000u) { free(d); free(iperm); return PA_FAIL("local panel has too many nonzeros for int32 indices"); }
   CPLM_Mat_CSR_t* A = &in->A;
   A->rowPtr = (int*)malloc((size_t)(m + 1) * sizeof(int));
-  A->colInd = (int*)malloc((lnnz ? lnnz : 1) * sizeof(int));
-  A->val = (double*)malloc((lnnz ? lnnz : 1) * sizeof(double));
+  A->colInd = (int*)big_alloc((lnnz ? lnnz : 1) * sizeof(int));
+  A->val = (double*)big_alloc((lnnz ? lnnz : 1) * sizeof(double));
   A->rowPtr[0] = 0;
   {
     int maxlen = 0;
@@ -527,6 +543,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
       free(buf);
     }
   }
+  TRACE("permute + sort rows");
   free(d); free(iperm);
   A->info.M = N; A->info.N = N; A->info.nnz = rowPtr[N]; A->info.m = m; A->info.n = N;
   A->info.lnnz = (int)lnnz; A->info.blockSize = 1; A->info.format = FORMAT_CSR;
@@ -540,6 +557,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   int* halo_cols = (int*)malloc((halo ? halo : 1) * sizeof(int));
   { int q = 0; for (int c = 0; c < N; ++c) if (mark[c]) { halo_cols[q] = c; mark[c] = ++q; } }
   in->halo = halo;
+  TRACE("halo marks");
   /* peers and receive counts */
   o->peers = (int*)malloc((size > 0 ? size : 1) * sizeof(int));
   o->recv_rows = (int*)calloc(size, sizeof(int));
@@ -575,8 +593,9 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     free(touches);
   }
   free(recv_by_proc);
+  TRACE("peer lists");
   /* 5. device CSR with local column ids */
-  int* lcol = (int*)malloc((lnnz + 8) * sizeof(int));
+  int* lcol = (int*)big_alloc((lnnz + 8) * sizeof(int));
 #pragma omp parallel for schedule(static)
   for (long long k = 0; k < (long long)lnnz; ++k) { int c = A->colInd[k]; lcol[k] = (c >= lo && c < hi) ? c - lo : m + mark[c] - 1; }
   for (size_t k = lnnz; k < lnnz + 8; ++k) lcol[k] = 0;
@@ -584,6 +603,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   o->halo_cols = halo_cols;
   o->send_idx = send_idx;
   o->lcol = lcol;
+  TRACE("local columns");
   if (g_plan_only) { in->built = 1; return 0; }
   int rc = 0;
   if (o->nsend > 0) {
@@ -904,8 +924,8 @@ static int build_plan_runs(pa_operator_t* o, int ts) {
   size_t ext_cap = 1024, next_tot = 0;
   int* ext_rows = (int*)malloc(ext_cap * sizeof(int));
   size_t run_cap = (size_t)(plain / 3.0 * 1.1) + 4096, nruns = 0;   /* stored runs (64 per step of a slice) */
-  unsigned short* c16 = (unsigned short*)malloc(run_cap * sizeof(unsigned short));
-  double* sval = (double*)malloc(run_cap * 3 * sizeof(double));
+  unsigned short* c16 = (unsigned short*)big_alloc(run_cap * sizeof(unsigned short));
+  double* sval = (double*)big_alloc(run_cap * 3 * sizeof(double));
   int nblk = 0, q = 0, max_stage = 0, rc = 0, gen = 0;
   if (!c16 || !sval || !stamp || !slot_of || !ext_rows) rc = -1;
   sl_off[0] = 0;
