@@ -980,31 +980,35 @@ __device__ __forceinline__ void bj_load_step(const double* __restrict__ r, int l
 }
 
 // A full chunk of CH steps with the first NA register sets (counted from the pivots' own set)
-// inside the band: straight-line code, all CH*NA band values read from LDS up front, no branch
-// and no scalar bookkeeping per step.  (Sets beyond NA would only meet the zero slot.)
+// inside the band: straight-line code, the band values of four steps at a time read from LDS
+// up front, no branch and no scalar bookkeeping per step.  (Sets beyond NA would only meet the zero slot.)
 template <int TS, int R, int CH, int K, int NA>
 __device__ __forceinline__ void bj_chunk_fast(double (&acc)[R][TS], const double* cur, int lc, int w,
                                               int wr, int lane) {
-  double cf[CH][NA];
+  constexpr int G = 4;                              // steps whose band values are in registers at once
 #pragma unroll
-  for (int a = 0; a < NA; ++a) {
-    const int a0 = a * 64 + lane - lc - 1;          // d - 1 of step 0 for this set
-#pragma unroll
-    for (int s = 0; s < CH; ++s) {
-      const unsigned idx = min((unsigned)(a0 - s), (unsigned)w);
-      cf[s][a] = cur[s * wr + idx];
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < CH; ++s) {
-    double y[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) y[c] = readlane_f64(acc[K][c], lc + s);
+  for (int s0 = 0; s0 < CH; s0 += G) {
+    double cf[G][NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-      const int k2 = (K + a) % R;
+      const int a0 = a * 64 + lane - lc - s0 - 1;   // d - 1 of step s0 for this set
 #pragma unroll
-      for (int c = 0; c < TS; ++c) acc[k2][c] = fma(-cf[s][a], y[c], acc[k2][c]);
+      for (int s = 0; s < G; ++s) {
+        const unsigned idx = min((unsigned)(a0 - s), (unsigned)w);
+        cf[s][a] = cur[(s0 + s) * wr + idx];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      double y[TS];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) y[c] = readlane_f64(acc[K][c], lc + s0 + s);
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const int k2 = (K + a) % R;
+#pragma unroll
+        for (int c = 0; c < TS; ++c) acc[k2][c] = fma(-cf[s][a], y[c], acc[k2][c]);
+      }
     }
   }
 }
@@ -1019,7 +1023,7 @@ __device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chu
     const double* cur = (chunk & 1) ? lds1 : lds0;
     if ((chunk + 1) * CH < b) bj_issue_chunk<CH>(rec, wr, chunk + 1, (chunk & 1) ? lds0 : lds1, lane);
     const int send = (lim - lc) < CH ? (lim - lc) : CH;
-    if constexpr (R <= 3) {
+    if constexpr (R <= 3 && TS <= 4) {   // (wider panels would spill the CH x NA band values)
       if (send == CH) {
         // sets the last step of the chunk reaches (wave-uniform): rel is inside the band from
         // step l >= rel*64 - w on
@@ -1117,7 +1121,7 @@ __device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __r
 // XS = panel stride: XS = TS, or a multiple of it when the panel is split by columns among XS/TS
 // wavefronts (opt-in, see bj_launch).
 template <int TS, int R, int CH, int XS>
-__global__ void k_bj_apply(
+__global__ __launch_bounds__(256) void k_bj_apply(
     const int* __restrict__ list, int count, const int* __restrict__ row0,
     const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off,
     const int* __restrict__ map_f, const int* __restrict__ map_b, const double* __restrict__ Lf,
