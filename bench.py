@@ -169,12 +169,13 @@ def main():
     # counters cannot be read from inside the process, so the committed summary is quoted when
     # the workload is the one it was collected on.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_elasticity.json")
-    if world == 1 and (a.workload, a.n, a.t, a.box) == ("elasticity", 70, 4, "2,4,8") and os.path.exists(pmc):
-        with open(pmc) as f:
+    profiled = {("elasticity", 70, 4, "2,4,8"): "r01_pmc_hbm_traffic_elasticity.json",
+                ("poisson", 100, 4, "5,5,10"): "r01_pmc_hbm_traffic_poisson.json"}
+    pmc = profiled.get((a.workload, a.n, a.t, a.box))
+    if world == 1 and pmc and os.path.exists(os.path.join(ROOT, "profiles", pmc)):
+        with open(os.path.join(ROOT, "profiles", pmc)) as f:
             traffic = json.load(f)["k_spmm"]["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r01_pmc_hbm_traffic_elasticity.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
-
+        traffic_src = "profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)" % pmc
     out = {
         "metric": "ECG iters/sec + SpMM HBM GB/s (% roofline), 3D-elasticity n~1M t=4",
         "value": its, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -131,6 +131,8 @@ def bind_process_group(L, prefer=None):
     prefer = prefer or os.environ.get("PREALPS_COMM", "rccl")
     rank, size = dist.get_rank(), dist.get_world_size()
     if prefer == "rccl" and dist.get_backend() == "nccl":
+        import torch
+        ok = 1
         try:
             buf = C.create_string_buffer(128)
             if rank == 0:
@@ -139,9 +141,16 @@ def bind_process_group(L, prefer=None):
             dist.broadcast_object_list(box, src=0)
             check(L.preAlps_hip_rccl_init(box[0], rank, size), "preAlps_hip_rccl_init")
             check(L.preAlps_hip_comm_selftest(), "preAlps_hip_comm_selftest")
-            return "rccl", None
         except Exception as e:
-            print("[prealps_amd] native RCCL hooks unavailable (%s); using torch.distributed" % e)
+            ok = 0
+            print("[prealps_amd] native RCCL hooks unavailable on rank %d (%s)" % (rank, e))
+        # every rank must end up on the same binding: one failure sends all of them to the fallback
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return "rccl", None
+        if rank == 0:
+            print("[prealps_amd] using the torch.distributed hooks on all ranks")
     hooks = DistributedHooks(L)
     check(L.preAlps_hip_comm_selftest(), "preAlps_hip_comm_selftest")
     return "torch." + dist.get_backend(), hooks
