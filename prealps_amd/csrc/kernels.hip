@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chu
     const double* cur = (chunk & 1) ? lds1 : lds0;
     if ((chunk + 1) * CH < b) bj_issue_chunk<CH>(rec, wr, chunk + 1, (chunk & 1) ? lds0 : lds1, lane);
     const int send = (lim - lc) < CH ? (lim - lc) : CH;
-    if constexpr (R <= 3 && TS <= 4) {   // (wider panels would spill the CH x NA band values)
+    if constexpr (R <= 3 && TS <= 4) {   // (no gain measured at 8 columns; 16 would spill)
       if (send == CH) {
         // sets the last step of the chunk reaches (wave-uniform): rel is inside the band from
         // step l >= rel*64 - w on
