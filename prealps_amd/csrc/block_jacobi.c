@@ -155,6 +155,9 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   double* invd_f = (double*)malloc((size_t)(m ? m : 1) * sizeof(double));
   double* invd_b = (double*)malloc((size_t)(m ? m : 1) * sizeof(double));
   double** bands = (double**)calloc(np, sizeof(double*));
+  long long** coo_off = (long long**)calloc(np, sizeof(long long*));   /* wide blocks, device path */
+  double** coo_val = (double**)calloc(np, sizeof(double*));
+  size_t* coo_n = (size_t*)calloc(np, sizeof(size_t));
   int fail_row = -1;
   for (int q = 0; q < np; ++q) { row0[q] = rowPos[op->part0 + q] - row_off; nrows[q] = rowPos[op->part0 + q + 1] - rowPos[op->part0 + q]; }
 
@@ -194,20 +197,47 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
      * axis slowest) can have the narrower band -- keep whichever is narrower */
     if (wnat <= w) { w = wnat; for (int i = 0; i < b; ++i) { order[i] = i; pos[i] = i; } }
     bw[q] = w;
-    /* band[i*(w+1) + d] = A(new i, new i-d) */
-    double* band = (double*)calloc((size_t)b * (w + 1), sizeof(double));
-    for (int i = 0; i < b; ++i) {
-      int ni = pos[i];
-      for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) {
-        int c = A->colInd[k];
-        if (c < g0 || c >= g1) continue;
-        int nj = pos[c - g0];
-        if (nj <= ni) band[(size_t)ni * (w + 1) + (ni - nj)] = A->val[k];
+    /* band[i*(w+1) + d] = A(new i, new i-d); blocks that go to the blocked device
+     * factorisation (k_bj_factor_big) are assembled diagonal-major instead: band[d*b + i] */
+    int big_dev = dev_factor && w > dev_wmax;
+    double* band = NULL;
+    if (big_dev) {
+      /* only the entries travel: (offset in the block's diagonal-major band, value) */
+      size_t cnt = 0;
+      for (int i = 0; i < b; ++i)
+        for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) {
+          int c = A->colInd[k];
+          if (c >= g0 && c < g1 && pos[c - g0] <= pos[i]) ++cnt;
+        }
+      long long* co = (long long*)malloc((cnt ? cnt : 1) * sizeof(long long));
+      double* cv = (double*)malloc((cnt ? cnt : 1) * sizeof(double));
+      cnt = 0;
+      for (int i = 0; i < b; ++i) {
+        int ni = pos[i];
+        for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) {
+          int c = A->colInd[k];
+          if (c < g0 || c >= g1) continue;
+          int nj = pos[c - g0];
+          if (nj > ni) continue;
+          co[cnt] = (long long)(ni - nj) * b + ni; cv[cnt] = A->val[k]; ++cnt;
+        }
+      }
+      coo_off[q] = co; coo_val[q] = cv; coo_n[q] = cnt;
+    } else {
+      band = (double*)calloc((size_t)b * (w + 1), sizeof(double));
+      for (int i = 0; i < b; ++i) {
+        int ni = pos[i];
+        for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) {
+          int c = A->colInd[k];
+          if (c < g0 || c >= g1) continue;
+          int nj = pos[c - g0];
+          if (nj <= ni) band[(size_t)ni * (w + 1) + (ni - nj)] = A->val[k];
+        }
       }
     }
     size_t ld = (size_t)w + 1;
-    /* narrow bands are factored on the device (k_bj_factor); wider ones here */
-    for (int i = 0; i < b && !(dev_factor && w <= dev_wmax); ++i) {
+    /* the device factors every band (k_bj_factor / k_bj_factor_big) unless PREALPS_BJ_FACTOR=host */
+    for (int i = 0; i < b && !dev_factor; ++i) {
       double* Li = band + (size_t)i * ld; /* Li[d] = L(i, i-d) */
       int jlo = i - w > 0 ? i - w : 0;
       for (int j = jlo; j < i; ++j) {
@@ -269,7 +299,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       rc = PA_FAIL("allocating %zu factor entries on the device failed: %s", tot, pa_rt_error());
   }
   int ndev = 0;
-  for (int q = 0; q < np; ++q) if (dev_factor && bw[q] <= dev_wmax) ++ndev;
+  for (int q = 0; q < np; ++q) if (dev_factor) ++ndev;
   if (!rc && ndev < np) {
     /* host-factored blocks: runs of consecutive blocks (up to 64 MiB of records) are laid out
      * by the host threads into a staging buffer (256 MiB, or one block if larger) and go to
@@ -279,9 +309,9 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     double* sf = NULL; double* sg = NULL;
     int q = 0;
     while (q < np && !rc) {
-      if (dev_factor && bw[q] <= dev_wmax) { ++q; continue; }
+      if (dev_factor) { ++q; continue; }
       int q1 = q;
-      while (q1 < np && !(dev_factor && bw[q1] <= dev_wmax) && (q1 == q || (size_t)(off[q1 + 1] - off[q]) <= cap)) ++q1;
+      while (q1 < np && !dev_factor && (q1 == q || (size_t)(off[q1 + 1] - off[q]) <= cap)) ++q1;
       size_t len = (size_t)(off[q1] - off[q]);
       if (len > sf_cap) {
         sf_cap = len;
@@ -377,44 +407,91 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     if (bad) rc = PA_FAIL("uploading the block factors failed: %s", pa_rt_error());
   }
   if (!rc && ndev > 0) {
-    /* narrow blocks: ship the assembled bands, factor and lay out on the device */
+    /* ship the assembled bands, factor and lay out on the device: bands up to dev_wmax with
+     * the LDS-window kernel (row-major band), wider ones with the blocked kernel
+     * (diagonal-major band, factored in place) */
     long long* boff = (long long*)malloc((np + 1) * sizeof(long long));
-    int* dlist = (int*)malloc(ndev * sizeof(int));
+    int* slist = (int*)malloc(np * sizeof(int));
+    int* blist = (int*)malloc(np * sizeof(int));
     size_t btot = 0;
-    int nd = 0, wdev = 0;
+    int ns = 0, nbig = 0, wsmall = 0, wbig = 0;
     for (int q = 0; q < np; ++q) {
       boff[q] = (long long)btot;
-      if (bw[q] <= dev_wmax) { dlist[nd++] = q; btot += (size_t)nrows[q] * (bw[q] + 1); if (bw[q] > wdev) wdev = bw[q]; }
+      btot += (size_t)nrows[q] * (bw[q] + 1);
+      if (bw[q] <= dev_wmax) { slist[ns++] = q; if (bw[q] > wsmall) wsmall = bw[q]; }
+      else { blist[nbig++] = q; if (bw[q] > wbig) wbig = bw[q]; }
     }
     boff[np] = (long long)btot;
-    double* hb = (double*)malloc((btot ? btot : 1) * sizeof(double));   /* one upload instead of one per block */
     double* d_band = (double*)pa_rt_malloc((btot ? btot : 1) * sizeof(double));
     long long* d_boff = (long long*)pa_rt_malloc((np + 1) * sizeof(long long));
-    int* d_list = (int*)pa_rt_malloc(ndev * sizeof(int));
+    int* d_slist = (int*)pa_rt_malloc((ns ? ns : 1) * sizeof(int));
+    int* d_blist = (int*)pa_rt_malloc((nbig ? nbig : 1) * sizeof(int));
     int* d_fail = (int*)pa_rt_malloc(sizeof(int));
     int fail = 0;
-    if (!hb || !d_band || !d_boff || !d_list || !d_fail) rc = PA_FAIL("allocating the band staging failed: %s", pa_rt_error());
-    if (!rc) {
+    if (!d_band || !d_boff || !d_slist || !d_blist || !d_fail)
+      rc = PA_FAIL("allocating %zu band entries on the device failed: %s", btot, pa_rt_error());
+    const int tr = getenv("PREALPS_SETUP_TRACE") != NULL;
+    double t_tr = pa_wtime();
+    const size_t cap = (size_t)32 << 20;
+    double* hb = NULL;
+    size_t hb_cap = 0;
+    /* narrow bands: runs of consecutive blocks go up in one copy of at most 256 MiB; wide
+     * bands: zero on the device, then only their entries are shipped and scattered */
+    if (!rc && nbig > 0 && pa_rt_memset(d_band, 0, btot * sizeof(double))) rc = PA_FAIL("%s", pa_rt_error());
+    for (int q = 0; q < np && !rc; ) {
+      if (!bands[q]) { ++q; continue; }
+      int q1 = q + 1;
+      while (q1 < np && bands[q1] && (size_t)(boff[q1 + 1] - boff[q]) <= cap) ++q1;
+      size_t len = (size_t)(boff[q1] - boff[q]);
+      if (len > hb_cap) { hb_cap = len; hb = (double*)realloc(hb, hb_cap * sizeof(double)); }
+      if (!hb) { rc = PA_FAIL("out of host memory for %zu band entries", len); break; }
 #pragma omp parallel for schedule(dynamic, 16)
-      for (int x = 0; x < nd; ++x) {
-        int q = dlist[x];
-        memcpy(hb + boff[q], bands[q], (size_t)nrows[q] * (bw[q] + 1) * sizeof(double));
+      for (int x = q; x < q1; ++x)
+        memcpy(hb + (boff[x] - boff[q]), bands[x], (size_t)nrows[x] * (bw[x] + 1) * sizeof(double));
+      if (pa_rt_h2d(d_band + boff[q], hb, len * sizeof(double))) rc = PA_FAIL("uploading the bands failed: %s", pa_rt_error());
+      for (int x = q; x < q1; ++x) { free(bands[x]); bands[x] = NULL; }
+      q = q1;
+    }
+    if (!rc && nbig > 0) {
+      size_t ntot = 0;
+      size_t* cbase = (size_t*)malloc((np + 1) * sizeof(size_t));
+      for (int q = 0; q < np; ++q) { cbase[q] = ntot; ntot += coo_n[q]; }
+      long long* go = (long long*)malloc((ntot ? ntot : 1) * sizeof(long long));
+      double* gv = (double*)malloc((ntot ? ntot : 1) * sizeof(double));
+      long long* d_go = (long long*)pa_rt_malloc((ntot ? ntot : 1) * sizeof(long long));
+      double* d_gv = (double*)pa_rt_malloc((ntot ? ntot : 1) * sizeof(double));
+      if (!go || !gv || !d_go || !d_gv) rc = PA_FAIL("out of memory for %zu band entries", ntot);
+      if (!rc) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int q = 0; q < np; ++q)
+          for (size_t e = 0; e < coo_n[q]; ++e) { go[cbase[q] + e] = boff[q] + coo_off[q][e]; gv[cbase[q] + e] = coo_val[q][e]; }
+        if (pa_rt_h2d(d_go, go, ntot * sizeof(long long)) || pa_rt_h2d(d_gv, gv, ntot * sizeof(double)) ||
+            pa_k_scatter(ntot, d_go, d_gv, d_band) || pa_rt_sync())
+          rc = PA_FAIL("assembling the wide bands on the device failed: %s", pa_rt_error());
       }
-      if (pa_rt_h2d(d_band, hb, btot * sizeof(double)) || pa_rt_h2d(d_boff, boff, (np + 1) * sizeof(long long)) ||
-          pa_rt_h2d(d_list, dlist, ndev * sizeof(int)) || pa_rt_h2d(d_fail, &fail, sizeof(int)) ||
-          pa_k_bj_factor(d_list, ndev, wdev, s->d_row0, s->d_nrows, s->d_bw, s->d_off, d_boff, d_band, s->d_Lf,
+      pa_rt_free(d_go); pa_rt_free(d_gv); free(go); free(gv); free(cbase);
+    }
+    free(hb);
+    if (tr) { fprintf(stderr, "[setup] band upload (%.1f GB)        %.3f s\n", 8e-9 * (double)btot, pa_wtime() - t_tr); t_tr = pa_wtime(); }
+    if (!rc) {
+      if (pa_rt_h2d(d_boff, boff, (np + 1) * sizeof(long long)) || pa_rt_h2d(d_slist, slist, ns * sizeof(int)) ||
+          pa_rt_h2d(d_blist, blist, nbig * sizeof(int)) || pa_rt_h2d(d_fail, &fail, sizeof(int)) ||
+          pa_k_bj_factor(d_slist, ns, wsmall, s->d_row0, s->d_nrows, s->d_bw, s->d_off, d_boff, d_band, s->d_Lf,
                          s->d_Lb, s->d_invd_f, s->d_invd_b, d_fail) ||
+          pa_k_bj_factor_big(d_blist, nbig, wbig, s->d_row0, s->d_nrows, s->d_bw, s->d_off, d_boff, d_band,
+                             s->d_Lf, s->d_Lb, s->d_invd_f, s->d_invd_b, d_fail) ||
           pa_rt_d2h(&fail, d_fail, sizeof(int)))
         rc = PA_FAIL("factorising the diagonal blocks on the device failed: %s", pa_rt_error());
       else if (fail > 0)
         rc = PA_FAIL("diagonal block is not SPD (global row %d)", row_off + map_f[fail - 1] +
                      row0[part_of_local_row(row0, nrows, np, fail - 1)]);
     }
-    free(hb); pa_rt_free(d_band); pa_rt_free(d_boff); pa_rt_free(d_list); pa_rt_free(d_fail);
-    free(boff); free(dlist);
+    if (tr) fprintf(stderr, "[setup] device factorisation + layout  %.3f s\n", pa_wtime() - t_tr);
+    pa_rt_free(d_band); pa_rt_free(d_boff); pa_rt_free(d_slist); pa_rt_free(d_blist); pa_rt_free(d_fail);
+    free(boff); free(slist); free(blist);
   }
-  for (int q = 0; q < np; ++q) free(bands[q]);
-  free(bands);
+  for (int q = 0; q < np; ++q) { free(bands[q]); free(coo_off[q]); free(coo_val[q]); }   /* (NULL where already released) */
+  free(bands); free(coo_off); free(coo_val); free(coo_n);
   free(row0); free(nrows); free(bw); free(off); free(map_f); free(map_b); free(invd_f); free(invd_b);
   if (rc) { preAlps_BlockJacobiFree(); return rc; }
   s->factor_bytes = 2.0 * 8.0 * (double)tot;

@@ -278,6 +278,16 @@ __global__ __launch_bounds__(WG) void k_pack_rows(int n, const int* __restrict__
   if (i < n) out[(size_t)i * TS + c] = X[(size_t)idx[i] * TS + c];
 }
 
+// Window (rows in flight = record length) of a wide block and the register sets per lane it
+// needs: the same rule as block_jacobi.c (bj_wide_window).
+__host__ __device__ inline int bjw_window(int w) {
+  int W = (w + 64 + 63) & ~63;
+  if (W <= 1024) return W;
+  W = (w + 64 + 127) & ~127;
+  if (W <= 2048) return W;
+  return (w + 64 + 255) & ~255;
+}
+
 // ------------------------------------------------ block-Jacobi setup ----
 // Band Cholesky of one diagonal block per workgroup (bands up to PA_BJ_FACTOR_WMAX), right
 // looking: the (w+1) x (w+1) window of rows j..j+w lives in LDS (row i in slot i mod (w+1),
@@ -331,6 +341,138 @@ __global__ __launch_bounds__(WG) void k_bj_factor(
     if (in < b)
       for (int e = tid; e < ld; e += WG) win[rj * ld + e] = A[(size_t)in * ld + e];
     __syncthreads();
+  }
+}
+
+// The same factorisation for wider bands (up to 4032), blocked by NB columns, one workgroup of
+// 1024 threads per block.  The band is stored diagonal-major (A(i, i-d) at band[d*b + i]) so
+// that a wavefront working on one diagonal touches consecutive addresses.  Per block column:
+// the NB x NB diagonal block is factored by one thread in LDS; one thread per row solves the
+// panel rows against it and leaves them in LDS (w x NB doubles: NB = 16 / 8 / 4 for bands up
+// to 1024 / 2048 / 4096); then the trailing window is updated diagonal by diagonal, the
+// diagonals dealt out to the wavefronts: A(i, i-d) -= panel[i] . panel[i-d].
+template <int NB>
+__global__ __launch_bounds__(1024) void k_bj_factor_big(
+    const int* __restrict__ list, const int* __restrict__ row0, const int* __restrict__ nrows,
+    const int* __restrict__ bw, const long long* __restrict__ boff, double* __restrict__ band,
+    int* __restrict__ fail) {
+  extern __shared__ double sm[];
+  const int p = list[blockIdx.x];
+  const int b = nrows[p], w = bw[p];
+  double* __restrict__ A = band + boff[p];
+  double* panel = sm;                        // [row][NB]
+  double* D = sm + (size_t)w * NB;           // [NB][NB], lower triangle of the diagonal block
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  for (int J = 0; J < b; J += NB) {
+    const int nbk = (b - J) < NB ? (b - J) : NB;
+    for (int e = tid; e < NB * NB; e += nt) {
+      const int r = e / NB, c = e % NB;
+      D[e] = (r < nbk && c <= r) ? A[(size_t)(r - c) * b + J + r] : (r == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int c = 0; c < nbk; ++c) {
+        double d = D[c * NB + c];
+        for (int k = 0; k < c; ++k) d -= D[c * NB + k] * D[c * NB + k];
+        if (!(d > 0.0)) { atomicCAS(fail, 0, row0[p] + J + c + 1); d = __longlong_as_double(0x7ff8000000000000LL); }
+        const double piv = sqrt(d);
+        D[c * NB + c] = piv;
+        for (int r = c + 1; r < nbk; ++r) {
+          double v = D[r * NB + c];
+          for (int k = 0; k < c; ++k) v -= D[r * NB + k] * D[c * NB + k];
+          D[r * NB + c] = v / piv;
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < nbk * NB; e += nt) {
+      const int r = e / NB, c = e % NB;
+      if (c <= r) A[(size_t)(r - c) * b + J + r] = D[e];
+    }
+    // panel: rows below the diagonal block that reach into these columns
+    const int i0 = J + nbk;
+    const int last = (J + nbk + w) < b ? (J + nbk + w) : b;
+    const int np_ = last - i0;
+    for (int ip = tid; ip < np_; ip += nt) {
+      const int i = i0 + ip;
+      double x[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        const int dd = i - (J + c);
+        x[c] = (c < nbk && dd <= w) ? A[(size_t)dd * b + i] : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        if (c < nbk) {
+          double v = x[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) v -= x[k] * D[c * NB + k];
+          x[c] = v / D[c * NB + c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        const int dd = i - (J + c);
+        panel[(size_t)ip * NB + c] = x[c];
+        if (c < nbk && dd <= w) A[(size_t)dd * b + i] = x[c];
+      }
+    }
+    __syncthreads();
+    // trailing update of the window, diagonal by diagonal
+    for (int ipb = 0; ipb < np_; ipb += 64) {
+      const int ip = ipb + lane;
+      const bool valid = ip < np_;
+      double pr[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) pr[c] = valid ? panel[(size_t)ip * NB + c] : 0.0;
+      const int dtop = (ipb + 63) < w ? (ipb + 63) : w;
+      for (int d = wave; d <= dtop; d += nw) {
+        if (valid && d <= ip) {
+          const double* q = panel + (size_t)(ip - d) * NB;
+          double sum = 0.0;
+#pragma unroll
+          for (int c = 0; c < NB; ++c) sum = fma(pr[c], q[c], sum);
+          A[(size_t)d * b + i0 + ip] -= sum;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// band[off[e]] = val[e]: assembly of the wide bands from the block's lower-triangle entries
+// (shipping the mostly empty band itself would cost gigabytes over PCIe)
+__global__ __launch_bounds__(WG) void k_scatter(size_t n, const long long* __restrict__ off,
+                                               const double* __restrict__ val, double* __restrict__ dst) {
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t e = (size_t)blockIdx.x * WG + threadIdx.x; e < n; e += stride) dst[off[e]] = val[e];
+}
+
+// Sweep records and 1/L(j,j) from a factored diagonal-major band: forward record j = column j
+// of L over L(j,j), backward record j = row b-1-j over its diagonal; `wide` records are in
+// window-slot order (k_bj_wide), the others [d = 1..w | 0] (k_bj_apply).
+__global__ __launch_bounds__(WG) void k_bj_layout_big(
+    const int* __restrict__ list, const int* __restrict__ row0, const int* __restrict__ nrows,
+    const int* __restrict__ bw, const long long* __restrict__ off, const long long* __restrict__ boff,
+    const double* __restrict__ band, int wide_from, double* __restrict__ Lf, double* __restrict__ Lb,
+    double* __restrict__ invd_f, double* __restrict__ invd_b) {
+  const int p = list[blockIdx.y];
+  const int b = nrows[p], w = bw[p], r0 = row0[p];
+  const double* __restrict__ A = band + boff[p];
+  const bool wide = w > wide_from;
+  const size_t reclen = wide ? (size_t)bjw_window(w) : (size_t)((w + 2) & ~1);
+  double* __restrict__ f = Lf + off[p];
+  double* __restrict__ g = Lb + off[p];
+  for (int j = blockIdx.x; j < b; j += gridDim.x) {
+    const int jr = b - 1 - j;
+    const double idf = 1.0 / A[j], idb = 1.0 / A[jr];
+    if (threadIdx.x == 0) { invd_f[r0 + j] = idf; invd_b[r0 + j] = idb; }
+    for (int dd = 1 + threadIdx.x; dd <= w; dd += WG) {
+      const size_t slot = wide ? (size_t)(j + dd) % reclen : (size_t)(dd - 1);
+      if (j + dd < b) f[(size_t)j * reclen + slot] = A[(size_t)dd * b + j + dd] * idf;
+      if (jr - dd >= 0) g[(size_t)j * reclen + slot] = A[(size_t)dd * b + jr] * idb;
+    }
   }
 }
 
@@ -1159,16 +1301,6 @@ __global__ __launch_bounds__(256) void k_bj_apply(
 // its rows.  Records are stored in window-slot order -- the value for target row i sits at
 // column i mod W -- so a lane reads the same column of every record: no index arithmetic,
 // coalesced, and prefetched D steps ahead in registers.
-// Window (rows in flight = record length) of a wide block and the register sets per lane it
-// needs: the same rule as block_jacobi.c (bj_wide_window).
-__host__ __device__ inline int bjw_window(int w) {
-  int W = (w + 64 + 63) & ~63;
-  if (W <= 1024) return W;
-  W = (w + 64 + 127) & ~127;
-  if (W <= 2048) return W;
-  return (w + 64 + 255) & ~255;
-}
-
 // The sweep is blocked by 64 pivots.  Phase A: the wave that holds the block's rows
 // eliminates them among themselves (in-wave, v_readlane; its 64 x 64 coefficients were
 // brought into LDS by LDS-DMA during the previous block) and publishes the 64 solved rows in
@@ -1547,6 +1679,22 @@ static int bj_wide_dispatch(const pa_bj_plan_t* pl, int ts, int wmax, const int*
   }
 }
 
+template <int NB>
+static int bj_factor_big_launch(const int* list, int count, int wmax, const int* row0, const int* nrows,
+                                const int* bw, const long long* boff, double* band, int* fail) {
+  const size_t lds = ((size_t)wmax * NB + NB * NB) * 8;
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_factor_big<NB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return kfail("hipFuncSetAttribute(k_bj_factor_big)");
+    configured = lds;
+  }
+  hipLaunchKernelGGL((k_bj_factor_big<NB>), dim3(count), dim3(1024), lds, cur_stream(), list, row0, nrows, bw,
+                     boff, band, fail);
+  return kfail("k_bj_factor_big");
+}
+
 extern "C" {
 
 int pa_bj_max_R(void) { return 8; }
@@ -1741,6 +1889,28 @@ int pa_k_bj_factor(const int* list, int count, int wmax, const int* row0, const 
   hipLaunchKernelGGL(k_bj_factor, dim3(count), dim3(WG), lds, cur_stream(), list, row0, nrows, bw, off, boff,
                      band, Lf, Lb, invd_f, invd_b, fail);
   return kfail("k_bj_factor");
+}
+
+int pa_k_scatter(size_t n, const long long* off, const double* val, double* dst) {
+  if (n == 0) return 0;
+  size_t blocks = (n + WG - 1) / WG;
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(k_scatter, dim3((unsigned)blocks), dim3(WG), 0, cur_stream(), n, off, val, dst);
+  return kfail("k_scatter");
+}
+
+int pa_k_bj_factor_big(const int* list, int count, int wmax, const int* row0, const int* nrows, const int* bw,
+                       const long long* off, const long long* boff, double* band, double* Lf, double* Lb,
+                       double* invd_f, double* invd_b, int* fail) {
+  if (count <= 0) return 0;
+  int rc;
+  if (wmax <= 1024) rc = bj_factor_big_launch<16>(list, count, wmax, row0, nrows, bw, boff, band, fail);
+  else if (wmax <= 2048) rc = bj_factor_big_launch<8>(list, count, wmax, row0, nrows, bw, boff, band, fail);
+  else rc = bj_factor_big_launch<4>(list, count, wmax, row0, nrows, bw, boff, band, fail);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bj_layout_big, dim3(512, count), dim3(WG), 0, cur_stream(), list, row0, nrows, bw, off,
+                     boff, band, 64 * pa_bj_max_R() - 64, Lf, Lb, invd_f, invd_b);
+  return kfail("k_bj_layout_big");
 }
 
 int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out) {

@@ -184,6 +184,13 @@ int pa_bj_max_R(void);
  * (pre-zeroed), invd_f, invd_b.  *fail (device, pre-zeroed) = 1 + local position of the first
  * non-positive pivot seen. */
 int pa_bj_factor_wmax(void);
+/* dst[off[e]] = val[e], e < n */
+int pa_k_scatter(size_t n, const long long* off, const double* val, double* dst);
+/* Wider bands (up to 4032): `band` diagonal-major per block (A(i, i-d) at boff + d*nrows + i),
+ * factored in place (blocked, one workgroup per block), then laid out into Lf / Lb / invd. */
+int pa_k_bj_factor_big(const int* list, int count, int wmax, const int* row0, const int* nrows, const int* bw,
+                       const long long* off, const long long* boff, double* band, double* Lf, double* Lb,
+                       double* invd_f, double* invd_b, int* fail);
 int pa_k_bj_factor(const int* list, int count, int wmax, const int* row0, const int* nrows, const int* bw,
                    const long long* off, const long long* boff, const double* band, double* Lf, double* Lb,
                    double* invd_f, double* invd_b, int* fail);

@@ -396,17 +396,26 @@ def test_full_size_properties_of_the_headline_workload():
         prob.close()
 
 
-def test_block_factorisation_on_device_matches_host(monkeypatch):
-    """Band Cholesky of the diagonal blocks on the device (k_bj_factor, bands up to 96) against the
-    host factorisation of the same blocks: the block solves agree to rounding, both invert
-    blockdiag(A), and an indefinite block is reported with its global row."""
-    import prealps_amd as pa
+@pytest.mark.parametrize("case", ["small", "mid", "wide"])
+def test_block_factorisation_on_device_matches_host(case, monkeypatch):
+    """Band Cholesky of the diagonal blocks on the device -- k_bj_factor (bands up to 96, LDS
+    window) and k_bj_factor_big (wider, blocked, diagonal-major band) -- against the host
+    factorisation of the same blocks: the block solves agree to rounding and both invert
+    blockdiag(A)."""
     from oracle import oracle as O
     from prealps_amd import gen
-    nn = 9
-    rp, ci, v = gen.elasticity3d_csr(nn)
-    part, nparts = gen.box_partition_nodes(nn, (3, 3, 3))
-    A = sp.csr_matrix((v, ci, rp), shape=(3 * nn ** 3, 3 * nn ** 3))
+    if case == "small":
+        nn = 9
+        rp, ci, v = gen.elasticity3d_csr(nn)
+        part, nparts = gen.box_partition_nodes(nn, (3, 3, 3))
+        A = sp.csr_matrix((v, ci, rp), shape=(3 * nn ** 3, 3 * nn ** 3))
+        lo, hi = 1, 96
+    elif case == "mid":
+        A, nparts, part = O.poisson3d(16), 2, None      # slabs of 8 x 16 x 16: band ~130
+        lo, hi = 97, 448
+    else:
+        A, nparts, part = O.poisson3d(32), 2, None      # slabs of 16 x 32 x 32: band > 448
+        lo, hi = 449, 4032
     X = np.random.default_rng(12).standard_normal((A.shape[0], 4))
     out = {}
     for mode in ("device", "host"):
@@ -414,18 +423,25 @@ def test_block_factorisation_on_device_matches_host(monkeypatch):
         prob, B, rowpos = _problem(A, nparts, part)
         try:
             out[mode] = prob.block_jacobi_apply(X, 4)
-            assert 0 < prob.stat("bj_max_bandwidth") <= 96
+            assert lo <= prob.stat("bj_max_bandwidth") <= hi
         finally:
             prob.close()
     zr = O.BlockJacobi(B, rowpos).apply(X)
     for mode in out:
         np.testing.assert_allclose(out[mode], zr, rtol=1e-8, atol=1e-9 * np.abs(zr).max())
     np.testing.assert_allclose(out["device"], out["host"], rtol=1e-9, atol=1e-10 * np.abs(zr).max())
-    # an indefinite diagonal block
+
+
+@pytest.mark.parametrize("n,P", [(8, 8), (16, 2)])
+def test_indefinite_diagonal_block_is_reported(n, P, monkeypatch):
+    """A non-positive pivot in either device factorisation kernel surfaces as the reference's
+    "not SPD" failure."""
+    import prealps_amd as pa
+    from oracle import oracle as O
     monkeypatch.setenv("PREALPS_BJ_FACTOR", "device")
-    Ab = sp.lil_matrix(O.poisson3d(8))
+    Ab = sp.lil_matrix(O.poisson3d(n))
     Ab[100, 100] = -5.0
-    prob, B, rowpos = _problem(sp.csr_matrix(Ab), 8)
+    prob, B, rowpos = _problem(sp.csr_matrix(Ab), P)
     try:
         with pytest.raises(pa.PreAlpsError, match="not SPD"):
             prob.create_block_jacobi()
