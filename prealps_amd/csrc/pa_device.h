@@ -161,17 +161,16 @@ typedef struct {
   const long long* off;    /* nparts: offset (doubles, even) of the block in Lf / Lb */
   const int* map_f;        /* local row visited at forward step j (m entries) */
   const int* map_b;        /* local row visited at backward step j */
-  /* One record of wr = (w+5)&~1 doubles per step, [1/L(j,j) | row id | 0 | band | 0]:
-   * forward  Lf[off + j*wr + 2 + d] = L(j+d, j),            d = 1..w
-   * backward Lb[off + j*wr + 2 + d] = L(b-1-j, b-1-j-d);  the row id (local row
-   * visited at the step, as an int in the low word) rides along so a step
-   * needs nothing but its record.  Arrays are padded by 2 KiB at the end. */
+  /* Narrow bands: one record of wr = (w+1 rounded up to even) doubles per step:
+   * forward  Lf[off + j*wr + d-1] = L(j+d, j) / L(j,j),                 d = 1..w, then a zero
+   * backward Lb[off + j*wr + d-1] = L(b-1-j, b-1-j-d) / L(b-1-j, b-1-j).
+   * Wide bands: records of W = bjw_window(w) doubles, the value for target row i at i mod W.
+   * Arrays are padded by 2 KiB at the end. */
   const double* Lf;
   const double* Lb;
   const double* invd_f;    /* 1 / L(j,j) in forward step order (m entries) */
   const double* invd_b;    /* ... in backward step order */
-  int nclass;              /* parts grouped by register sets R = ceil((w+64)/64); R = 0: wide band,
-                              one workgroup per part, records of roundup(w+64, 256) doubles in slot order */
+  int nclass;              /* parts grouped by register sets R = ceil((w+64)/64) of the one-wavefront kernel */
   const int* class_R;      /* host array, nclass: register sets per lane; < 0: wide class (workgroup per block) */
   const int* class_count;  /* host array */
   const int* class_wmax;   /* host array: widest band in the class (sizes the LDS chunks) */
