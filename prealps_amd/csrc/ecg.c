@@ -51,6 +51,8 @@ typedef struct {
   int rotate;         /* NO_BS_RED: rotate pointers instead of copying */
   void* ev_res;       /* recorded after the residual norm has been copied to the host */
   int fuse;           /* NO_BS_RED: two-pass first half (PREALPS_ECG_FUSE=0 keeps the four-pass one) */
+  int lazy_stop;      /* several processes: the residual norm rides on the beta all-reduce (see below) */
+  double* lazy_ptr;   /* where the first half left [res2, potrf status] for that */
 } ecg_priv_t;
 
 static ecg_priv_t* priv_of(preAlps_ECG_t* ecg) {
@@ -153,6 +155,15 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
   publish_pointers(ecg, pv);
   pv->rotate = (ecg->bs_red == NO_BS_RED);
   { const char* f = getenv("PREALPS_ECG_FUSE"); pv->fuse = f ? atoi(f) : 1; }
+  /* With more than one process every collective costs tens of microseconds.  The norm of the
+   * new residual is only needed for the stopping decision, so the driver loops of this library
+   * (preAlps_ECGSolve / ECGAdvance) let it travel with the beta all-reduce of the same
+   * iteration and decide one half-step later; the last half-step is then simply unused.  The
+   * RCI entry preAlps_ECGStoppingCriterion keeps working (it reduces the norm by itself). */
+  { const char* f = getenv("PREALPS_ECG_LAZY_STOP");
+    pv->lazy_stop = pa_world_size() > 1 && pv->fuse && ecg->bs_red == NO_BS_RED &&
+                    ecg->ortho_alg != ORTHODIR_FUSED && ecg->enlFac >= 2 && (f ? atoi(f) : 1);
+    pv->lazy_ptr = NULL; }
   pa_set_desc(ecg->X, M, t, m, t, ts);
   pa_set_desc(ecg->R, M, t, m, t, ts);
   pa_set_desc(ecg->Z, M, t, m, t, ts);
@@ -242,10 +253,11 @@ static int stopping_begin(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   /* rtr_valid == 2: the update kernel summed the norm itself and, in a single-process run,
    * already wrote it to the pinned words the host reads */
   if (!single || pv->rtr_valid == 3) {
+    double* src = (pv->rtr_valid == 2 && pv->lazy_ptr) ? pv->lazy_ptr : pv->d_res2;
     double t0 = pa_wtime();
-    if (pa_allreduce(pv->d_res2, 1)) return 1;
+    if (pa_allreduce(src, 1)) return 1;
     ecg->comm_t += pa_wtime() - t0;
-    PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->d_res2, 2 * sizeof(double)));
+    PA_CHECK(pa_rt_d2h_async(pv->h_pin, src, 2 * sizeof(double)));
   }
   pv->rtr_valid = 0;
   PA_CHECK(pa_rt_event_record(pv->ev_res));
@@ -346,9 +358,11 @@ static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
   }
   t0 = pa_wtime();
   pa_time_begin(PA_T_UPDATE);
+  /* the slot right behind beta: free once the kernel has read U from it (Odir: d_mu) */
+  pv->lazy_ptr = pv->lazy_stop ? pv->d_beta + (size_t)ecg->beta->info.lda * ecg->beta->info.n : NULL;
   PA_CHECK(pa_k_trsm_update(m, ts, t, ecg->X->info.n, pv->d_mu, pv->d_alpha, ecg->P->val, ecg->AP->val,
-                            pv->d_X, pv->d_R, pv->d_rtr_part, &nb, T, pv->d_res2, pv->d_info,
-                            single ? pv->h_pin : NULL));
+                            pv->d_X, pv->d_R, pv->d_rtr_part, &nb, T, pv->lazy_ptr ? pv->lazy_ptr : pv->d_res2,
+                            pv->d_info, single ? pv->h_pin : NULL));
   pv->rtr_nblk = nb;
   pa_time_end(PA_T_UPDATE);
   pv->rtr_valid = 2;
@@ -365,6 +379,7 @@ static int update_iterate(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
                           pv->d_res2, pv->d_info, pa_world_size() == 1 ? pv->h_pin : NULL));
   pa_time_end(PA_T_UPDATE);
   pv->rtr_valid = 2;
+  pv->lazy_ptr = NULL;
   ecg->gemm_t += pa_wtime() - t0;
   return 0;
 }
@@ -405,7 +420,24 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   pa_time_end(PA_T_GRAM);
   ecg->gemm_t += pa_wtime() - t0;
   t0 = pa_wtime();
-  if (pa_allreduce(pv->d_beta, ecg->beta->info.lda * ecg->beta->info.n)) return 1;
+  {
+    int cnt = ecg->beta->info.lda * ecg->beta->info.n;
+    if (pv->rtr_valid == 2 && pv->lazy_ptr == pv->d_beta + cnt) {
+      /* the norm of the new residual (and the Cholesky status) ride along */
+      if (pa_allreduce(pv->d_beta, cnt + 2)) return 1;
+      PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->lazy_ptr, 2 * sizeof(double)));
+      PA_CHECK(pa_rt_event_record(pv->ev_res));
+      pv->rtr_valid = 0;
+    } else {
+      if (pa_allreduce(pv->d_beta, cnt)) return 1;
+      if (pv->lazy_ptr && pv->rtr_valid == 2) {   /* (beta not where expected: reduce the norm by itself) */
+        if (pa_allreduce(pv->lazy_ptr, 1)) return 1;
+        PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->lazy_ptr, 2 * sizeof(double)));
+        PA_CHECK(pa_rt_event_record(pv->ev_res));
+        pv->rtr_valid = 0;
+      }
+    }
+  }
   ecg->comm_t += pa_wtime() - t0;
   t0 = pa_wtime();
   pa_time_begin(PA_T_UPDATE);
@@ -701,9 +733,18 @@ int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_h
          * the residual norm (it does not depend on it and is simply unused after a stop) */
         ecg_priv_t* pv = priv_of(ecg);
         if (!pv) return PA_FAIL("solver not initialised");
-        if (stopping_begin(ecg, pv)) return 1;
-        if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
-        else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+        if (pv->lazy_stop && pv->lazy_ptr) {
+          /* several processes: the norm travels with the beta all-reduce of the second half;
+           * the half-step and the product queued before the decision are unused after a stop */
+          if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
+          else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+          if (preAlps_ECGIterate(ecg, &rci)) return 1;
+          if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+        } else {
+          if (stopping_begin(ecg, pv)) return 1;
+          if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
+          else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+        }
         if (stopping_end(ecg, pv, &stop)) return 1;
         if (res_hist && nh < max_hist) { res_hist[nh] = ecg->res; if (bs_hist) bs_hist[nh] = ecg->bs; }
         ++nh;
@@ -741,10 +782,19 @@ int preAlps_ECGAdvance(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int ns
        * then wait for the norm: the apply does not depend on it and is discarded on stop */
       ecg_priv_t* pv = priv_of(ecg);
       if (!pv) return PA_FAIL("solver not initialised");
-      if (stopping_begin(ecg, pv)) return 1;
-      if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
-      else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+      int lazy = pv->lazy_stop && pv->lazy_ptr;
+      if (lazy) {   /* see preAlps_ECGSolve */
+        if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
+        else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+        if (preAlps_ECGIterate(ecg, rci_request)) return 1;
+        if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+      } else {
+        if (stopping_begin(ecg, pv)) return 1;
+        if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
+        else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+      }
       if (stopping_end(ecg, pv, &stop)) return 1;
+      if (lazy && stop != 1) ++done;
       if (stop == 1) {
         if (restarts) ++*restarts;
         if (last_iters) *last_iters = ecg->iter;

@@ -1,7 +1,9 @@
 """Two ranks sharing the one GPU of the test box, talking through gloo (host
 staging): the whole multi-process path -- sharded operator, halo exchange of
 boundary rows inside preAlps_BlockOperator, all-reduced t x t blocks inside
-preAlps_ECGIterate -- must reproduce the single-process oracle solve."""
+preAlps_ECGIterate -- must reproduce the single-process oracle solve.  With more than
+one process preAlps_ECGSolve lets the residual norm ride on the beta all-reduce
+("odir", "omin"); "odir_eager" keeps the separate reduction of the RCI protocol."""
 import os
 import socket
 import sys
@@ -29,6 +31,9 @@ def _worker(rank, world, port, alg, q):
         os.environ["LOCAL_RANK"] = "0"
         if alg == "fused":
             os.environ["PREALPS_SPMM_RUNS"] = "2"   # halo slots inside the run plan of the SpMM
+        if alg == "odir_eager":                      # the residual norm reduced by itself, before the decision
+            os.environ["PREALPS_ECG_LAZY_STOP"] = "0"
+            alg = "odir"
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -65,7 +70,7 @@ def _worker(rank, world, port, alg, q):
         q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize("alg", ["odir", "omin", "fused", "dodir"])
+@pytest.mark.parametrize("alg", ["odir", "odir_eager", "omin", "fused", "dodir"])
 def test_two_ranks_one_gpu_match_oracle(alg):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
