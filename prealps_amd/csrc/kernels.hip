@@ -502,16 +502,17 @@ __global__ __launch_bounds__(WG) void k_probe_read(size_t n2, const double2* __r
 template <int BS>
 __device__ __forceinline__ void finish_sum(const double* partials, int nblk, int npan, int ts,
                                            int a_lo, int a_hi, int nb, double* out, int ld_out,
-                                           double* red) {
+                                           double* red, int ner_cap = BS, int g0 = 0, int gstride = 1) {
   const int ldp = npan * ts;
   const int na = a_lo + a_hi;
   const int ne = na * nb;
   int ner = 1;
-  while (ner < ne && ner < BS) ner <<= 1;
-  const int nsl = BS / ner;
+  while (ner < ne && ner < ner_cap) ner <<= 1;        // elements summed side by side
+  const int nsl = BS / ner;                           // slices of the partial blocks per element
   const int tid = threadIdx.x;
   const int e0 = tid % ner, s = tid / ner;
-  for (int base = 0; base < ne; base += ner) {
+  // groups of `ner` elements, dealt out to the workgroups of the launch
+  for (int base = g0 * ner; base < ne; base += gstride * ner) {
     const int e = base + e0;
     double sum = 0.0;
     int i = 0, j = 0;
@@ -541,16 +542,36 @@ __device__ __forceinline__ void finish_sum(const double* partials, int nblk, int
   }
 }
 
-// [W ; G^T] ((t+T) x t, ld t+T) -> mu = chol(W) (t x t, ld t), alpha = U^-T G (t x T, ld t);
-// called by a whole workgroup, W / G = 256 doubles of LDS each.  (ecg.c:431 + :438 with the
-// Gram of the un-normalised P: (P U^-1)^T R = U^-T (P^T R).)
-__device__ __forceinline__ void potrf_alpha_wg(const double* buf, int t, int T, double* mu,
-                                               double* alpha, int* info, double* W, double* G) {
-  const int ld = t + T, nt = blockDim.x;
-  for (int e = threadIdx.x; e < t * t; e += nt) W[e] = buf[(e % t) + ld * (e / t)];
-  for (int e = threadIdx.x; e < t * T; e += nt) { const int i = e % t, c = e / t; G[e] = buf[(t + c) + ld * i]; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
+// In-place upper Cholesky of the t x t column-major W in LDS (LAPACK dpotf2 'U': on failure
+// the failing pivot is stored and the rest of W is left untouched), called by a whole
+// workgroup.  One wavefront: columns one after the other, the entries of a column in parallel;
+// larger workgroups (where a barrier costs more than a 8 x 8 factorisation): one thread.
+// Both orders perform the same operations per entry, so the factor is bitwise the same.
+__device__ __forceinline__ void potrf_upper_wg(double* W, int t, int* info) {
+  const int nt = blockDim.x;
+  if (nt <= 64) {
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    for (int j = 0; j < t; ++j) {
+      if (threadIdx.x == 0 && s_fail == 0) {
+        double d = W[j + t * j];
+        for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
+        if (!(d > 0.0)) { W[j + t * j] = d; s_fail = j + 1; }
+        else W[j + t * j] = sqrt(d);
+      }
+      __syncthreads();
+      if (s_fail) break;
+      const int i = j + 1 + threadIdx.x;
+      if (i < t) {
+        double sv = W[j + t * i];
+        for (int k = 0; k < j; ++k) sv -= W[k + t * j] * W[k + t * i];
+        W[j + t * i] = sv / W[j + t * j];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *info = s_fail;
+  } else if (threadIdx.x == 0) {
     int fail = 0;
     for (int j = 0; j < t; ++j) {
       double d = W[j + t * j];
@@ -567,6 +588,18 @@ __device__ __forceinline__ void potrf_alpha_wg(const double* buf, int t, int T, 
     *info = fail;
   }
   __syncthreads();
+}
+
+// [W ; G^T] ((t+T) x t, ld t+T) -> mu = chol(W) (t x t, ld t), alpha = U^-T G (t x T, ld t);
+// called by a whole workgroup, W / G = 256 doubles of LDS each.  (ecg.c:431 + :438 with the
+// Gram of the un-normalised P: (P U^-1)^T R = U^-T (P^T R).)
+__device__ __forceinline__ void potrf_alpha_wg(const double* buf, int t, int T, double* mu,
+                                               double* alpha, int* info, double* W, double* G) {
+  const int ld = t + T, nt = blockDim.x;
+  for (int e = threadIdx.x; e < t * t; e += nt) W[e] = buf[(e % t) + ld * (e / t)];
+  for (int e = threadIdx.x; e < t * T; e += nt) { const int i = e % t, c = e / t; G[e] = buf[(t + c) + ld * i]; }
+  __syncthreads();
+  potrf_upper_wg(W, t, info);
   if (threadIdx.x < T) {            // one column of alpha per lane: forward substitution with U^T
     const int c = threadIdx.x;
     for (int i = 0; i < t; ++i) {
@@ -671,7 +704,9 @@ __global__ __launch_bounds__(1024) void k_finish(const double* __restrict__ part
                                                int npan, int ts, int a_lo, int a_hi, int nb,
                                                double* __restrict__ out, int ld_out) {
   __shared__ double red[1024];
-  finish_sum<1024>(partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out, red);
+  // several workgroups (large blocks, 16-column panels): 64 elements at a time each
+  if (gridDim.x > 1) finish_sum<1024>(partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out, red, 64, blockIdx.x, gridDim.x);
+  else finish_sum<1024>(partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out, red);
 }
 
 // k_finish followed by k_potrf_alpha on its output, one launch (single-process runs, where no
@@ -694,23 +729,7 @@ __global__ void k_potrf(double* __restrict__ Wg, int t, int* __restrict__ info) 
   __shared__ double W[16 * 16];
   for (int e = threadIdx.x; e < t * t; e += 64) W[e] = Wg[e];
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int fail = 0;
-    for (int j = 0; j < t; ++j) {
-      double d = W[j + t * j];
-      for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
-      if (!(d > 0.0)) { W[j + t * j] = d; fail = j + 1; break; }
-      d = sqrt(d);
-      W[j + t * j] = d;
-      for (int i = j + 1; i < t; ++i) {
-        double s = W[j + t * i];
-        for (int k = 0; k < j; ++k) s -= W[k + t * j] * W[k + t * i];
-        W[j + t * i] = s / d;
-      }
-    }
-    *info = fail;
-  }
-  __syncthreads();
+  potrf_upper_wg(W, t, info);
   for (int e = threadIdx.x; e < t * t; e += 64) Wg[e] = W[e];
 }
 
@@ -1752,6 +1771,10 @@ int pa_k_gram_finish(int m, int ts, const double* A0, const double* A1, const do
       snprintf(g_kerr, sizeof(g_kerr), "pa_k_gram_finish: [W ; G^T] layout expected");
       return 1;
     }
+    if ((t + T) * t > 128) {   // large block: spread the sum, then factor
+      if (pa_k_finish(partials, nblk, 2, ts, t, T, t, out, t + T)) return 1;
+      return pa_k_potrf_alpha(out, t, T, mu, alpha, info);
+    }
     hipLaunchKernelGGL(k_finish_potrf_alpha, dim3(1), dim3(1024), 0, cur_stream(), partials, nblk, 2, ts,
                        t, T, out, mu, alpha, info);
     return kfail("k_finish_potrf_alpha");
@@ -1761,8 +1784,10 @@ int pa_k_gram_finish(int m, int ts, const double* A0, const double* A1, const do
 
 int pa_k_finish(const double* partials, int nblk, int npan, int ts, int a_lo, int a_hi, int nb,
                 double* out, int ld_out) {
-  if ((a_lo + a_hi) * nb <= 0) return 0;
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, cur_stream(), partials, nblk, npan, ts, a_lo,
+  const int ne = (a_lo + a_hi) * nb;
+  if (ne <= 0) return 0;
+  const int groups = ne > 128 ? (ne + 63) / 64 : 1;    // one workgroup unless the block is large
+  hipLaunchKernelGGL(k_finish, dim3(groups), dim3(1024), 0, cur_stream(), partials, nblk, npan, ts, a_lo,
                      a_hi, nb, out, ld_out);
   return kfail("k_finish");
 }
