@@ -493,6 +493,56 @@ __global__ __launch_bounds__(WG) void k_probe_read(size_t n2, const double2* __r
   if (s == 12345.678) out[0] = s;   // keeps the loads alive, never true for the zero-filled buffer
 }
 
+// 16-column panels: the same Gram product on the f64 matrix cores.  One v_mfma_f64_16x16x4
+// takes four panel rows: lane l supplies A[row l>>4][col l&15] and B[row l>>4][col l&15] --
+// a wave-wide load of either operand is 512 contiguous bytes -- and accumulates
+// C[i][j] = sum_rows A[row][i] B[row][j] (C/D map: col = lane&15, row = (lane>>4) + 4*reg).
+// The register-tiled kernel above re-reads every panel segment from L1 four to eight times at
+// this width (139 us for 395 MB); this one reads each byte once.  Same partial-block layout.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+template <int NPAN>
+__global__ __launch_bounds__(WG) void k_gram_mfma16(int m, const double* __restrict__ A0,
+                                                    const double* __restrict__ A1,
+                                                    const double* __restrict__ B,
+                                                    double* __restrict__ partials) {
+  constexpr int TS = 16, LDP = NPAN * TS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, rsub = lane >> 4;
+  mfma_d4 acc[NPAN];
+#pragma unroll
+  for (int p = 0; p < NPAN; ++p) acc[p] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  const size_t nquad = ((size_t)m + 3) >> 2;
+  const size_t qstride = (size_t)gridDim.x * (WG / 64);
+  constexpr int U = 4;                                 // quads in flight per wavefront
+  for (size_t q0 = (size_t)blockIdx.x * (WG / 64) + wave; q0 < nquad; q0 += U * qstride) {
+    double a[U][NPAN], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t row = (q0 + u * qstride) * 4 + rsub;
+      const bool ok = row < (size_t)m;
+      b[u] = ok ? B[row * TS + col] : 0.0;
+      a[u][0] = ok ? A0[row * TS + col] : 0.0;
+      if (NPAN > 1) a[u][NPAN - 1] = ok ? A1[row * TS + col] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int p = 0; p < NPAN; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][p], b[u], acc[p], 0, 0, 0);
+  }
+  __shared__ double red[WG / 64][LDP * TS];
+#pragma unroll
+  for (int p = 0; p < NPAN; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(p * TS + rsub + 4 * r) + LDP * col] = acc[p][r];
+  __syncthreads();
+  for (int e = tid; e < LDP * TS; e += WG) {
+    double sum = red[0][e];
+#pragma unroll
+    for (int w2 = 1; w2 < WG / 64; ++w2) sum += red[w2][e];
+    partials[(size_t)blockIdx.x * (LDP * TS) + e] = sum;
+  }
+}
+
 // ------------------------------------------------ small finishing steps ----
 // Measured and rejected: letting the last workgroup of the producing kernel (ticket counter)
 // do these sums.  The device-scope release every workgroup needs before taking its ticket
@@ -1750,6 +1800,11 @@ int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B
   int blocks = grid_rows(m, 4);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
+  if (ts == 16) {   // matrix cores (k_gram_mfma16)
+    if (A1) hipLaunchKernelGGL((k_gram_mfma16<2>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
+    else hipLaunchKernelGGL((k_gram_mfma16<1>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
+    return kfail("k_gram_mfma16");
+  }
   if (A1) {
     TS_DISPATCH(ts, hipLaunchKernelGGL((k_gram<TS_, 2>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                        A0, A1, B, partials));
