@@ -1058,6 +1058,60 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
   }
 }
 
+// 16-column panels on the f64 matrix cores: a tile of 16 rows of Z is the C/D operand (lane l
+// holds Z[row (l>>4) + 4r][col l&15]: four fully coalesced 512-byte accesses), the rows of
+// [V0 | V1] are the A operand (A[row l&15][k = 4s + (l>>4)], 32-byte pieces of 16 rows per
+// load, every cache line used up over four loads) and -beta the B operand, a per-lane constant.
+__global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_hi, int nc,
+                                                        const double* __restrict__ beta, int ldb,
+                                                        const double* __restrict__ V0,
+                                                        const double* __restrict__ V1,
+                                                        double* __restrict__ Z) {
+  constexpr int TS = 16;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+  // B[k][j] = -beta(k, j), k = 4s + hi (s < 4: rows of beta that meet V0, s >= 4: V1), j = lo
+  double bneg[8];
+#pragma unroll
+  for (int s2 = 0; s2 < 8; ++s2) {
+    const int k = 4 * (s2 & 3) + hi;
+    const bool first = s2 < 4;
+    const bool ok = lo < nc && (first ? k < a_lo : k < a_hi);
+    bneg[s2] = ok ? -beta[(first ? k : a_lo + k) + ldb * lo] : 0.0;
+  }
+  const size_t ntile = ((size_t)m + 15) >> 4;
+  const size_t tstride = (size_t)gridDim.x * (WG / 64);
+  for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
+    const size_t r0 = t << 4;
+    mfma_d4 z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = r0 + hi + 4 * r;
+      z[r] = row < (size_t)m ? Z[row * TS + lo] : 0.0;
+    }
+    const size_t arow = r0 + lo;
+    const bool aok = arow < (size_t)m;
+    double a[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) a[s2] = aok ? V0[arow * TS + 4 * s2 + hi] : 0.0;
+    if (a_hi > 0) {
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) a[4 + s2] = aok ? V1[arow * TS + 4 * s2 + hi] : 0.0;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) z = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bneg[s2], z, 0, 0, 0);
+    if (a_hi > 0) {
+#pragma unroll
+      for (int s2 = 4; s2 < 8; ++s2) z = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bneg[s2], z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = r0 + hi + 4 * r;
+      if (row < (size_t)m && lo < nc) Z[row * TS + lo] = z[r];
+    }
+  }
+}
+
 template <int TS>
 __global__ __launch_bounds__(WG) void k_copy_cols(int m, int nc, const double* __restrict__ src,
                                                   double* __restrict__ dst) {
@@ -1920,6 +1974,11 @@ int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, doub
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
                   const double* V0, const double* V1, double* Z) {
   if (nc <= 0) return 0;
+  if (ts == 16) {   // matrix cores (k_update_z_mfma16), one 16-row tile per wavefront and step
+    hipLaunchKernelGGL(k_update_z_mfma16, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
+                       beta, ldb, V0, V1, Z);
+    return kfail("k_update_z_mfma16");
+  }
   TS_DISPATCH(ts, hipLaunchKernelGGL((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
                                      cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z));
   return kfail("k_update_z");
