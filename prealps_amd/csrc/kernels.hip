@@ -28,6 +28,8 @@ int kfail(const char* what) {
   return 1;
 }
 
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));   // C/D operand of v_mfma_f64_16x16x4
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, lane);
@@ -499,7 +501,6 @@ __global__ __launch_bounds__(WG) void k_probe_read(size_t n2, const double2* __r
 // C[i][j] = sum_rows A[row][i] B[row][j] (C/D map: col = lane&15, row = (lane>>4) + 4*reg).
 // The register-tiled kernel above re-reads every panel segment from L1 four to eight times at
 // this width (139 us for 395 MB); this one reads each byte once.  Same partial-block layout.
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 template <int NPAN>
 __global__ __launch_bounds__(WG) void k_gram_mfma16(int m, const double* __restrict__ A0,
                                                     const double* __restrict__ A1,
@@ -1424,6 +1425,155 @@ __global__ __launch_bounds__(256) void k_bj_apply(
 // its rows.  Records are stored in window-slot order -- the value for target row i sits at
 // column i mod W -- so a lane reads the same column of every record: no index arithmetic,
 // coalesced, and prefetched D steps ahead in registers.
+// ---- the same sweeps on the f64 matrix cores (panels of 8 / 16 columns) ----
+// The window is kept as NT tiles of 16 rows in the C/D layout of v_mfma_f64_16x16x4 (lane l,
+// register r <-> tile row (l>>4) + 4r, panel column l&15).  Four pivots at a time: they are
+// the four rows of one register of the pivot tile, so after a 3-step solve among themselves
+// (values passed down 16 lanes with a shuffle) that register *is* the B operand
+// Y[k = l>>4][j = l&15] of the rank-4 update  tile -= L[rows of tile][4 pivots] * Y  -- no
+// data movement.  The A operand is the band value of (row l&15 of the tile, pivot l>>4), one
+// LDS read per lane and tile.  Per step this costs a quarter of the v_readlane / v_fma_f64
+// recurrence above at 16 columns.  Same records, same LDS-DMA chunks of 8 steps.
+template <int TS, int NT, int TP>
+__device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], int g, int& chunk, int b,
+                                         int w, int wr, const double* __restrict__ rec,
+                                         const double* __restrict__ invd, const int* __restrict__ iomap,
+                                         size_t rowbase, const double* __restrict__ src,
+                                         double* __restrict__ dst, double* lds0, double* lds1, int lane) {
+  const int lo = lane & 15, hi = lane >> 4;
+  const double* cur = lds0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if ((r & 1) == 0) {   // a new chunk of 8 steps starts with this group of four pivots
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      cur = (chunk & 1) ? lds1 : lds0;
+      if ((chunk + 1) * 8 < b) bj_issue_chunk<8>(rec, wr, chunk + 1, (chunk & 1) ? lds0 : lds1, lane);
+      ++chunk;
+    }
+    const double* grec = cur + (size_t)(4 * (r & 1)) * wr;     // records of this group's pivots
+    const double* prec = grec + (size_t)hi * wr;               // record of "my" pivot (k = hi)
+    // every band value this group needs, read with explicit ds_read_b64 + one wait: a
+    // compiler-visible LDS read of an LDS-DMA target drains all outstanding VMEM first (the
+    // chunk in flight), once per read
+    double cg[3], ct[NT];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const unsigned ad = (unsigned)(uintptr_t)(lds_void_ptr)(grec + (size_t)a * wr + min(max(hi - a - 1, 0), w));
+      asm volatile("ds_read_b64 %0, %1" : "=v"(cg[a]) : "v"(ad));
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const unsigned d1 = (unsigned)(16 * t + lo - 4 * r - hi - 1);
+      const unsigned ad = (unsigned)(uintptr_t)(lds_void_ptr)(prec + min(d1, (unsigned)w));
+      asm volatile("ds_read_b64 %0, %1" : "=v"(ct[t]) : "v"(ad));
+    }
+    if constexpr (NT == 4)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]));
+    else if constexpr (NT == 6)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]), "+v"(ct[6]), "+v"(ct[7]));
+    // the four pivots among themselves: pivot a (lanes hi == a) updates the rows below it
+    double y = acc[TP][r];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double ya = __shfl(y, a * 16 + lo);
+      const double cf = (hi > a) ? cg[a] : 0.0;
+      y = fma(-cf, ya, y);
+    }
+    acc[TP][r] = y;
+    // rank-4 update of every tile the band reaches
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (16 * t - 4 * r - 3 <= w) {
+        double cf = ct[t];
+        if (t == 0 && (lo >> 2) == r) cf = 0.0;               // rows of this group: done above
+        acc[(TP + t) % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cf, y, acc[(TP + t) % NT], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("" ::: "memory");   // the next LDS-DMA into these buffers stays behind the reads
+  // the tile is solved: scale, store, and take the tile NT further down
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = 16 * g + hi + 4 * r;
+    if (j < b && lo < TS) dst[(rowbase + rid[TP][r]) * TS + lo] = acc[TP][r] * invd[j];
+    const int jn = j + 16 * NT;
+    double v = 0.0;
+    int id = 0;
+    if (jn < b) { id = iomap[jn]; if (lo < TS) v = src[(rowbase + id) * TS + lo]; }
+    acc[TP][r] = v;
+    rid[TP][r] = id;
+  }
+}
+
+template <int TS, int NT, int TP>
+__device__ __forceinline__ void bjm_tiles(mfma_d4 (&acc)[NT], int (&rid)[NT][4], int g0, int& chunk, int b,
+                                          int w, int wr, const double* __restrict__ rec,
+                                          const double* __restrict__ invd, const int* __restrict__ iomap,
+                                          size_t rowbase, const double* __restrict__ src,
+                                          double* __restrict__ dst, double* lds0, double* lds1, int lane) {
+  if constexpr (TP < NT) {
+    if (16 * (g0 + TP) < b) {
+      bjm_tile<TS, NT, TP>(acc, rid, g0 + TP, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lds1, lane);
+      bjm_tiles<TS, NT, TP + 1>(acc, rid, g0, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lds1, lane);
+    }
+  }
+}
+
+template <int TS, int NT>
+__device__ __forceinline__ void bjm_sweep(int b, int w, int wr, const double* __restrict__ rec,
+                                          const double* __restrict__ invd, const int* __restrict__ iomap,
+                                          size_t rowbase, const double* __restrict__ src,
+                                          double* __restrict__ dst, double* lds0, double* lds1, int lane) {
+  const int lo = lane & 15, hi = lane >> 4;
+  mfma_d4 acc[NT];
+  int rid[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * t + hi + 4 * r;
+      double v = 0.0;
+      int id = 0;
+      if (j < b) { id = iomap[j]; if (lo < TS) v = src[(rowbase + id) * TS + lo]; }
+      acc[t][r] = v;
+      rid[t][r] = id;
+    }
+  bj_issue_chunk<8>(rec, wr, 0, lds0, lane);
+  int chunk = 0;
+  for (int g0 = 0; 16 * g0 < b; g0 += NT)
+    bjm_tiles<TS, NT, 0>(acc, rid, g0, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lds1, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int TS, int NT>
+__global__ __launch_bounds__(256) void k_bj_mfma(
+    const int* __restrict__ list, int count, const int* __restrict__ row0,
+    const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off,
+    const int* __restrict__ map_f, const int* __restrict__ map_b, const double* __restrict__ Lf,
+    const double* __restrict__ Lb, const double* __restrict__ invd_f,
+    const double* __restrict__ invd_b, int lds_per_wave, const double* __restrict__ in,
+    double* __restrict__ out) {
+  extern __shared__ double smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int pi = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (pi >= count) return;
+  const int p = __builtin_amdgcn_readfirstlane(list[pi]);
+  const int r0 = __builtin_amdgcn_readfirstlane(row0[p]);
+  const int b = __builtin_amdgcn_readfirstlane(nrows[p]);
+  const int w = __builtin_amdgcn_readfirstlane(bw[p]);
+  const int wr = (w + 2) & ~1;
+  const long long o64 = off[p];
+  const size_t o = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(o64 >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)o64);
+  double* lds0 = smem + (size_t)wave * lds_per_wave;
+  double* lds1 = lds0 + (lds_per_wave >> 1);
+  bjm_sweep<TS, NT>(b, w, wr, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in, out, lds0, lds1, lane);
+  __threadfence_block();
+  bjm_sweep<TS, NT>(b, w, wr, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, lds0, lds1, lane);
+}
+
 // The sweep is blocked by 64 pivots.  Phase A: the wave that holds the block's rows
 // eliminates them among themselves (in-wave, v_readlane; its 64 x 64 coefficients were
 // brought into LDS by LDS-DMA during the previous block) and publishes the 64 solved rows in
@@ -1753,6 +1903,27 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
                      const double* in, double* out) {
   // chunks of 8 steps: measured equal or better than 16 and 32 (smaller LDS footprint,
   // more workgroups per CU)
+  // PREALPS_BJ_MFMA=1: the matrix-core sweep for panels of 8 / 16 columns and bands up to 112
+  // (=2: for narrower panels too).  Correct, but as written 2-5x slower than the register
+  // recurrence (810-840 us per apply at every panel width): the compiler drains all outstanding
+  // VMEM before each ds_bpermute behind an LDS-DMA, shuttles the tiles between AGPRs and VGPRs,
+  // and needs ~250 registers (one wavefront per SIMD).  Kept for the next round.
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("PREALPS_BJ_MFMA"); use_mfma = e ? atoi(e) : 0; }
+  if (wmax <= 112 && ((TS >= 8 && use_mfma) || use_mfma >= 2)) {
+    const int wr = (wmax + 2) & ~1;
+    int per_wave = 2 * ((8 * wr + 127) & ~127);
+    int waves = 4;
+    const size_t lds = (size_t)waves * per_wave * 8;
+    const int blocks = (count + waves - 1) / waves;
+#define BJM_LAUNCH(NTT)                                                                              \
+    hipLaunchKernelGGL((k_bj_mfma<TS, NTT>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, \
+                       pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb,   \
+                       pl->invd_f, pl->invd_b, per_wave, in, out)
+    if (wmax <= 48) BJM_LAUNCH(4); else if (wmax <= 80) BJM_LAUNCH(6); else BJM_LAUNCH(8);
+#undef BJM_LAUNCH
+    return kfail("k_bj_mfma");
+  }
   // PREALPS_BJ_SPLIT=1: panels of 8 / 16 columns as 2 / 4 wavefronts of 4 columns each per
   // subdomain.  Measured slower (each wavefront streams the factor again through L2: 257 vs
   // 243 us at 8 columns, 485 vs 434 us at 16), so one wavefront carries all columns by default.
