@@ -1428,8 +1428,8 @@ __global__ __launch_bounds__(256) void k_bj_apply(
 // ---- the same sweeps on the f64 matrix cores (panels of 8 / 16 columns) ----
 // The window is kept as NT tiles of 16 rows in the C/D layout of v_mfma_f64_16x16x4 (lane l,
 // register r <-> tile row (l>>4) + 4r, panel column l&15).  Four pivots at a time: they are
-// the four rows of one register of the pivot tile, so after a 3-step solve among themselves
-// (values passed down 16 lanes with a shuffle) that register *is* the B operand
+// the four rows of one register of the pivot tile, so once they are settled among themselves
+// that register *is* the B operand
 // Y[k = l>>4][j = l&15] of the rank-4 update  tile -= L[rows of tile][4 pivots] * Y  -- no
 // data movement.  The A operand is the band value of (row l&15 of the tile, pivot l>>4), one
 // LDS read per lane and tile.  Per step this costs a quarter of the v_readlane / v_fma_f64
@@ -1442,6 +1442,17 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
                                          double* __restrict__ dst, double* lds0, double* lds1, int lane) {
   const int lo = lane & 15, hi = lane >> 4;
   const double* cur = lds0;
+  // what the hand-over at the end needs is fetched now: 1/L(j,j) of the tile's rows and the
+  // ids of the rows that take over the slot (their values follow once the ids have landed)
+  double idl[4], nxt[4];
+  int nid[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = 16 * g + hi + 4 * r, jn = j + 16 * NT;
+    idl[r] = j < b ? invd[j] : 0.0;
+    nid[r] = jn < b ? iomap[jn] : 0;
+    nxt[r] = 0.0;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if ((r & 1) == 0) {   // a new chunk of 8 steps starts with this group of four pivots
@@ -1449,18 +1460,18 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
       cur = (chunk & 1) ? lds1 : lds0;
       if ((chunk + 1) * 8 < b) bj_issue_chunk<8>(rec, wr, chunk + 1, (chunk & 1) ? lds0 : lds1, lane);
       ++chunk;
+      if (r == 0) {
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2)
+          if (16 * g + hi + 4 * r2 + 16 * NT < b && lo < TS) nxt[r2] = src[(rowbase + nid[r2]) * TS + lo];
+      }
     }
     const double* grec = cur + (size_t)(4 * (r & 1)) * wr;     // records of this group's pivots
     const double* prec = grec + (size_t)hi * wr;               // record of "my" pivot (k = hi)
     // every band value this group needs, read with explicit ds_read_b64 + one wait: a
     // compiler-visible LDS read of an LDS-DMA target drains all outstanding VMEM first (the
     // chunk in flight), once per read
-    double cg[3], ct[NT];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const unsigned ad = (unsigned)(uintptr_t)(lds_void_ptr)(grec + (size_t)a * wr + min(max(hi - a - 1, 0), w));
-      asm volatile("ds_read_b64 %0, %1" : "=v"(cg[a]) : "v"(ad));
-    }
+    double ct[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const unsigned d1 = (unsigned)(16 * t + lo - 4 * r - hi - 1);
@@ -1468,28 +1479,23 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
       asm volatile("ds_read_b64 %0, %1" : "=v"(ct[t]) : "v"(ad));
     }
     if constexpr (NT == 4)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]));
     else if constexpr (NT == 6)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]));
     else
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]), "+v"(ct[6]), "+v"(ct[7]));
-    // the four pivots among themselves: pivot a (lanes hi == a) updates the rows below it
-    double y = acc[TP][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]), "+v"(ct[6]), "+v"(ct[7]));
+    // the pivot tile takes the four pivots one after the other (A masked to one pivot per
+    // instruction, B re-read from the tile): this also settles the four rows among themselves,
+    // with no lane-crossing move
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const double ya = __shfl(y, a * 16 + lo);
-      const double cf = (hi > a) ? cg[a] : 0.0;
-      y = fma(-cf, ya, y);
-    }
-    acc[TP][r] = y;
-    // rank-4 update of every tile the band reaches
+    for (int a = 0; a < 4; ++a)
+      acc[TP] = __builtin_amdgcn_mfma_f64_16x16x4f64((hi == a) ? -ct[0] : 0.0, acc[TP][r], acc[TP], 0, 0, 0);
+    // the other tiles the band reaches: one rank-4 update each
+    const double y = acc[TP][r];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (16 * t - 4 * r - 3 <= w) {
-        double cf = ct[t];
-        if (t == 0 && (lo >> 2) == r) cf = 0.0;               // rows of this group: done above
-        acc[(TP + t) % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cf, y, acc[(TP + t) % NT], 0, 0, 0);
-      }
+    for (int t = 1; t < NT; ++t) {
+      if (16 * t - 4 * r - 3 <= w)
+        acc[(TP + t) % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ct[t], y, acc[(TP + t) % NT], 0, 0, 0);
     }
   }
   asm volatile("" ::: "memory");   // the next LDS-DMA into these buffers stays behind the reads
@@ -1497,14 +1503,11 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int j = 16 * g + hi + 4 * r;
-    if (j < b && lo < TS) dst[(rowbase + rid[TP][r]) * TS + lo] = acc[TP][r] * invd[j];
-    const int jn = j + 16 * NT;
-    double v = 0.0;
-    int id = 0;
-    if (jn < b) { id = iomap[jn]; if (lo < TS) v = src[(rowbase + id) * TS + lo]; }
-    acc[TP][r] = v;
-    rid[TP][r] = id;
+    if (j < b && lo < TS) dst[(rowbase + rid[TP][r]) * TS + lo] = acc[TP][r] * idl[r];
+    acc[TP][r] = nxt[r];
+    rid[TP][r] = nid[r];
   }
+  __builtin_amdgcn_sched_barrier(0);   // keep the next tile's prefetches from piling up here
 }
 
 template <int TS, int NT, int TP>
@@ -1905,9 +1908,9 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
   // more workgroups per CU)
   // PREALPS_BJ_MFMA=1: the matrix-core sweep for panels of 8 / 16 columns and bands up to 112
   // (=2: for narrower panels too).  Correct, but as written 2-5x slower than the register
-  // recurrence (810-840 us per apply at every panel width): the compiler drains all outstanding
-  // VMEM before each ds_bpermute behind an LDS-DMA, shuttles the tiles between AGPRs and VGPRs,
-  // and needs ~250 registers (one wavefront per SIMD).  Kept for the next round.
+  // recurrence (745-765 us per apply at every panel width, i.e. latency bound): ~250 registers
+  // (one or two wavefronts per SIMD) and a chain of four dependent f64 MFMAs per group of
+  // four pivots.  Kept for the next round.
   static int use_mfma = -1;
   if (use_mfma < 0) { const char* e = getenv("PREALPS_BJ_MFMA"); use_mfma = e ? atoi(e) : 0; }
   if (wmax <= 112 && ((TS >= 8 && use_mfma) || use_mfma >= 2)) {
