@@ -544,6 +544,48 @@ __global__ __launch_bounds__(WG) void k_gram_mfma16(int m, const double* __restr
   }
 }
 
+// 8-column panels: [A0 | A1] fills the 16 rows of one tile, B its first 8 columns.
+template <int NPAN>
+__global__ __launch_bounds__(WG) void k_gram_mfma8(int m, const double* __restrict__ A0,
+                                                   const double* __restrict__ A1,
+                                                   const double* __restrict__ B,
+                                                   double* __restrict__ partials) {
+  constexpr int TS = 8, LDP = NPAN * TS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, rsub = lane >> 4;
+  const double* __restrict__ Ap = (col < TS) ? A0 : A1;      // panel this lane's A column lives in
+  const bool a_on = col < LDP, b_on = col < TS;
+  const int ac = col & (TS - 1);
+  mfma_d4 acc = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  const size_t nquad = ((size_t)m + 3) >> 2;
+  const size_t qstride = (size_t)gridDim.x * (WG / 64);
+  constexpr int U = 4;
+  for (size_t q0 = (size_t)blockIdx.x * (WG / 64) + wave; q0 < nquad; q0 += U * qstride) {
+    double a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t row = (q0 + u * qstride) * 4 + rsub;
+      const bool ok = row < (size_t)m;
+      a[u] = (ok && a_on) ? Ap[row * TS + ac] : 0.0;
+      b[u] = (ok && b_on) ? B[row * TS + col] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+  __shared__ double red[WG / 64][LDP * TS];
+  if (b_on)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (rsub + 4 * r < LDP) red[wave][(rsub + 4 * r) + LDP * col] = acc[r];
+  __syncthreads();
+  for (int e = tid; e < LDP * TS; e += WG) {
+    double sum = red[0][e];
+#pragma unroll
+    for (int w2 = 1; w2 < WG / 64; ++w2) sum += red[w2][e];
+    partials[(size_t)blockIdx.x * (LDP * TS) + e] = sum;
+  }
+}
+
 // ------------------------------------------------ small finishing steps ----
 // Measured and rejected: letting the last workgroup of the producing kernel (ticket counter)
 // do these sums.  The device-scope release every workgroup needs before taking its ticket
@@ -2032,6 +2074,11 @@ int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B
     if (A1) hipLaunchKernelGGL((k_gram_mfma16<2>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
     else hipLaunchKernelGGL((k_gram_mfma16<1>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
     return kfail("k_gram_mfma16");
+  }
+  if (ts == 8) {
+    if (A1) hipLaunchKernelGGL((k_gram_mfma8<2>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
+    else hipLaunchKernelGGL((k_gram_mfma8<1>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
+    return kfail("k_gram_mfma8");
   }
   if (A1) {
     TS_DISPATCH(ts, hipLaunchKernelGGL((k_gram<TS_, 2>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
