@@ -1490,9 +1490,10 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
   int nid[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
+    // branch-free: rows past the end read row 0 / entry 0 and are masked when used
     const int j = 16 * g + hi + 4 * r, jn = j + 16 * NT;
-    idl[r] = j < b ? invd[j] : 0.0;
-    nid[r] = jn < b ? iomap[jn] : 0;
+    idl[r] = invd[j < b ? j : 0];
+    nid[r] = iomap[jn < b ? jn : 0];
     nxt[r] = 0.0;
   }
 #pragma unroll
@@ -1502,10 +1503,12 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
       cur = (chunk & 1) ? lds1 : lds0;
       if ((chunk + 1) * 8 < b) bj_issue_chunk<8>(rec, wr, chunk + 1, (chunk & 1) ? lds0 : lds1, lane);
       ++chunk;
-      if (r == 0) {
+      if (r == 0) {   // the ids have landed: the four row loads go out back to back
+        const double* sp[4];
 #pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2)
-          if (16 * g + hi + 4 * r2 + 16 * NT < b && lo < TS) nxt[r2] = src[(rowbase + nid[r2]) * TS + lo];
+        for (int r2 = 0; r2 < 4; ++r2) sp[r2] = src + (rowbase + nid[r2]) * TS + (lo < TS ? lo : 0);
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) nxt[r2] = *sp[r2];
       }
     }
     const double* grec = cur + (size_t)(4 * (r & 1)) * wr;     // records of this group's pivots
@@ -1533,12 +1536,11 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
     for (int a = 0; a < 4; ++a)
       acc[TP] = __builtin_amdgcn_mfma_f64_16x16x4f64((hi == a) ? -ct[0] : 0.0, acc[TP][r], acc[TP], 0, 0, 0);
     // the other tiles the band reaches: one rank-4 update each
+    // (tiles past the band meet the record's zero slot: no branch)
     const double y = acc[TP][r];
 #pragma unroll
-    for (int t = 1; t < NT; ++t) {
-      if (16 * t - 4 * r - 3 <= w)
-        acc[(TP + t) % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ct[t], y, acc[(TP + t) % NT], 0, 0, 0);
-    }
+    for (int t = 1; t < NT; ++t)
+      acc[(TP + t) % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ct[t], y, acc[(TP + t) % NT], 0, 0, 0);
   }
   asm volatile("" ::: "memory");   // the next LDS-DMA into these buffers stays behind the reads
   // the tile is solved: scale, store, and take the tile NT further down
@@ -1546,7 +1548,7 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
   for (int r = 0; r < 4; ++r) {
     const int j = 16 * g + hi + 4 * r;
     if (j < b && lo < TS) dst[(rowbase + rid[TP][r]) * TS + lo] = acc[TP][r] * idl[r];
-    acc[TP][r] = nxt[r];
+    acc[TP][r] = (j + 16 * NT < b && lo < TS) ? nxt[r] : 0.0;
     rid[TP][r] = nid[r];
   }
   __builtin_amdgcn_sched_barrier(0);   // keep the next tile's prefetches from piling up here
@@ -1948,14 +1950,13 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
                      const double* in, double* out) {
   // chunks of 8 steps: measured equal or better than 16 and 32 (smaller LDS footprint,
   // more workgroups per CU)
-  // PREALPS_BJ_MFMA=1: the matrix-core sweep for panels of 8 / 16 columns and bands up to 112
-  // (=2: for narrower panels too).  Correct, but as written 2-5x slower than the register
-  // recurrence (745-765 us per apply at every panel width, i.e. latency bound): ~250 registers
-  // (one or two wavefronts per SIMD) and a chain of four dependent f64 MFMAs per group of
-  // four pivots.  Kept for the next round.
+  // The matrix-core sweep (k_bj_mfma, bands up to 112) costs 240-270 us per apply whatever the
+  // panel width (latency: three wavefronts per SIMD, four dependent MFMAs per group of pivots),
+  // the register recurrence 172 / 246 / 443 us at 4 / 8 / 16 columns: so it takes the
+  // 16-column panels.  PREALPS_BJ_MFMA=0: never; 1: from 8 columns; 2: always.
   static int use_mfma = -1;
-  if (use_mfma < 0) { const char* e = getenv("PREALPS_BJ_MFMA"); use_mfma = e ? atoi(e) : 0; }
-  if (wmax <= 112 && ((TS >= 8 && use_mfma) || use_mfma >= 2)) {
+  if (use_mfma < 0) { const char* e = getenv("PREALPS_BJ_MFMA"); use_mfma = e ? atoi(e) : -1; if (use_mfma < 0) use_mfma = 3; }
+  if (wmax <= 112 && ((TS >= 16 && use_mfma == 3) || (TS >= 8 && use_mfma == 1) || use_mfma == 2)) {
     const int wr = (wmax + 2) & ~1;
     int per_wave = 2 * ((8 * wr + 127) & ~127);
     int waves = 4;
