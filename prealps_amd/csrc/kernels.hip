@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(256) void k_bj_apply(
 // The window is kept as NT tiles of 16 rows in the C/D layout of v_mfma_f64_16x16x4 (lane l,
 // register r <-> tile row (l>>4) + 4r, panel column l&15).  Four pivots at a time: they are
 // the four rows of one register of the pivot tile, so once they are settled among themselves
-// that register *is* the B operand
+// (three ds_bpermute steps) that register *is* the B operand
 // Y[k = l>>4][j = l&15] of the rank-4 update  tile -= L[rows of tile][4 pivots] * Y  -- no
 // data movement.  The A operand is the band value of (row l&15 of the tile, pivot l>>4), one
 // LDS read per lane and tile.  Per step this costs a quarter of the v_readlane / v_fma_f64
@@ -1516,7 +1516,12 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
     // every band value this group needs, read with explicit ds_read_b64 + one wait: a
     // compiler-visible LDS read of an LDS-DMA target drains all outstanding VMEM first (the
     // chunk in flight), once per read
-    double ct[NT];
+    double ct[NT], cg[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {   // pivot a of the group against row hi of the group
+      const unsigned ad = (unsigned)(uintptr_t)(lds_void_ptr)(grec + (size_t)a * wr + min(max(hi - a - 1, 0), w));
+      asm volatile("ds_read_b64 %0, %1" : "=v"(cg[a]) : "v"(ad));
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const unsigned d1 = (unsigned)(16 * t + lo - 4 * r - hi - 1);
@@ -1524,23 +1529,35 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
       asm volatile("ds_read_b64 %0, %1" : "=v"(ct[t]) : "v"(ad));
     }
     if constexpr (NT == 4)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]));
     else if constexpr (NT == 6)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]));
     else
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]), "+v"(ct[6]), "+v"(ct[7]));
-    // the pivot tile takes the four pivots one after the other (A masked to one pivot per
-    // instruction, B re-read from the tile): this also settles the four rows among themselves,
-    // with no lane-crossing move
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]), "+v"(ct[6]), "+v"(ct[7]));
+    // the four pivots among themselves: the value of pivot a (lanes hi == a) goes down to the
+    // rows below it with ds_bpermute (issued by hand: behind an LDS-DMA the compiler would
+    // drain all outstanding VMEM in front of every DS instruction); the matrix pipe is the
+    // bottleneck of this kernel, so these three steps are not worth four masked MFMAs
+    double y = acc[TP][r];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-      acc[TP] = __builtin_amdgcn_mfma_f64_16x16x4f64((hi == a) ? -ct[0] : 0.0, acc[TP][r], acc[TP], 0, 0, 0);
-    // the other tiles the band reaches: one rank-4 update each
-    // (tiles past the band meet the record's zero slot: no branch)
-    const double y = acc[TP][r];
+    for (int a = 0; a < 3; ++a) {
+      const int from = (a * 16 + lo) * 4;
+      int ylo = __double2loint(y), yhi = __double2hiint(y), plo, phi;
+      asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(plo), "=&v"(phi) : "v"(from), "v"(ylo), "v"(yhi));
+      const double ya = __hiloint2double(phi, plo);
+      y = fma((hi > a) ? -cg[a] : 0.0, ya, y);
+    }
+    acc[TP][r] = y;
+    // rank-4 update of every tile the band reaches (rows of this group in the pivot tile: done)
+    // (tiles past the band meet the record's zero slot: no branch -- a uniform skip makes the
+    // compiler merge register states with thousands of moves)
 #pragma unroll
-    for (int t = 1; t < NT; ++t)
-      acc[(TP + t) % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ct[t], y, acc[(TP + t) % NT], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) {
+      double cf = ct[t];
+      if (t == 0 && (lo >> 2) == r) cf = 0.0;
+      acc[(TP + t) % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cf, y, acc[(TP + t) % NT], 0, 0, 0);
+    }
   }
   asm volatile("" ::: "memory");   // the next LDS-DMA into these buffers stays behind the reads
   // the tile is solved: scale, store, and take the tile NT further down
@@ -1950,13 +1967,14 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
                      const double* in, double* out) {
   // chunks of 8 steps: measured equal or better than 16 and 32 (smaller LDS footprint,
   // more workgroups per CU)
-  // The matrix-core sweep (k_bj_mfma, bands up to 112) costs 240-270 us per apply whatever the
-  // panel width (latency: three wavefronts per SIMD, four dependent MFMAs per group of pivots),
-  // the register recurrence 172 / 246 / 443 us at 4 / 8 / 16 columns: so it takes the
-  // 16-column panels.  PREALPS_BJ_MFMA=0: never; 1: from 8 columns; 2: always.
+  // The matrix-core sweep (k_bj_mfma, bands up to 112) costs 225-260 us per apply whatever the
+  // panel width (latency: three wavefronts per SIMD, the chain of three lane moves and the
+  // pivot tile's MFMA per group of pivots), the register recurrence 172 / 246 / 443 us at
+  // 4 / 8 / 16 columns: so it takes the panels of 8 and 16 columns.
+  // PREALPS_BJ_MFMA=0: never; 2: always.
   static int use_mfma = -1;
-  if (use_mfma < 0) { const char* e = getenv("PREALPS_BJ_MFMA"); use_mfma = e ? atoi(e) : -1; if (use_mfma < 0) use_mfma = 3; }
-  if (wmax <= 112 && ((TS >= 16 && use_mfma == 3) || (TS >= 8 && use_mfma == 1) || use_mfma == 2)) {
+  if (use_mfma < 0) { const char* e = getenv("PREALPS_BJ_MFMA"); use_mfma = e ? atoi(e) : 1; }
+  if (wmax <= 112 && ((TS >= 8 && use_mfma == 1) || use_mfma == 2)) {
     const int wr = (wmax + 2) & ~1;
     int per_wave = 2 * ((8 * wr + 127) & ~127);
     int waves = 4;
