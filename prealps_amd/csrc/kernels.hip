@@ -1484,18 +1484,13 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
                                          double* __restrict__ dst, double* lds0, double* lds1, int lane) {
   const int lo = lane & 15, hi = lane >> 4;
   const double* cur = lds0;
-  // what the hand-over at the end needs is fetched now: 1/L(j,j) of the tile's rows and the
-  // ids of the rows that take over the slot (their values follow once the ids have landed)
+  // what the hand-over at the end needs -- 1/L(j,j) of the tile's rows, the ids of the rows
+  // that take over the slot, then their values -- is fetched right *behind* the two chunk
+  // waits, so that every s_waitcnt vmcnt(0) only meets loads issued eight steps earlier
   double idl[4], nxt[4];
   int nid[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    // branch-free: rows past the end read row 0 / entry 0 and are masked when used
-    const int j = 16 * g + hi + 4 * r, jn = j + 16 * NT;
-    idl[r] = invd[j < b ? j : 0];
-    nid[r] = iomap[jn < b ? jn : 0];
-    nxt[r] = 0.0;
-  }
+  for (int r = 0; r < 4; ++r) { idl[r] = 0.0; nid[r] = 0; nxt[r] = 0.0; }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if ((r & 1) == 0) {   // a new chunk of 8 steps starts with this group of four pivots
@@ -1503,7 +1498,14 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
       cur = (chunk & 1) ? lds1 : lds0;
       if ((chunk + 1) * 8 < b) bj_issue_chunk<8>(rec, wr, chunk + 1, (chunk & 1) ? lds0 : lds1, lane);
       ++chunk;
-      if (r == 0) {   // the ids have landed: the four row loads go out back to back
+      if (r == 0) {
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {   // branch-free: past the end, entry 0 (masked when used)
+          const int j = 16 * g + hi + 4 * r2, jn = j + 16 * NT;
+          idl[r2] = invd[j < b ? j : 0];
+          nid[r2] = iomap[jn < b ? jn : 0];
+        }
+      } else {              // the ids have landed: the four row loads go out back to back
         const double* sp[4];
 #pragma unroll
         for (int r2 = 0; r2 < 4; ++r2) sp[r2] = src + (rowbase + nid[r2]) * TS + (lo < TS ? lo : 0);
@@ -1967,7 +1969,7 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
                      const double* in, double* out) {
   // chunks of 8 steps: measured equal or better than 16 and 32 (smaller LDS footprint,
   // more workgroups per CU)
-  // The matrix-core sweep (k_bj_mfma, bands up to 112) costs 225-260 us per apply whatever the
+  // The matrix-core sweep (k_bj_mfma, bands up to 112) costs 210-250 us per apply whatever the
   // panel width (latency: three wavefronts per SIMD, the chain of three lane moves and the
   // pivot tile's MFMA per group of pivots), the register recurrence 172 / 246 / 443 us at
   // 4 / 8 / 16 columns: so it takes the panels of 8 and 16 columns.
