@@ -1155,6 +1155,53 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_h
   }
 }
 
+// 8-column panels: [V0 | V1] is one 16-wide A operand (four k-steps), Z uses half the tile.
+__global__ __launch_bounds__(WG) void k_update_z_mfma8(int m, int a_lo, int a_hi, int nc,
+                                                       const double* __restrict__ beta, int ldb,
+                                                       const double* __restrict__ V0,
+                                                       const double* __restrict__ V1,
+                                                       double* __restrict__ Z) {
+  constexpr int TS = 8;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+  double bneg[4];
+  bool von[4];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+    const int k = 4 * s2 + hi;                 // column of [V0 | V1]
+    const bool first = k < TS;
+    const int kk = first ? k : k - TS;
+    von[s2] = first ? kk < a_lo : kk < a_hi;
+    bneg[s2] = (von[s2] && lo < nc) ? -beta[(first ? kk : a_lo + kk) + ldb * lo] : 0.0;
+  }
+  const size_t ntile = ((size_t)m + 15) >> 4;
+  const size_t tstride = (size_t)gridDim.x * (WG / 64);
+  for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
+    const size_t r0 = t << 4;
+    mfma_d4 z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = r0 + hi + 4 * r;
+      z[r] = (row < (size_t)m && lo < TS) ? Z[row * TS + lo] : 0.0;
+    }
+    const size_t arow = r0 + lo;
+    const bool aok = arow < (size_t)m;
+    double a[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int k = 4 * s2 + hi;
+      a[s2] = (aok && von[s2]) ? (k < TS ? V0[arow * TS + k] : V1[arow * TS + k - TS]) : 0.0;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) z = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bneg[s2], z, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = r0 + hi + 4 * r;
+      if (row < (size_t)m && lo < nc) Z[row * TS + lo] = z[r];
+    }
+  }
+}
+
 template <int TS>
 __global__ __launch_bounds__(WG) void k_copy_cols(int m, int nc, const double* __restrict__ src,
                                                   double* __restrict__ dst) {
@@ -2220,6 +2267,11 @@ int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta,
     hipLaunchKernelGGL(k_update_z_mfma16, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
                        beta, ldb, V0, V1, Z);
     return kfail("k_update_z_mfma16");
+  }
+  if (ts == 8) {
+    hipLaunchKernelGGL(k_update_z_mfma8, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
+                       beta, ldb, V0, V1, Z);
+    return kfail("k_update_z_mfma8");
   }
   TS_DISPATCH(ts, hipLaunchKernelGGL((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
                                      cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z));
