@@ -275,8 +275,13 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
    * block): records of W = bj_wide_window(w) >= w + 64 doubles in window-slot order, the value
    * for target row i at column i mod W. */
   int maxR = pa_bj_max_R();
+  /* Bands above `wide_from` get one workgroup per block (k_bj_wide) instead of one wavefront
+   * (k_bj_apply / k_bj_mfma): always above 448, where the wavefront's registers end, and from
+   * 97 on when the blocks are too few to give every SIMD a wavefront -- a lone wavefront per
+   * SIMD is latency bound (measured on Poisson 100^3 with 512 blocks, w = 133: 1.6 ms). */
+  const int wide_from = np < 1024 ? pa_bj_factor_wmax() : 64 * maxR - 64;
   for (int q = 0; q < np; ++q) {
-    int wide = (bw[q] + 127) / 64 > maxR;
+    int wide = bw[q] > wide_from;
     long long reclen = wide ? bj_wide_window(bw[q]) : ((bw[q] + 2) & ~1);
     off[q + 1] = off[q] + (long long)nrows[q] * reclen;
     if (bw[q] > maxw) maxw = bw[q];
@@ -335,7 +340,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
         int x = item_part[it];
         int b = nrows[x], w = bw[x], r0 = row0[x];
         size_t ld = (size_t)w + 1;
-        int wide = (w + 127) / 64 > maxR;
+        int wide = w > wide_from;
         size_t reclen = wide ? (size_t)bj_wide_window(w) : (size_t)((w + 2) & ~1);
         const double* band = bands[x];
         double* f = sf + (off[x] - off[q]);
@@ -372,7 +377,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     s->nclass = 0;
     for (int q = 0; q < np; ++q) {
       int R = (bw[q] + 127) / 64, c;
-      if (R > maxR) { /* wide classes: -(register sets per lane) */
+      if (bw[q] > wide_from) { /* wide classes: -(register sets per lane) */
         int W = bj_wide_window(bw[q]);
         R = W <= 1024 ? -1 : (W <= 2048 ? -2 : -4);
       }
@@ -478,8 +483,8 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
           pa_rt_h2d(d_blist, blist, nbig * sizeof(int)) || pa_rt_h2d(d_fail, &fail, sizeof(int)) ||
           pa_k_bj_factor(d_slist, ns, wsmall, s->d_row0, s->d_nrows, s->d_bw, s->d_off, d_boff, d_band, s->d_Lf,
                          s->d_Lb, s->d_invd_f, s->d_invd_b, d_fail) ||
-          pa_k_bj_factor_big(d_blist, nbig, wbig, s->d_row0, s->d_nrows, s->d_bw, s->d_off, d_boff, d_band,
-                             s->d_Lf, s->d_Lb, s->d_invd_f, s->d_invd_b, d_fail) ||
+          pa_k_bj_factor_big(d_blist, nbig, wbig, wide_from, s->d_row0, s->d_nrows, s->d_bw, s->d_off, d_boff,
+                             d_band, s->d_Lf, s->d_Lb, s->d_invd_f, s->d_invd_b, d_fail) ||
           pa_rt_d2h(&fail, d_fail, sizeof(int)))
         rc = PA_FAIL("factorising the diagonal blocks on the device failed: %s", pa_rt_error());
       else if (fail > 0)

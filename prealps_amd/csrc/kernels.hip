@@ -2332,8 +2332,8 @@ int pa_k_scatter(size_t n, const long long* off, const double* val, double* dst)
   return kfail("k_scatter");
 }
 
-int pa_k_bj_factor_big(const int* list, int count, int wmax, const int* row0, const int* nrows, const int* bw,
-                       const long long* off, const long long* boff, double* band, double* Lf, double* Lb,
+int pa_k_bj_factor_big(const int* list, int count, int wmax, int wide_from, const int* row0, const int* nrows,
+                       const int* bw, const long long* off, const long long* boff, double* band, double* Lf, double* Lb,
                        double* invd_f, double* invd_b, int* fail) {
   if (count <= 0) return 0;
   int rc;
@@ -2342,7 +2342,7 @@ int pa_k_bj_factor_big(const int* list, int count, int wmax, const int* row0, co
   else rc = bj_factor_big_launch<4>(list, count, wmax, row0, nrows, bw, boff, band, fail);
   if (rc) return rc;
   hipLaunchKernelGGL(k_bj_layout_big, dim3(512, count), dim3(WG), 0, cur_stream(), list, row0, nrows, bw, off,
-                     boff, band, 64 * pa_bj_max_R() - 64, Lf, Lb, invd_f, invd_b);
+                     boff, band, wide_from, Lf, Lb, invd_f, invd_b);
   return kfail("k_bj_layout_big");
 }
 

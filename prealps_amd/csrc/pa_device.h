@@ -186,9 +186,10 @@ int pa_bj_factor_wmax(void);
 /* dst[off[e]] = val[e], e < n */
 int pa_k_scatter(size_t n, const long long* off, const double* val, double* dst);
 /* Wider bands (up to 4032): `band` diagonal-major per block (A(i, i-d) at boff + d*nrows + i),
- * factored in place (blocked, one workgroup per block), then laid out into Lf / Lb / invd. */
-int pa_k_bj_factor_big(const int* list, int count, int wmax, const int* row0, const int* nrows, const int* bw,
-                       const long long* off, const long long* boff, double* band, double* Lf, double* Lb,
+ * factored in place (blocked, one workgroup per block), then laid out into Lf / Lb / invd
+ * (records in window-slot order for bands above wide_from, else [d = 1..w | 0]). */
+int pa_k_bj_factor_big(const int* list, int count, int wmax, int wide_from, const int* row0, const int* nrows,
+                       const int* bw, const long long* off, const long long* boff, double* band, double* Lf, double* Lb,
                        double* invd_f, double* invd_b, int* fail);
 int pa_k_bj_factor(const int* list, int count, int wmax, const int* row0, const int* nrows, const int* bw,
                    const long long* off, const long long* boff, const double* band, double* Lf, double* Lb,
