@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- ECG iterations/s on MI355X (+ SpMM roofline, + CPU baseline).
+"""bench.py -- ECG iterations/s on MI355X (+ SpMM roofline, + CPU baseline, + parity line).
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under
-torch.distributed.run, one rank per GPU) prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).
+With --gpus N > 1 and no launcher environment (RANK unset) the script starts its own N
+ranks (`python -m torch.distributed.run --nproc-per-node N ...` as a child process, decided
+before anything touches the GPU) and relays their output; under a launcher it checks that
+WORLD_SIZE equals --gpus and exits non-zero otherwise.
 
 A step = one full ECG iteration of the reference driver loop
 (examples/test_ecg_prealps_op.c:208-221): Iterate(rci 0) -> stopping test ->
 block-Jacobi apply -> Iterate(rci 1) -> SpMM, through the C ABI of
 libprealps_hip.so.  Default workload = what BASELINE.json's metric is quoted on:
-3-D elasticity, n ~ 1M dofs (Q1 hexahedra on 70^3 nodes, N = 1,029,000,
+3-D elasticity, n ~ 1M dofs (the reference's Q1 element on 70^3 nodes, N = 1,029,000,
 nnz = 80,990,208), t = 4, block-Jacobi, fp64, inputs resident in HBM before the
-timed region.  `--workload poisson` runs BASELINE configs[1] (7-pt Poisson 100^3).  If the solve converges inside the timed region it
-is restarted from the same rhs (the restart is inside the timing).
+timed region.  `--workload poisson` runs BASELINE configs[1] (7-pt Poisson 100^3).  If the
+solve converges inside the timed region it is restarted from the same rhs (the restart is
+inside the timing).  After the timed region: the SpMM against the HBM roofline (HIP events on
+the library stream), the per-phase device times of the iteration in the layout of
+examples/test_ecg_bench_fused.c:300-336 (stderr + `phases`), and -- rank 0, N = 1 -- the CPU
+ports on a bounded sample with the parity line of BASELINE.md section 3 (max relative
+difference of the first residuals, GPU vs CPU oracle).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+ROUND = "r02"
 
 
 def parse():
@@ -37,11 +48,25 @@ def parse():
     ap.add_argument("--n", type=int, default=0, help="grid points (nodes) per side; default 100 (poisson) / 70 (elasticity)")
     ap.add_argument("--t", type=int, default=4, help="enlarging factor")
     ap.add_argument("--box", type=str, default="", help="subdomain box in nodes; default 5,5,10 (poisson) / 2,4,8 (elasticity)")
+    ap.add_argument("--nparts", type=int, default=0,
+                    help="number of subdomains from the library's own graph partitioner instead of --box")
     ap.add_argument("--alg", type=str, default="odir", choices=["odir", "omin", "fused"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--spmm-reps", type=int, default=50)
+    ap.add_argument("--phase-iters", type=int, default=20, help="iterations timed phase by phase (hipEvents)")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """--gpus N without a launcher: become the launcher.  Nothing has touched the GPU yet."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def run_iterations(prob, e, rhs, L, nsteps, state):
@@ -55,11 +80,35 @@ def run_iterations(prob, e, rhs, L, nsteps, state):
     state["last_iters"], state["last_res"] = last_it.value, last_res.value
 
 
+PHASE_KEYS = ("operator", "precond", "gram", "trsm", "update", "small", "comm")
+
+
+def phase_table(title, ranks, iters, ph, ecg_fields, out=sys.stderr):
+    """The report of examples/test_ecg_bench_fused.c:300-336 for one run."""
+    print("=== %s ===" % title, file=out)
+    print("\t# ranks     : %d" % ranks, file=out)
+    print("\titerations  : %d" % iters, file=out)
+    print("\ttotal   : %e s" % ph.get("total", float("nan")), file=out)
+    print("\toperator: %e s" % ph.get("operator", float("nan")), file=out)
+    print("\tprecond : %e s" % ph.get("precond", float("nan")), file=out)
+    for k in ("tot_t", "comm_t", "trsm_t", "gemm_t", "potrf_t", "pstrf_t", "lapmt_t", "gesvd_t", "geqrf_t",
+              "ormqr_t", "copy_t"):
+        if k in ecg_fields:
+            print("\t%-8s: %e s" % ({"tot_t": "tot_iter"}.get(k, k[:-2]), ecg_fields[k]), file=out)
+    print("", file=out)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
     import torch
     import torch.distributed as dist
     # rehearsal knobs for a one-GPU box: PREALPS_BENCH_BACKEND=gloo PREALPS_BENCH_ONE_DEVICE=1
@@ -91,22 +140,34 @@ def main():
     else:
         rowptr, colind, val = gen.elasticity3d_csr(a.n)
         part, nparts = gen.box_partition_nodes(a.n, box)
-        N, wname = 3 * a.n ** 3, "Q1 3-D elasticity, %d^3 nodes, nu=0.25, stiff/soft inclusions (SURVEY A.3 structure)" % a.n
+        N, wname = 3 * a.n ** 3, ("Q1 3-D elasticity, %d^3 nodes, the reference's element matrix (nu=0.25), stiff/soft "
+                                  "inclusions (examples/test_ecg_petsc_ela.c:217-347)" % a.n)
+    if a.nparts > 0:
+        part, nparts = None, a.nparts      # the library's k-way graph partitioner (operator.c / partition.c)
     nnz = len(val)
     t_setup = time.perf_counter()
     prob = prealps_amd.EcgProblem(rowptr, colind, val, nparts, part, scale=True, device=local_rank,
-                                  distributed=distributed)
+                                  distributed=distributed, partitioner=(a.nparts > 0))
     L = prob.L
     prob.create_block_jacobi()
     check(L.preAlps_hip_prepare_operator(a.t), "prepare_operator")   # the SpMM plan is part of the setup
     t_setup = time.perf_counter() - t_setup
+    if distributed:
+        # every rank must be on the same binding, and for the nccl backend it has to be the native one
+        kinds = [None] * world
+        dist.all_gather_object(kinds, prob.comm_kind)
+        if len(set(kinds)) != 1:
+            raise SystemExit("bench.py: ranks disagree on the communication binding: %s" % kinds)
+        if backend == "nccl" and prob.comm_kind != "rccl" and not os.environ.get("PREALPS_COMM"):
+            raise SystemExit("bench.py: the native RCCL binding is unavailable (got %s)" % prob.comm_kind)
     rhs = prob.reference_rhs()
     alg = {"odir": pl.ORTHODIR, "omin": pl.ORTHOMIN, "fused": pl.ORTHODIR_FUSED}[a.alg]
     if alg == pl.ORTHODIR_FUSED:
         raise SystemExit("bench.py times the two-phase RCI loop; use --alg odir|omin")
     e = prob.new_ecg(a.t, alg, pl.NO_BS_RED, 1e-5, 100000)
     rci = C.c_int(0)
-    check(L.preAlps_ECGInitialize(C.byref(e), rhs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(rci)), "ECGInitialize")
+    prhs = rhs.ctypes.data_as(C.POINTER(C.c_double))
+    check(L.preAlps_ECGInitialize(C.byref(e), prhs, C.byref(rci)), "ECGInitialize")
     check(L.preAlps_BlockJacobiApply(e.R, e.P), "BlockJacobiApply")
     check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
     state = {"rci": rci, "restarts": 0, "last_iters": 0, "last_res": float("nan")}
@@ -130,8 +191,33 @@ def main():
         dt = float(tt.item())
     its = a.steps / dt
 
+    # ---- the same loop phase by phase: hipEvent pairs around every phase (one stream sync each,
+    #      so this is a separate, slower pass), accumulated by the library and in preAlps_ECG_t
+    phases, ecg_fields = {}, {}
+    if a.phase_iters > 0:
+        for k in ("tot_t", "comm_t", "trsm_t", "gemm_t", "potrf_t", "copy_t"):
+            setattr(e, k, 0.0)
+        L.preAlps_hip_timing(1)
+        L.preAlps_hip_timing_reset()
+        barrier()
+        tp0 = time.perf_counter()
+        run_iterations(prob, e, rhs, L, a.phase_iters, state)
+        barrier()
+        phases["total"] = time.perf_counter() - tp0
+        L.preAlps_hip_timing(0)
+        sec = C.c_double()
+        for k in PHASE_KEYS:
+            L.preAlps_hip_get_time(k.encode(), C.byref(sec))
+            phases[k] = sec.value
+        ecg_fields = {k: getattr(e, k) for k in ("tot_t", "comm_t", "trsm_t", "gemm_t", "potrf_t", "pstrf_t",
+                                                 "lapmt_t", "gesvd_t", "geqrf_t", "ormqr_t", "copy_t")}
+        if distributed:   # MPI_Allreduce(MAX) of the reference's report
+            keys = sorted(phases)
+            tt = torch.tensor([phases[k] for k in keys], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            phases = dict(zip(keys, [float(v) for v in tt.tolist()]))
+
     # ---- dominant kernel (SpMM) against the HBM roofline: HIP events on the library stream
-    ts = L.preAlps_hip_panel_stride(a.t)
     m_loc, nnz_loc = int(prob.stat("rows_local")), int(prob.stat("nnz_local"))
     halo = int(prob.stat("halo_rows"))
     sec = C.c_double()
@@ -169,21 +255,31 @@ def main():
     # counters cannot be read from inside the process, so the committed summary is quoted when
     # the workload is the one it was collected on.
     traffic, traffic_src = None, None
-    profiled = {("elasticity", 70, 4, "2,4,8"): "r01_pmc_hbm_traffic_elasticity.json",
-                ("poisson", 100, 4, "5,5,10"): "r01_pmc_hbm_traffic_poisson.json"}
-    pmc = profiled.get((a.workload, a.n, a.t, a.box))
-    if world == 1 and pmc and os.path.exists(os.path.join(ROOT, "profiles", pmc)):
-        with open(os.path.join(ROOT, "profiles", pmc)) as f:
-            traffic = json.load(f)["k_spmm"]["traffic_bytes_per_launch"]
-        traffic_src = "profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)" % pmc
+    profiled = {("elasticity", 70, 4, "2,4,8"): "pmc_hbm_traffic_elasticity.json",
+                ("poisson", 100, 4, "5,5,10"): "pmc_hbm_traffic_poisson.json"}
+    pmc = profiled.get((a.workload, a.n, a.t, a.box)) if a.nparts == 0 else None
+    if world == 1 and pmc:
+        for rnd in (ROUND, "r01"):
+            path = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, pmc))
+            if os.path.exists(path):
+                with open(path) as f:
+                    traffic = json.load(f)["k_spmm"]["traffic_bytes_per_launch"]
+                traffic_src = "profiles/%s_%s (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)" % (rnd, pmc)
+                break
+    halo_rows = [halo]
+    if distributed:
+        halo_rows = [None] * world
+        dist.all_gather_object(halo_rows, halo)
+    per_it = {k: 1e6 * v / a.phase_iters for k, v in phases.items()} if phases else {}
     out = {
         "metric": "ECG iters/sec + SpMM HBM GB/s (% roofline), 3D-elasticity n~1M t=4",
         "value": its, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s (N=%d, nnz=%d), ECG %s + block-Jacobi, t=%d, tol 1e-5" % (wname, N, nnz, a.alg, a.t),
-                   "nparts": int(nparts), "subdomain_box": list(box), "parallelism": "rows x%d" % world,
-                   "comm": prob.comm_kind,
+                   "nparts": int(nparts), "partition": "library k-way" if a.nparts > 0 else "boxes of %s nodes" % (list(box),),
+                   "parallelism": "rows x%d" % world,
+                   "comm": prob.comm_kind, "halo_rows_per_rank": halo_rows,
                    "restarts_in_timed_region": state["restarts"],
                    "iterations_to_converge": state["last_iters"], "setup_seconds": t_setup,
                    "setup_breakdown_s": {k: prob.stat("setup_" + k + "_s") for k in ("build", "plan", "bj_factor", "bj_layout")},
@@ -198,7 +294,14 @@ def main():
                      "note": "each timed launch follows one preconditioner apply (cache state of the solver loop)"},
         "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "factor_bytes": prob.stat("bj_factor_bytes"),
                          "achieved_GBs": bj_bytes / bj_s / 1e9},
+        "phases": {"iterations": a.phase_iters, "device_us_per_iteration": per_it,
+                   "ecg_struct_timers_s": ecg_fields,
+                   "note": "hipEvent pairs per phase (max over ranks); dense = gram + trsm + update + small; the pass "
+                           "syncs after every phase, so its total is above ms_per_step"},
     }
+    if rank == 0 and phases:
+        phase_table("ODIR on %d x MI355X (device time, %d iterations)" % (world, a.phase_iters)
+                    if a.alg == "odir" else "OMIN on %d x MI355X" % world, world, a.phase_iters, phases, ecg_fields)
 
     # ---- CPU baseline on the host cores, rank 0, N=1.  Two ports of the same algorithm are timed on
     #      a bounded sample and the FASTER one is reported: (a) oracle/ecg_oracle.c, plain C + OpenMP,
@@ -208,13 +311,24 @@ def main():
         from oracle import oracle as O
         from oracle import mkl_path as M
         import scipy.sparse as sp
+        # the first residuals of a fresh solve on the GPU (same rhs, same partition) for the parity line
+        gpu = prob.solve(rhs, a.t, ortho_alg=alg, max_iter=a.cpu_iters)
         A = sp.csr_matrix((val, colind.astype(np.int32), rowptr), shape=(N, N))
-        B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, nparts)
+        B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), prob.part_vector(), nparts)
         rhs_cpu = O.reference_rhs(rowpos)
         tf0 = time.perf_counter()
         ecg = O.ECG(B, rowpos, a.t, O.ORTHODIR if a.alg == "odir" else O.ORTHOMIN, O.NO_BS_RED, 1e-5, a.cpu_iters)
         tfac = time.perf_counter() - tf0
         r = ecg.solve(rhs_cpu)
+        k = min(len(gpu.res), len(r["res"]))
+        rel = np.abs(gpu.res[:k] - r["res"][:k]) / np.abs(r["res"][:k])
+        out["parity"] = {"max_rel_diff_res": float(rel.max()) if k else None, "iterations_compared": int(k),
+                         "normb_rel_diff": abs(gpu.normb - r["normb"]) / r["normb"],
+                         "gpu_res": [float(x) for x in gpu.res[:k]], "cpu_res": [float(x) for x in r["res"][:k]],
+                         "note": "residual norm after each of the first iterations, HIP path vs oracle/ecg_oracle.c "
+                                 "on the same matrix, partition and rhs (BASELINE.md section 3)"}
+        phase_table("ODIR on the host CPU, C/OpenMP port (%d threads)" % O.lib().orc_num_threads(), 1, r["iters"],
+                    {"total": r["t_total"], "operator": r["t_op"], "precond": r["t_prec"]}, {})
         cands = [(r["iters"] / r["t_total"], O.lib().orc_num_threads(),
                   "C/OpenMP port (oracle/ecg_oracle.c): %d iterations, operator %.3fs precond %.3fs of %.3fs, "
                   "factorisation %.1fs outside the rate" % (r["iters"], r["t_op"], r["t_prec"], r["t_total"], tfac))]
@@ -222,6 +336,9 @@ def main():
             try:
                 e_cpu = M.MklEcg(B, rowpos, a.t, 1e-5, a.cpu_iters, threads=min(os.cpu_count() or 1, 128))
                 rm = e_cpu.solve(rhs_cpu)
+                phase_table("ODIR on the host CPU, MKL kernels (%d threads)" % int(rm["threads"]), 1, rm["iters"],
+                            {"total": rm["t_total"], "operator": rm["t_op"], "precond": rm["t_prec"]},
+                            {"gemm_t": rm["t_dense"]})
                 cands.append((rm["iters"] / rm["t_total"], int(rm["threads"]),
                               "MKL kernels (mkl_dcsrmm %.3fs, PARDISO solves %.3fs, BLAS dense %.3fs of %.3fs for %d "
                               "iterations, PARDISO factorisation %.1fs outside the rate)"
@@ -238,6 +355,7 @@ def main():
                                "host_cores_online": os.cpu_count()}
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     prob.close()
     if distributed:
         dist.destroy_process_group()

@@ -54,6 +54,7 @@ int preAlps_hip_set_comm(preAlps_allreduce_fn allreduce,
 /* Built-in hooks: RCCL (ncclAllReduce / grouped ncclSend+ncclRecv over xGMI) on the
  * library stream.  Rank 0 creates the 128-byte id, the launcher broadcasts it, every
  * rank calls preAlps_hip_rccl_init (which also does set_world + set_comm). */
+int preAlps_hip_rccl_available(void);   /* 0: librccl.so loads; ranks vote on this before the collective init */
 int preAlps_hip_rccl_unique_id(char* id128);
 int preAlps_hip_rccl_init(const char* id128, int rank, int size);
 /* Collective: checks the installed hooks with one all-reduce and one ring exchange. */
@@ -70,6 +71,13 @@ int preAlps_hip_comm_selftest(void);
 int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd,
                                  const double* val, int nparts, const int* part,
                                  int scale);
+/* k-way partition of the adjacency graph of a square matrix with a structurally symmetric
+ * pattern (0-based CSR, diagonal stored) into nparts compact, balanced parts:
+ * part[i] in [0, nparts) for every row i.  This is what the library calls in place of the
+ * reference's METIS_PartGraphKway (utils/cplm_core/cplm_matcsr_core.c:394-457); consecutive
+ * part ids are neighbouring regions, so a process that owns a range of ids owns a compact
+ * piece of the domain.  Host code: needs no GPU. */
+int preAlps_hip_partition_kway(int N, const int* rowPtr, const int* colInd, int nparts, int* part);
 /* Cut the SpMM plan (slices, LDS staging lists) for this enlarging factor now rather than
  * inside the first preAlps_BlockOperator call; optional. */
 int preAlps_hip_prepare_operator(int enlFac);

@@ -279,7 +279,19 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
    * (k_bj_apply / k_bj_mfma): always above 448, where the wavefront's registers end, and from
    * 97 on when the blocks are too few to give every SIMD a wavefront -- a lone wavefront per
    * SIMD is latency bound (measured on Poisson 100^3 with 512 blocks, w = 133: 1.6 ms). */
-  const int wide_from = np < 1024 ? pa_bj_factor_wmax() : 64 * maxR - 64;
+  int wide_from = np < 1024 ? pa_bj_factor_wmax() : 64 * maxR - 64;
+  {
+    /* PREALPS_BJ_WIDE_FROM = first band that is NOT given to a single wavefront, minus one
+     * (tests use it to reach both dispatches on small problems).  The device factorisation lays
+     * out window-slot records only for bands above pa_bj_factor_wmax(), and a wavefront's
+     * registers end at 64 * maxR - 64. */
+    const char* e = getenv("PREALPS_BJ_WIDE_FROM");
+    if (e && *e) {
+      wide_from = atoi(e);
+      if (wide_from < pa_bj_factor_wmax()) wide_from = pa_bj_factor_wmax();
+      if (wide_from > 64 * maxR - 64) wide_from = 64 * maxR - 64;
+    }
+  }
   for (int q = 0; q < np; ++q) {
     int wide = bw[q] > wide_from;
     long long reclen = wide ? bj_wide_window(bw[q]) : ((bw[q] + 2) & ~1);

@@ -54,6 +54,7 @@ int nfail(ncclResult_t r, const char* what) {
 extern "C" {
 
 const char* pa_rccl_error(void) { return g_err; }
+int pa_rccl_available(void) { return load_api(); }
 
 /* 128 bytes to be broadcast by the caller's launcher (torch.distributed, MPI, ...). */
 int pa_rccl_unique_id(char* id128) {
@@ -84,6 +85,11 @@ int pa_rccl_allreduce(void* ctx, double* buf, int count) {
                "ncclAllReduce");
 }
 
+/* One communicator serves both streams: the send/recv group goes to the side stream only after
+ * that stream has waited for an event recorded on the main stream behind the previous
+ * collective (operator.c: ev_packed), and the next all-reduce on the main stream comes after
+ * the main stream has waited for the exchange (ev_halo) -- the operations on the communicator
+ * are totally ordered by these events, never concurrent. */
 int pa_rccl_exchange(void* ctx, const double* send, const int* send_counts, double* recv,
                      const int* recv_counts, const int* peers, int npeers) {
   (void)ctx;

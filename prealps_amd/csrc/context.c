@@ -118,6 +118,11 @@ int preAlps_hip_set_comm(preAlps_allreduce_fn allreduce, preAlps_exchange_fn exc
 }
 /* Native binding: RCCL on the library stream.  The 128-byte id comes from rank 0
  * (preAlps_hip_rccl_unique_id) and is broadcast by whatever launched the processes. */
+/* 0 when librccl.so and every entry point this library uses can be loaded (no communicator yet). */
+int preAlps_hip_rccl_available(void) {
+  if (pa_rccl_available()) return PA_FAIL("%s", pa_rccl_error());
+  return 0;
+}
 int preAlps_hip_rccl_unique_id(char* id128) {
   if (pa_rccl_unique_id(id128)) return PA_FAIL("%s", pa_rccl_error());
   return 0;
@@ -203,13 +208,17 @@ void pa_time_begin(int key) {
   if (!g_timing || !g_ev0) return;
   if (g_time_depth++ == 0) pa_rt_event_record(g_ev0);
 }
-void pa_time_end(int key) {
-  if (!g_timing || !g_ev0) return;
+/* Returns the device seconds of the region that just closed, or -1 when timing is off or the
+ * region is nested inside another one (the outermost region owns the event pair). */
+double pa_time_end(int key) {
+  if (!g_timing || !g_ev0) return -1.0;
   if (--g_time_depth == 0) {
     pa_rt_event_record(g_ev1);
     double s = pa_rt_event_elapsed_s(g_ev0, g_ev1);
     if (s > 0) g_times[key] += s;
+    return s > 0 ? s : 0.0;
   }
+  return -1.0;
 }
 static void* g_sw0 = NULL;
 static void* g_sw1 = NULL;

@@ -31,6 +31,14 @@
 
 #define PA_ECG_MAGIC 0x45434731u
 
+/* The reference brackets every BLAS / MPI call with MPI_Wtime (ecg.c:316-320 ...).  Launches
+ * are asynchronous here, so the host clock only sees the enqueue; with preAlps_hip_timing(1)
+ * the phase's hipEvent pair is read instead (one stream sync per phase) and the timer fields
+ * of preAlps_ECG_t hold device time, which is what preAlps_ECGPrint then reports. */
+#define TIC(key) do { pa_time_begin(key); t0 = pa_wtime(); } while (0)
+#define TAC(key, field) \
+  do { double d_ = pa_time_end(key); ecg->field += d_ >= 0.0 ? d_ : pa_wtime() - t0; } while (0)
+
 typedef struct {
   unsigned magic;
   int ts, T, m;
@@ -196,11 +204,12 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
   free(r0);
   if (rc) return PA_FAIL("%s", pa_rt_error());
   if (pa_world_size() > 1) {
-    double t0 = pa_wtime();
+    double t0;
+    TIC(PA_T_COMM);
     PA_CHECK(pa_rt_h2d(pv->d_res2, &nb2, sizeof(double)));
     if (pa_allreduce(pv->d_res2, 1)) return 1;
     PA_CHECK(pa_rt_d2h(&nb2, pv->d_res2, sizeof(double)));
-    ecg->comm_t += pa_wtime() - t0;
+    TAC(PA_T_COMM, comm_t);
   }
   ecg->normb = sqrt(nb2);
   ecg->res = 1.0; ecg->iter = 0; ecg->bs = t; ecg->kbs = ecg->V->info.n;
@@ -254,9 +263,10 @@ static int stopping_begin(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
    * already wrote it to the pinned words the host reads */
   if (!single || pv->rtr_valid == 3) {
     double* src = (pv->rtr_valid == 2 && pv->lazy_ptr) ? pv->lazy_ptr : pv->d_res2;
-    double t0 = pa_wtime();
+    double t0;
+    TIC(PA_T_COMM);
     if (pa_allreduce(src, 1)) return 1;
-    ecg->comm_t += pa_wtime() - t0;
+    TAC(PA_T_COMM, comm_t);
     PA_CHECK(pa_rt_d2h_async(pv->h_pin, src, 2 * sizeof(double)));
   }
   pv->rtr_valid = 0;
@@ -293,34 +303,26 @@ int preAlps_ECGStoppingCriterion(preAlps_ECG_t* ecg, int* stop) {
 static int a_orthonormalise_and_alpha(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
   int m = pv->m, ts = pv->ts;
   double t0;
-  pa_time_begin(PA_T_GRAM);
-  t0 = pa_wtime();
+  TIC(PA_T_GRAM);
   PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, NULL, ecg->P->val, pv->d_partials, t, 0, t, pv->d_mu, t,
                             0, 0, NULL, NULL, NULL));
-  ecg->gemm_t += pa_wtime() - t0;
-  pa_time_end(PA_T_GRAM);
-  t0 = pa_wtime();
+  TAC(PA_T_GRAM, gemm_t);
+  TIC(PA_T_COMM);
   if (pa_allreduce(pv->d_mu, t * t)) return 1;
-  ecg->comm_t += pa_wtime() - t0;
-  pa_time_begin(PA_T_SMALL);
-  t0 = pa_wtime();
+  TAC(PA_T_COMM, comm_t);
+  TIC(PA_T_SMALL);
   PA_CHECK(pa_k_potrf(pv->d_mu, t, pv->d_info));
-  ecg->potrf_t += pa_wtime() - t0;
-  pa_time_end(PA_T_SMALL);
-  pa_time_begin(PA_T_TRSM);
-  t0 = pa_wtime();
+  TAC(PA_T_SMALL, potrf_t);
+  TIC(PA_T_TRSM);
   PA_CHECK(pa_k_trsm(m, ts, t, pv->d_mu, ecg->P->val, ecg->AP->val));
-  ecg->trsm_t += pa_wtime() - t0;
-  pa_time_end(PA_T_TRSM);
-  pa_time_begin(PA_T_GRAM);
-  t0 = pa_wtime();
+  TAC(PA_T_TRSM, trsm_t);
+  TIC(PA_T_GRAM);
   PA_CHECK(pa_k_gram_finish(m, ts, ecg->P->val, NULL, ecg->R->val, pv->d_partials, ecg->alpha->info.m, 0,
                             ecg->alpha->info.n, pv->d_alpha, ecg->alpha->info.lda, 0, 0, NULL, NULL, NULL));
-  ecg->gemm_t += pa_wtime() - t0;
-  pa_time_end(PA_T_GRAM);
-  t0 = pa_wtime();
+  TAC(PA_T_GRAM, gemm_t);
+  TIC(PA_T_COMM);
   if (pa_allreduce(pv->d_alpha, ecg->alpha->info.lda * ecg->alpha->info.n)) return 1;
-  ecg->comm_t += pa_wtime() - t0;
+  TAC(PA_T_COMM, comm_t);
   return 0;
 }
 
@@ -333,54 +335,47 @@ static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
   int nb = 0, m = pv->m, ts = pv->ts, T = ecg->enlFac;
   int single = pa_world_size() == 1;
   double* buf = pv->d_q; /* (t+T) x t */
-  double t0 = pa_wtime();
-  pa_time_begin(PA_T_GRAM);
+  double t0;
+  TIC(PA_T_GRAM);
   if (single) {
     /* nothing to reduce across processes: the Gram kernel's last workgroup sums the partial
      * blocks and factors them right away */
     PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, t, T, t, buf, t + T,
                               t, T, pv->d_mu, pv->d_alpha, pv->d_info));
-    pa_time_end(PA_T_GRAM);
-    ecg->gemm_t += pa_wtime() - t0;
+    TAC(PA_T_GRAM, gemm_t);
   } else {
     PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, t, T, t, buf, t + T,
                               0, 0, NULL, NULL, NULL));
-    pa_time_end(PA_T_GRAM);
-    ecg->gemm_t += pa_wtime() - t0;
-    t0 = pa_wtime();
+    TAC(PA_T_GRAM, gemm_t);
+    TIC(PA_T_COMM);
     if (pa_allreduce(buf, (t + T) * t)) return 1;
-    ecg->comm_t += pa_wtime() - t0;
-    t0 = pa_wtime();
-    pa_time_begin(PA_T_SMALL);
+    TAC(PA_T_COMM, comm_t);
+    TIC(PA_T_SMALL);
     PA_CHECK(pa_k_potrf_alpha(buf, t, T, pv->d_mu, pv->d_alpha, pv->d_info));
-    pa_time_end(PA_T_SMALL);
-    ecg->potrf_t += pa_wtime() - t0;
+    TAC(PA_T_SMALL, potrf_t);
   }
-  t0 = pa_wtime();
-  pa_time_begin(PA_T_UPDATE);
+  TIC(PA_T_UPDATE);
   /* the slot right behind beta: free once the kernel has read U from it (Odir: d_mu) */
   pv->lazy_ptr = pv->lazy_stop ? pv->d_beta + (size_t)ecg->beta->info.lda * ecg->beta->info.n : NULL;
   PA_CHECK(pa_k_trsm_update(m, ts, t, ecg->X->info.n, pv->d_mu, pv->d_alpha, ecg->P->val, ecg->AP->val,
                             pv->d_X, pv->d_R, pv->d_rtr_part, &nb, T, pv->lazy_ptr ? pv->lazy_ptr : pv->d_res2,
                             pv->d_info, single ? pv->h_pin : NULL));
   pv->rtr_nblk = nb;
-  pa_time_end(PA_T_UPDATE);
+  TAC(PA_T_UPDATE, trsm_t);
   pv->rtr_valid = 2;
-  ecg->trsm_t += pa_wtime() - t0;
   return 0;
 }
 
 /* X += P alpha ; R -= AP alpha (ecg.c:337-338, :500-501) + residual norms */
 static int update_iterate(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
-  double t0 = pa_wtime();
-  pa_time_begin(PA_T_UPDATE);
+  double t0;
+  TIC(PA_T_UPDATE);
   PA_CHECK(pa_k_update_xr(pv->m, pv->ts, ecg->P->info.n, ecg->X->info.n, pv->d_alpha, ecg->P->val,
                           ecg->AP->val, pv->d_X, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk, ecg->enlFac,
                           pv->d_res2, pv->d_info, pa_world_size() == 1 ? pv->h_pin : NULL));
-  pa_time_end(PA_T_UPDATE);
+  TAC(PA_T_UPDATE, gemm_t);
   pv->rtr_valid = 2;
   pv->lazy_ptr = NULL;
-  ecg->gemm_t += pa_wtime() - t0;
   return 0;
 }
 
@@ -412,14 +407,13 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   int T = ecg->enlFac;
   int kb = ecg->beta->info.m; /* rows of beta = columns of V in use */
   int a_lo = kb < T ? kb : T, a_hi = kb - a_lo;
-  double t0 = pa_wtime();
-  pa_time_begin(PA_T_GRAM);
+  double t0;
+  TIC(PA_T_GRAM);
   PA_CHECK(pa_k_gram_finish(pv->m, pv->ts, pv->buf_av[0], a_hi > 0 ? pv->buf_av[1] : NULL, pv->buf_z,
                             pv->d_partials, a_lo, a_hi, ecg->beta->info.n, pv->d_beta, ecg->beta->info.lda,
                             0, 0, NULL, NULL, NULL));
-  pa_time_end(PA_T_GRAM);
-  ecg->gemm_t += pa_wtime() - t0;
-  t0 = pa_wtime();
+  TAC(PA_T_GRAM, gemm_t);
+  TIC(PA_T_COMM);
   {
     int cnt = ecg->beta->info.lda * ecg->beta->info.n;
     if (pv->rtr_valid == 2 && pv->lazy_ptr == pv->d_beta + cnt) {
@@ -438,15 +432,13 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
       }
     }
   }
-  ecg->comm_t += pa_wtime() - t0;
-  t0 = pa_wtime();
-  pa_time_begin(PA_T_UPDATE);
+  TAC(PA_T_COMM, comm_t);
+  TIC(PA_T_UPDATE);
   int vn = ecg->V->info.n;
   int v_lo = vn < T ? vn : T, v_hi = vn - v_lo;
   PA_CHECK(pa_k_update_z(pv->m, pv->ts, v_lo, v_hi, ecg->Z->info.n, pv->d_beta, ecg->beta->info.lda,
                          pv->buf_v[0], pv->buf_v[1], pv->buf_z));
-  pa_time_end(PA_T_UPDATE);
-  ecg->gemm_t += pa_wtime() - t0;
+  TAC(PA_T_UPDATE, gemm_t);
   return 0;
 }
 
@@ -470,7 +462,7 @@ static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z
     t0 = pa_wtime();
     pa_sd_qr_q(t, hq);                         /* hq <- Q of the Householder QR of U */
     ecg->geqrf_t += pa_wtime() - t0;
-    t0 = pa_wtime();
+    TIC(PA_T_UPDATE);
     pa_sd_qt_times(t, nrhs, hq, ha);           /* alpha <- Q^T alpha */
     /* keep the first t1 rows, leading dimension t1 (mkl_dimatcopy, ecg.c:483) */
     double* packed = hq + (size_t)nrhs * nrhs;
@@ -480,7 +472,7 @@ static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z
     PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->P->val));
     PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->AP->val));
     if (with_Z) PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->Z->val));
-    ecg->ormqr_t += pa_wtime() - t0;
+    TAC(PA_T_UPDATE, ormqr_t);
     CPLM_MatDenseSetInfo(ecg->alpha, t1, nrhs, t1, nrhs, COL_MAJOR);
     pa_set_desc(ecg->P, M, t1, m, t1, ts);
     pa_set_desc(ecg->AP, M, t1, m, t1, ts);
@@ -538,31 +530,32 @@ int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
     if (ecg->bs_red == ADAPT_BS) {
       /* BF-Omin: G = P^T P -> pivoted Cholesky -> permute, P <- P U^-1 (ecg.c:361-393) */
       int nb = 0, rank = 0;
-      double t0 = pa_wtime();
+      double t0;
+      TIC(PA_T_GRAM);
       PA_CHECK(pa_k_gram(m, ts, ecg->P->val, NULL, ecg->P->val, pv->d_partials, &nb));
       PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, nrhs, 0, nrhs, pv->d_mu, nrhs));
-      ecg->gemm_t += pa_wtime() - t0;
-      t0 = pa_wtime();
+      TAC(PA_T_GRAM, gemm_t);
+      TIC(PA_T_COMM);
       if (pa_allreduce(pv->d_mu, nrhs * nrhs)) return 1;
-      ecg->comm_t += pa_wtime() - t0;
+      TAC(PA_T_COMM, comm_t);
       double* hg = pv->h_pin + 16;
       PA_CHECK(pa_rt_d2h_async(hg, pv->d_mu, (size_t)nrhs * nrhs * sizeof(double)));
       PA_CHECK(pa_rt_sync());
       t0 = pa_wtime();
       pa_sd_pstrf_upper(nrhs, hg, nrhs, ecg->iwork, &rank, -1.0);
       ecg->pstrf_t += pa_wtime() - t0;
-      t0 = pa_wtime();
+      TIC(PA_T_UPDATE);
       for (int j = 0; j < nrhs; ++j) pv->h_pin_i[j] = ecg->iwork[j] - 1;
       PA_CHECK(pa_rt_h2d(pv->d_piv, pv->h_pin_i, nrhs * sizeof(int)));
       PA_CHECK(pa_k_permute_cols(m, ts, nrhs, pv->d_piv, ecg->P->val));
-      ecg->lapmt_t += pa_wtime() - t0;
-      t0 = pa_wtime();
+      TAC(PA_T_UPDATE, lapmt_t);
       /* leading rank x rank block, leading dimension rank for the kernel */
       double* hu = hg + (size_t)nrhs * nrhs;
       for (int j = 0; j < rank; ++j) for (int i = 0; i < rank; ++i) hu[i + (size_t)rank * j] = hg[i + (size_t)nrhs * j];
       PA_CHECK(pa_rt_h2d(pv->d_q, hu, (size_t)rank * rank * sizeof(double)));
+      TIC(PA_T_TRSM);
       PA_CHECK(pa_k_trsm(m, ts, rank, pv->d_q, ecg->P->val, NULL));
-      ecg->trsm_t += pa_wtime() - t0;
+      TAC(PA_T_TRSM, trsm_t);
       t = rank;
       pa_set_desc(ecg->P, M, t, m, t, ts);
       pa_set_desc(ecg->AP, M, t, m, t, ts);
@@ -581,9 +574,9 @@ int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
   if (!pv) return PA_FAIL("solver not initialised");
   int m = pv->m, ts = pv->ts, nrhs = ecg->enlFac;
   int t = ecg->P->info.n;
-  double t0 = pa_wtime();
+  double t0;
   /* the four local Gram blocks, stacked [alpha | beta | mu | RtR] (ecg.c:554-560) */
-  pa_time_begin(PA_T_GRAM);
+  TIC(PA_T_GRAM);
   PA_CHECK(pa_k_gram_finish(m, ts, ecg->P->val, NULL, ecg->R->val, pv->d_partials, ecg->alpha->info.m, 0,
                             ecg->alpha->info.n, pv->d_alpha, ecg->alpha->info.lda, 0, 0, NULL, NULL, NULL));
   {
@@ -598,38 +591,31 @@ int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
    * already there, except on the first call */
   if (!pv->rtr_valid) PA_CHECK(pa_k_colnorm2(m, ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
   PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, ts, nrhs, pv->d_rtr, NULL));
-  pa_time_end(PA_T_GRAM);
-  ecg->gemm_t += pa_wtime() - t0;
-  t0 = pa_wtime();
+  TAC(PA_T_GRAM, gemm_t);
+  TIC(PA_T_COMM);
   if (pa_allreduce(pv->d_F, 5 * nrhs * nrhs)) return 1; /* the single reduction (ecg.c:563) */
-  ecg->comm_t += pa_wtime() - t0;
+  TAC(PA_T_COMM, comm_t);
   PA_CHECK(pa_rt_d2h_async(pv->h_pin, pv->d_rtr, sizeof(double)));
   PA_CHECK(pa_rt_sync());
   ecg->res = sqrt(pv->h_pin[0]);
   if (ecg->res < ecg->tol * ecg->normb || ecg->iter > ecg->maxIter) *rci_request = 1;
   else *rci_request = 0;
-  t0 = pa_wtime();
-  pa_time_begin(PA_T_SMALL);
+  TIC(PA_T_SMALL);
   /* mu = U^T U ; beta <- beta U^-1 ; alpha <- U^-T alpha ; beta(0:t,0:t) <- U^-T beta */
   PA_CHECK(pa_k_fused_small(pv->d_mu, t, nrhs, ecg->beta->info.m, ecg->beta->info.n, ecg->kbs,
                             pv->d_alpha, pv->d_beta, pv->d_info));
-  pa_time_end(PA_T_SMALL);
-  ecg->potrf_t += pa_wtime() - t0;
-  t0 = pa_wtime();
-  pa_time_begin(PA_T_TRSM);
+  TAC(PA_T_SMALL, potrf_t);
+  TIC(PA_T_TRSM);
   PA_CHECK(pa_k_trsm(m, ts, t, pv->d_mu, ecg->P->val, ecg->AP->val));
   PA_CHECK(pa_k_trsm(m, ts, ecg->Z->info.n, pv->d_mu, ecg->Z->val, NULL));
-  pa_time_end(PA_T_TRSM);
-  ecg->trsm_t += pa_wtime() - t0;
-  t0 = pa_wtime();
-  pa_time_begin(PA_T_UPDATE);
+  TAC(PA_T_TRSM, trsm_t);
+  TIC(PA_T_UPDATE);
   {
     int vn = ecg->V->info.n, v_lo = vn < nrhs ? vn : nrhs, v_hi = vn - v_lo;
     PA_CHECK(pa_k_update_z(m, ts, v_lo, v_hi, ecg->Z->info.n, pv->d_beta, ecg->beta->info.lda,
                            pv->buf_v[0], pv->buf_v[1], pv->buf_z));
   }
-  pa_time_end(PA_T_UPDATE);
-  ecg->gemm_t += pa_wtime() - t0;
+  TAC(PA_T_UPDATE, gemm_t);
   if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 1)) return 1;
   if (update_iterate(ecg, pv)) return 1;
   ecg->iter++;

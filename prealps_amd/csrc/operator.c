@@ -525,6 +525,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
       A->rowPtr[i + 1] = A->rowPtr[i] + l;
     }
     /* rows are independent: scale, renumber the columns and sort each one (threads as available) */
+    int dup_row = -1;   /* (benign race: any offending row will do for the message) */
 #pragma omp parallel
     {
       cv_t* buf = (cv_t*)malloc((maxlen ? maxlen : 1) * sizeof(cv_t));
@@ -538,14 +539,19 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
           if (l > 0 && buf[l].c < buf[l - 1].c) sorted = 0;
         }
         if (!sorted) qsort(buf, l, sizeof(cv_t), cmp_cv);
+        for (int q = 1; q < l; ++q) if (buf[q].c == buf[q - 1].c) dup_row = old;
         int base = A->rowPtr[i];
         for (int q = 0; q < l; ++q) { A->colInd[base + q] = buf[q].c; A->val[base + q] = buf[q].v; }
       }
       free(buf);
     }
+    if (dup_row >= 0) {
+      free(d); free(iperm);
+      return PA_FAIL("row %d holds the same column twice: sum duplicate entries before building the operator", dup_row);
+    }
   }
   TRACE("permute + sort rows");
-  free(d); free(iperm);
+  free(d);
   A->info.M = N; A->info.N = N; A->info.nnz = rowPtr[N]; A->info.m = m; A->info.n = N;
   A->info.lnnz = (int)lnnz; A->info.blockSize = 1; A->info.format = FORMAT_CSR;
   A->info.structure = UNSYMMETRIC;
@@ -568,31 +574,44 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   int* recv_by_proc = (int*)calloc(size, sizeof(int));
   for (int q = 0; q < halo; ++q)
     recv_by_proc[owner_of_part(part_of_row(in->rowPos, nparts, halo_cols[q]), nparts, size)]++;
-  o->npeers = 0;
-  for (int g = 0; g < size; ++g) if (recv_by_proc[g]) { o->peers[o->npeers] = g; o->recv_rows[o->npeers] = recv_by_proc[g]; o->npeers++; }
-  /* send lists by structural symmetry: my rows that touch a column owned by g */
-  int* send_idx = (int*)malloc((size_t)(halo ? halo : 1) * 8 * sizeof(int));
-  size_t send_cap = (size_t)(halo ? halo : 1) * 8;
+  /* Send lists, exactly: process g receives from us the rows of ours that occur as columns in
+   * ITS rows (ascending) -- which is how g numbers its halo slots.  Every process holds the
+   * whole matrix at build time, so this needs no communication and, unlike taking "our rows
+   * that touch a column of g", it stays right for a pattern that is not structurally symmetric
+   * (a `general` .mtx with explicit zeros dropped on one side). */
+  unsigned char* need = NULL;   /* need[g * m + i]: process g reads our local row i */
+  if (size > 1) {
+    need = (unsigned char*)calloc((size_t)size * (m ? m : 1), 1);
+    if (!need) { free(iperm); free(mark); free(recv_by_proc); return PA_FAIL("out of host memory for the halo plan"); }
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int i = 0; i < N; ++i) {
+      int r = iperm[i];
+      if (r >= lo && r < hi) continue;
+      unsigned char* ng = need + (size_t)owner_of_part(part_of_row(in->rowPos, nparts, r), nparts, size) * m;
+      for (int k = rowPtr[i]; k < rowPtr[i + 1]; ++k) {
+        int c = iperm[colInd[k]];
+        if (c >= lo && c < hi) ng[c - lo] = 1;   /* (all writers store the same value) */
+      }
+    }
+  }
+  free(iperm);
+  size_t send_cap = 1024;
+  int* send_idx = (int*)malloc(send_cap * sizeof(int));
   o->nsend = 0;
-  {
-    char* touches = (char*)malloc(m ? m : 1);
-    for (int pi = 0; pi < o->npeers; ++pi) {
-      int g = o->peers[pi];
-      int glo = in->rowPos[(int)((long long)g * nparts / size)];
-      int ghi = in->rowPos[(int)((long long)(g + 1) * nparts / size)];
-      memset(touches, 0, m ? m : 1);
-      for (int i = 0; i < m; ++i)
-        for (int k = A->rowPtr[i]; k < A->rowPtr[i + 1] && !touches[i]; ++k)
-          touches[i] = (A->colInd[k] >= glo && A->colInd[k] < ghi);
-      int cnt = 0;
-      for (int i = 0; i < m; ++i) if (touches[i]) {
+  o->npeers = 0;
+  for (int g = 0; g < size; ++g) {
+    int cnt = 0;
+    if (need && g != rank)
+      for (int i = 0; i < m; ++i) if (need[(size_t)g * m + i]) {
         if ((size_t)o->nsend + 1 > send_cap) { send_cap *= 2; send_idx = (int*)realloc(send_idx, send_cap * sizeof(int)); }
         send_idx[o->nsend++] = i; ++cnt;
       }
-      o->send_rows[pi] = cnt;
+    if (cnt || recv_by_proc[g]) {
+      o->peers[o->npeers] = g; o->recv_rows[o->npeers] = recv_by_proc[g]; o->send_rows[o->npeers] = cnt;
+      o->npeers++;
     }
-    free(touches);
   }
+  free(need);
   free(recv_by_proc);
   TRACE("peer lists");
   /* 5. device CSR with local column ids */
@@ -664,18 +683,30 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
   free(I); free(J); free(V); free(cnt);
   int* ci = (int*)malloc((size_t)tot * sizeof(int));
   double* vv = (double*)malloc((size_t)tot * sizeof(double));
+  /* repeated (i, j) entries are legal in coordinate files and mean their sum */
+  long long out = 0;
   for (int i = 0; i < M; ++i) {
-    qsort(ent + rp[i], rp[i + 1] - rp[i], sizeof(cv_t), cmp_cv);
-    for (int k = rp[i]; k < rp[i + 1]; ++k) { ci[k] = ent[k].c; vv[k] = ent[k].v; }
+    int k0 = rp[i], k1 = rp[i + 1];
+    qsort(ent + k0, k1 - k0, sizeof(cv_t), cmp_cv);
+    rp[i] = (int)out;
+    for (int k = k0; k < k1; ++k) {
+      if (k > k0 && ent[k].c == ci[out - 1]) vv[out - 1] += ent[k].v;
+      else { ci[out] = ent[k].c; vv[out] = ent[k].v; ++out; }
+    }
   }
+  rp[M] = (int)out;
   free(ent);
   *N_out = M; *rp_out = rp; *ci_out = ci; *v_out = vv;
   return 0;
 }
 
-/* The number of subdomains is PREALPS_NPARTS (default: the process count, as
- * in the reference); the partition is PREALPS_PARTITION_FILE (one part id per
- * line, e.g. METIS output) or contiguous blocks of rows. */
+/* The number of subdomains is PREALPS_NPARTS (default: the process count, as in the
+ * reference).  The partition comes from the library's k-way graph partitioner
+ * (partition.c), which stands where the reference calls METIS_PartGraphKway
+ * (utils/operator.c:77-97 -> utils/cplm_core/cplm_matcsr_core.c:394-457); or from
+ * PREALPS_PARTITION_FILE (one part id per line, e.g. METIS output); or, with
+ * PREALPS_PARTITION=contiguous, from contiguous blocks of rows (the partition the
+ * recorded reference runs of BASELINE.md used). */
 int preAlps_OperatorBuild(const char* matrixFilename, MPI_Comm comm) {
   (void)comm;
   size_t len = strlen(matrixFilename);
@@ -694,6 +725,13 @@ int preAlps_OperatorBuild(const char* matrixFilename, MPI_Comm comm) {
     for (int i = 0; i < N; ++i)
       if (fscanf(f, "%d", &part[i]) != 1) { fclose(f); free(part); free(rp); free(ci); free(v); return PA_FAIL("partition file %s is too short", pf); }
     fclose(f);
+  } else {
+    const char* how = getenv("PREALPS_PARTITION");
+    if (!(how && !strcmp(how, "contiguous")) && nparts > 1) {
+      if (nparts > N) { free(rp); free(ci); free(v); return PA_FAIL("invalid sizes N=%d nparts=%d", N, nparts); }
+      part = (int*)malloc((size_t)N * sizeof(int));
+      if (!part || preAlps_hip_partition_kway(N, rp, ci, nparts, part)) { free(part); free(rp); free(ci); free(v); return 1; }
+    }
   }
   rc = preAlps_OperatorBuildFromCSR(N, rp, ci, v, nparts, part, 1);
   free(part); free(rp); free(ci); free(v);

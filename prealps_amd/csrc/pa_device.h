@@ -40,6 +40,7 @@ int pa_rt_num_cus(void);
 
 /* ---- native RCCL hooks (comm_rccl.hip) --------------------------------- */
 const char* pa_rccl_error(void);
+int pa_rccl_available(void);
 int pa_rccl_unique_id(char* id128);
 int pa_rccl_init(const char* id128, int rank, int size);
 void pa_rccl_shutdown(void);

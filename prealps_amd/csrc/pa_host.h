@@ -36,7 +36,7 @@ int pa_exchange(const double* dev_send, const int* send_counts, double* dev_recv
 /* ---- phase timing ------------------------------------------------------- */
 enum { PA_T_OPERATOR, PA_T_PRECOND, PA_T_GRAM, PA_T_TRSM, PA_T_UPDATE, PA_T_SMALL, PA_T_COMM, PA_T_COUNT };
 void pa_time_begin(int key);
-void pa_time_end(int key);
+double pa_time_end(int key);   /* device seconds of the closed outermost region, else -1 */
 
 /* ---- operator state shared with block_jacobi.c / ecg.c ------------------ */
 typedef struct {

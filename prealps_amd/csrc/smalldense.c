@@ -116,6 +116,8 @@ int pa_sd_pstrf_upper(int n, double* A, int lda, int* piv, int* rank, double tol
   /* right-looking form: after step j the trailing block holds the Schur
    * complement, whose diagonal drives the pivot choice */
   double S[SD_MAX][SD_MAX]; /* full symmetric working copy */
+  if (n <= 0) { *rank = 0; return 0; }
+  S[0][0] = 0.0;
   for (int j = 0; j < n; ++j)
     for (int i = 0; i <= j; ++i) S[i][j] = S[j][i] = A[i + (size_t)lda * j];
   for (int i = 0; i < n; ++i) piv[i] = i + 1;

@@ -132,23 +132,31 @@ def bind_process_group(L, prefer=None):
     rank, size = dist.get_rank(), dist.get_world_size()
     if prefer == "rccl" and dist.get_backend() == "nccl":
         import torch
-        ok = 1
-        try:
-            buf = C.create_string_buffer(128)
-            if rank == 0:
-                check(L.preAlps_hip_rccl_unique_id(buf), "preAlps_hip_rccl_unique_id")
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def all_ok(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        # vote BEFORE the collective ncclCommInitRank: a rank that cannot load librccl or (rank 0)
+        # cannot create the id must not leave the others blocked inside it
+        buf = C.create_string_buffer(128)
+        ok = L.preAlps_hip_rccl_available() == 0
+        if ok and rank == 0:
+            ok = L.preAlps_hip_rccl_unique_id(buf) == 0
+        if not ok:
+            print("[prealps_amd] native RCCL hooks unavailable on rank %d (%s)" % (rank, L.preAlps_hip_last_error()))
+        if all_ok(ok):
             box = [bytes(buf.raw)]
             dist.broadcast_object_list(box, src=0)
-            check(L.preAlps_hip_rccl_init(box[0], rank, size), "preAlps_hip_rccl_init")
-            check(L.preAlps_hip_comm_selftest(), "preAlps_hip_comm_selftest")
-        except Exception as e:
-            ok = 0
-            print("[prealps_amd] native RCCL hooks unavailable on rank %d (%s)" % (rank, e))
-        # every rank must end up on the same binding: one failure sends all of them to the fallback
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            return "rccl", None
+            ok = L.preAlps_hip_rccl_init(box[0], rank, size) == 0
+            ok = ok and L.preAlps_hip_comm_selftest() == 0
+            if not ok:
+                print("[prealps_amd] native RCCL binding failed on rank %d (%s)" % (rank, L.preAlps_hip_last_error()))
+            # every rank must end up on the same binding: one failure sends all of them to the fallback
+            if all_ok(ok):
+                return "rccl", None
         if rank == 0:
             print("[prealps_amd] using the torch.distributed hooks on all ranks")
     hooks = DistributedHooks(L)
@@ -156,12 +164,26 @@ def bind_process_group(L, prefer=None):
     return "torch." + dist.get_backend(), hooks
 
 
+def partition_kway(rowptr, colind, nparts):
+    """preAlps_hip_partition_kway: the library's stand-in for METIS_PartGraphKway (host code)."""
+    L = _l.load()
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colind = np.ascontiguousarray(colind, dtype=np.int32)
+    part = np.empty(len(rowptr) - 1, dtype=np.int32)
+    check(L.preAlps_hip_partition_kway(len(part), _pi(rowptr), _pi(colind), int(nparts), _pi(part)),
+          "preAlps_hip_partition_kway")
+    return part
+
+
 class EcgProblem:
     """One operator + one block-Jacobi preconditioner (both process-global in
     the library, as in the reference) and solves on them."""
 
     def __init__(self, rowptr, colind, val, nparts, part=None, scale=True, device=None,
-                 distributed=False, use_torch_stream=False):
+                 distributed=False, use_torch_stream=False, partitioner=False):
+        """part: explicit partition vector; None = contiguous row blocks, or -- with
+        partitioner=True -- the library's k-way graph partitioner (what preAlps_OperatorBuild
+        uses where the reference calls METIS)."""
         self.L = L = _l.load()
         import os
         dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
@@ -180,21 +202,28 @@ class EcgProblem:
         val = np.ascontiguousarray(val, dtype=np.float64)
         self.N = len(rowptr) - 1
         p = None if part is None else np.ascontiguousarray(part, dtype=np.int32)
+        if p is None and partitioner:
+            p = partition_kway(rowptr, colind, nparts)
         check(L.preAlps_OperatorBuildFromCSR(self.N, _pi(rowptr), _pi(colind), _pd(val), int(nparts),
                                              None if p is None else _pi(p), 1 if scale else 0),
               "preAlps_OperatorBuildFromCSR")
         self._after_build()
 
     @classmethod
-    def from_mtx(cls, path, nparts=None, device=0):
-        """preAlps_OperatorBuild(file, comm) like the reference driver."""
+    def from_mtx(cls, path, nparts=None, device=0, partition=None):
+        """preAlps_OperatorBuild(file, comm) like the reference driver.  partition: None = the
+        library's graph partitioner (where the reference calls METIS), "contiguous" = row blocks."""
         import os
         self = cls.__new__(cls)
         self.L = L = _l.load()
-        self.hooks = None
+        self.hooks, self.comm_kind = None, "none"
         check(L.preAlps_hip_init(device), "preAlps_hip_init")
         if nparts is not None:
             os.environ["PREALPS_NPARTS"] = str(nparts)
+        if partition is None:
+            os.environ.pop("PREALPS_PARTITION", None)
+        else:
+            os.environ["PREALPS_PARTITION"] = partition
         check(L.preAlps_OperatorBuild(path.encode(), 0x44000000), "preAlps_OperatorBuild")
         self._after_build()
         return self
@@ -220,6 +249,12 @@ class EcgProblem:
         self.nparts = L.preAlps_hip_nparts()
         self.row_off = 0
         self.has_precond = False
+
+    def part_vector(self):
+        """part[i] of every original row i, recovered from the permutation and rowPos."""
+        part = np.empty(self.N, dtype=np.int32)
+        part[self.perm] = np.repeat(np.arange(self.nparts, dtype=np.int32), np.diff(self.rowpos))
+        return part
 
     # -- pieces of the driver --------------------------------------------------
     def create_block_jacobi(self):

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nparts, n, box, q):
+def _worker(rank, world, port, nparts, n, box, q, mode="box"):
     try:
         sys.path.insert(0, ROOT)
         import torch
@@ -41,6 +41,19 @@ def _worker(rank, world, port, nparts, n, box, q):
         rp, ci, v = gen.poisson3d_csr(n)
         part, npz = gen.box_partition(n, box)
         assert npz == nparts
+        if mode == "kway":       # the library's own graph partitioner (deterministic: same on every rank)
+            from prealps_amd.solver import partition_kway
+            part = partition_kway(rp, ci, nparts)
+        if mode == "unsym":
+            # a `general` matrix whose pattern is not symmetric: every third entry below the
+            # diagonal is dropped, its mirror image stays.  The send lists must still be exactly
+            # what the receivers expect (they are derived from the receivers' rows).
+            import scipy.sparse as sp0
+            A0 = sp0.coo_matrix(sp0.csr_matrix((v, ci, rp), shape=(n ** 3, n ** 3)))
+            keep = ~((A0.row > A0.col) & ((A0.row + A0.col) % 3 == 0))
+            A0 = sp0.csr_matrix((A0.data[keep], (A0.row[keep], A0.col[keep])), shape=A0.shape)
+            A0.sort_indices()
+            rp, ci, v = A0.indptr.astype(np.int32), A0.indices.astype(np.int32), A0.data.copy()
         pi, pd = C.POINTER(C.c_int), C.POINTER(C.c_double)
         check(L.preAlps_OperatorBuildFromCSR(n ** 3, rp.ctypes.data_as(pi), ci.ctypes.data_as(pi),
                                              v.ctypes.data_as(pd), nparts, part.ctypes.data_as(pi), 1), "build")
@@ -108,13 +121,14 @@ def _worker(rank, world, port, nparts, n, box, q):
         q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc()), 0, 0))
 
 
-@pytest.mark.parametrize("world,box,nparts", [(2, (4, 4, 4), 27), (3, (6, 6, 3), 16)])
-def test_sharded_spmm_and_gram_match_global(world, box, nparts):
+@pytest.mark.parametrize("world,box,nparts,mode", [(2, (4, 4, 4), 27, "box"), (3, (6, 6, 3), 16, "box"),
+                                                   (2, (4, 4, 4), 27, "kway"), (3, (4, 4, 4), 27, "unsym")])
+def test_sharded_spmm_and_gram_match_global(world, box, nparts, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, nparts, 12, box, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nparts, 12, box, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

@@ -165,7 +165,7 @@ def test_ecg_block_size_reduction_parity(poisson24, golden, alg, t):
 
 def test_lfat5_from_matrixmarket_file(golden):
     import prealps_amd
-    prob = prealps_amd.EcgProblem.from_mtx(os.path.join(GOLD, "LFAT5.mtx"), nparts=2)
+    prob = prealps_amd.EcgProblem.from_mtx(os.path.join(GOLD, "LFAT5.mtx"), nparts=2, partition="contiguous")
     try:
         got = prob.solve(prob.reference_rhs(), 2)
         g = golden["lfat5"]["np2_t2_odir"]
@@ -179,7 +179,7 @@ def test_lfat5_from_matrixmarket_file(golden):
 
 def test_enlarging_factor_larger_than_parts_is_refused():
     import prealps_amd
-    prob = prealps_amd.EcgProblem.from_mtx(os.path.join(GOLD, "LFAT5.mtx"), nparts=2)
+    prob = prealps_amd.EcgProblem.from_mtx(os.path.join(GOLD, "LFAT5.mtx"), nparts=2, partition="contiguous")
     try:
         with pytest.raises(prealps_amd.PreAlpsError, match="Enlarging factor"):
             prob.solve(prob.reference_rhs(), 4)
@@ -219,7 +219,7 @@ def test_c_driver_end_to_end(tmp_path, golden):
                            os.path.join(root, "examples", "ecg_driver.c"), "-L" + os.path.join(root, "prealps_amd"),
                            "-lprealps_hip", "-Wl,-rpath," + os.path.join(root, "prealps_amd"), "-lm", "-o", exe])
     r = subprocess.run([exe, "-m", os.path.join(GOLD, "LFAT5.mtx"), "-e", "2", "-o", "0", "-r", "0"],
-                       capture_output=True, text=True, env=dict(os.environ, PREALPS_NPARTS="2"), timeout=120)
+                       capture_output=True, text=True, env=dict(os.environ, PREALPS_NPARTS="2", PREALPS_PARTITION="contiguous"), timeout=120)
     assert r.returncode == 0, r.stderr
     it = int(re.search(r"iter: (\d+)", r.stdout).group(1))
     res = float(re.search(r"res : (\S+)", r.stdout).group(1))
