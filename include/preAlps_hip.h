@@ -111,6 +111,19 @@ int preAlps_hip_panel_alloc(CPLM_Mat_Dense_t* A, int M, int N, int m, int n, int
 void preAlps_hip_panel_free(CPLM_Mat_Dense_t* A);
 int preAlps_hip_panel_to_host(const CPLM_Mat_Dense_t* A, int enlFac, double* host, int ld);
 int preAlps_hip_panel_from_host(CPLM_Mat_Dense_t* A, int enlFac, const double* host, int ld);
+/* The tall-skinny panel kernels of the iteration on their own (what a kernel-level check calls;
+ * the solver launches the same kernels): host_out (ld_out >= rows) = [A0 | A1]^T B, column major
+ * (the dgemm of ecg.c:311,330,347,425,438,510);  Z -= [V0 | V1] beta with beta on the host,
+ * column major (ecg.c:354,517);  P <- P U^-1, AP <- AP U^-1, X += P alpha, R -= AP alpha and
+ * *host_res2 = sum of squares of the new R (ecg.c:324-338,434-435,500-501,250), U upper
+ * triangular t x t, alpha t x X.n, both on the host, column major.  A1 / V1 may be NULL. */
+int preAlps_hip_panel_gram(const CPLM_Mat_Dense_t* A0, const CPLM_Mat_Dense_t* A1, const CPLM_Mat_Dense_t* B,
+                           double* host_out, int ld_out);
+int preAlps_hip_panel_update(CPLM_Mat_Dense_t* Z, const CPLM_Mat_Dense_t* V0, const CPLM_Mat_Dense_t* V1,
+                             const double* host_beta, int ldb);
+int preAlps_hip_panel_trsm_update(CPLM_Mat_Dense_t* P, CPLM_Mat_Dense_t* AP, CPLM_Mat_Dense_t* X,
+                                  CPLM_Mat_Dense_t* R, const double* host_U, const double* host_alpha,
+                                  double* host_res2);
 /* Numeric facts about the built operator / preconditioner, by name:
  * "nnz_local", "rows_local", "halo_rows", "spmm_blocks", "bj_factor_bytes",
  * "bj_max_bandwidth", "bj_parts_local".  Returns non-zero for unknown keys. */

@@ -76,6 +76,7 @@ EXPORTS = [
     "preAlps_hip_timer_start", "preAlps_hip_timer_stop",
     "preAlps_hip_timing_reset", "preAlps_hip_get_time",
     "preAlps_hip_partition_kway", "preAlps_hip_rccl_available",
+    "preAlps_hip_panel_gram", "preAlps_hip_panel_update", "preAlps_hip_panel_trsm_update",
 ]
 
 _lib = None
@@ -138,6 +139,9 @@ def load():
     L.preAlps_hip_get_time.argtypes = [C.c_char_p, pd]
     L.preAlps_hip_timer_stop.argtypes = [pd]
     L.preAlps_hip_hbm_probe.argtypes = [C.c_size_t, C.c_int, pd, pd]
+    L.preAlps_hip_panel_gram.argtypes = [_PD, _PD, _PD, pd, C.c_int]
+    L.preAlps_hip_panel_update.argtypes = [_PD, _PD, _PD, pd, C.c_int]
+    L.preAlps_hip_panel_trsm_update.argtypes = [_PD, _PD, _PD, _PD, pd, pd, pd]
     L.preAlps_hip_partition_kway.argtypes = [C.c_int, pi, pi, C.c_int, pi]
     L.preAlps_hip_timing.restype = None
     L.preAlps_hip_timing_reset.restype = None

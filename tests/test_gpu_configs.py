@@ -1,0 +1,323 @@
+"""Every BASELINE.json configuration exercised through the C ABI against the CPU oracle at a size
+the oracle finishes in seconds (the matrix class, enlarging factor, variant and reduction of the
+configuration; the size is what shrinks), plus the full-size headline workload's first
+iterations, the dispatch paths of the block solve that small problems would not reach, and the
+BF-Omin shrink.  fp64; residual histories to 1e-8 relative unless a test says otherwise."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL_HIST = 1e-8
+
+
+def _problem(A, P, part=None, **kw):
+    import prealps_amd
+    from oracle import oracle as O
+    part = O.contiguous_partition(A.shape[0], P) if part is None else part
+    rp, ci, v = O.as_csr(A)
+    prob = prealps_amd.EcgProblem(rp, ci, v, P, part, scale=True, device=0, **kw)
+    B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, P)
+    return prob, B, rowpos
+
+
+def _elasticity(nn, box):
+    from prealps_amd import gen
+    rp, ci, v = gen.elasticity3d_csr(nn)
+    part, nparts = gen.box_partition_nodes(nn, box)
+    N = len(rp) - 1
+    return sp.csr_matrix((v, ci, rp), shape=(N, N)), part, nparts
+
+
+def _algs(name):
+    import prealps_amd as pa
+    from oracle import oracle as O
+    return {"odir": (pa.ORTHODIR, O.ORTHODIR), "omin": (pa.ORTHOMIN, O.ORTHOMIN),
+            "fused": (pa.ORTHODIR_FUSED, O.ORTHODIR_FUSED)}[name]
+
+
+# ---- configs[0]: elasticity3d 12 x 10 x 10, ECG + block-Jacobi, t = 4, 8 subdomains ------------------
+def test_config0_elasticity_12x10x10_t4_p8():
+    """`test_ecg_prealps_op -e 4 -o 0 -r 0` on the stand-in for matrix/elasticity3d_12x10x10_var.mtx
+    (SURVEY 8d C1(iii)): the reference's element matrix on 12 x 10 x 10 nodes, 8 subdomains from
+    the graph partitioner (the reference: METIS), tol 1e-5, at most 1000 iterations."""
+    import prealps_amd as pa
+    from prealps_amd import gen
+    from prealps_amd.solver import partition_kway
+    from oracle import oracle as O
+    rp, ci, v = gen.elasticity3d_csr((12, 10, 10))
+    N = 3600
+    A = sp.csr_matrix((v, ci, rp), shape=(N, N))
+    part = partition_kway(rp, ci, 8)
+    prob, B, rowpos = _problem(A, 8, part)
+    try:
+        rhs = prob.reference_rhs()
+        np.testing.assert_array_equal(rhs, O.reference_rhs(rowpos))
+        got = prob.solve(rhs, 4, ortho_alg=pa.ORTHODIR, bs_red=pa.NO_BS_RED, tol=1e-5, max_iter=1000)
+        ref = O.ECG(B, rowpos, 4, O.ORTHODIR, O.NO_BS_RED, 1e-5, 1000).solve(rhs)
+        assert got.iters == ref["iters"] and got.iters < 1000
+        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-7)
+        np.testing.assert_allclose(got.x, ref["x"], rtol=1e-6, atol=1e-8 * np.abs(ref["x"]).max())
+        assert got.final_res <= 1e-5 * got.normb
+    finally:
+        prob.close()
+
+
+# ---- configs[2]: an unstructured SPD matrix (Flan_1565's class), t = 4, through the partitioner -----
+def _unstructured_spd(npts, seed):
+    """Graph Laplacian + mass of a random point cloud in the unit cube (12 nearest neighbours,
+    3 dofs per point coupled by a random SPD 3 x 3 block), randomly renumbered: no grid, no
+    geometry in the ids, vector-valued like a 3-D mechanics matrix."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    X = rng.random((npts, 3))
+    _, nb = cKDTree(X).query(X, k=13)
+    rows = np.repeat(np.arange(npts), 12)
+    cols = nb[:, 1:].ravel()
+    G = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(npts, npts)).tocsr()
+    G = ((G + G.T) > 0).astype(np.float64)                    # symmetric pattern
+    W = sp.triu(G, 1).tocoo()
+    w = 0.5 + rng.random(W.nnz)                                # edge stiffness
+    K = rng.standard_normal((W.nnz, 3, 3))
+    K = np.einsum("eij,ekj->eik", K, K) + 0.2 * np.eye(3)     # SPD 3 x 3 per edge
+    K *= w[:, None, None]
+    n3 = 3 * npts
+    i3 = (3 * W.row[:, None, None] + np.arange(3)[None, :, None]) + 0 * np.arange(3)[None, None, :]
+    j3 = (3 * W.col[:, None, None] + np.arange(3)[None, None, :]) + 0 * np.arange(3)[None, :, None]
+    ii = (3 * W.row[:, None, None] + np.arange(3)[None, :, None]) + 0 * np.arange(3)[None, None, :]
+    jj = (3 * W.row[:, None, None] + np.arange(3)[None, None, :]) + 0 * np.arange(3)[None, :, None]
+    kk = (3 * W.col[:, None, None] + np.arange(3)[None, :, None]) + 0 * np.arange(3)[None, None, :]
+    ll = (3 * W.col[:, None, None] + np.arange(3)[None, None, :]) + 0 * np.arange(3)[None, :, None]
+    A = (sp.coo_matrix((-K.ravel(), (i3.ravel(), j3.ravel())), shape=(n3, n3)) +
+         sp.coo_matrix((-np.transpose(K, (0, 2, 1)).ravel(), (j3.transpose(0, 2, 1).ravel(), i3.transpose(0, 2, 1).ravel())), shape=(n3, n3)) +
+         sp.coo_matrix((K.ravel(), (ii.ravel(), jj.ravel())), shape=(n3, n3)) +
+         sp.coo_matrix((K.ravel(), (kk.ravel(), ll.ravel())), shape=(n3, n3))).tocsr()
+    A = A + 0.05 * sp.identity(n3)
+    A = 0.5 * (A + A.T)
+    q = rng.permutation(npts)
+    q3 = (3 * q[:, None] + np.arange(3)[None, :]).ravel()
+    A = sp.csr_matrix(A[q3][:, q3])
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+def test_config2_unstructured_matrix_through_the_partitioner(tmp_path):
+    """BASELINE configs[2] (Flan_1565: unstructured 3-D mechanics, t = 4): no such file offline, so
+    an unstructured vector-valued SPD matrix is generated, written as MatrixMarket and solved
+    through preAlps_OperatorBuild -- reader, scaling, the library's graph partitioner where the
+    reference calls METIS, permutation -- exactly like the reference driver; the oracle gets the
+    same partition.  The same matrix in memory with the explicit partition must agree too."""
+    import scipy.io
+    import prealps_amd as pa
+    from oracle import oracle as O
+    A = _unstructured_spd(2500, 4)
+    N, P, t = A.shape[0], 40, 4
+    path = str(tmp_path / "unstructured.mtx")
+    scipy.io.mmwrite(path, sp.tril(A), symmetry="symmetric")
+    prob = pa.EcgProblem.from_mtx(path, nparts=P)
+    try:
+        part = prob.part_vector()
+        sizes = np.bincount(part, minlength=P)
+        assert sizes.min() > 0 and sizes.max() <= 1.25 * N / P
+        A2 = O.load_mtx(path)
+        B, perm, rowpos = O.permute_by_part(O.symrac_scale(A2), part, P)
+        np.testing.assert_array_equal(prob.rowpos, rowpos)
+        rhs = prob.reference_rhs()
+        np.testing.assert_array_equal(rhs, O.reference_rhs(rowpos))
+        got = prob.solve(rhs, t, max_iter=1000)
+        ref = O.ECG(B, rowpos, t, max_iter=1000).solve(rhs)
+        assert got.iters == ref["iters"] and got.iters < 1000
+        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-7)
+        np.testing.assert_allclose(got.x, ref["x"], rtol=1e-6, atol=1e-8 * np.abs(ref["x"]).max())
+        band_kway = prob.stat("bj_max_bandwidth")
+    finally:
+        prob.close()
+    # the same through the in-memory builder with the partition handed over explicitly
+    prob2, B2, rowpos2 = _problem(A2, P, part)
+    try:
+        got2 = prob2.solve(prob2.reference_rhs(), t, max_iter=1000)
+        assert got2.iters == got.iters
+        np.testing.assert_allclose(got2.res, got.res, rtol=1e-9)
+    finally:
+        prob2.close()
+    # contiguous row blocks of the randomly numbered matrix are not subdomains at all: the
+    # partitioner's parts are compact (far narrower bands) and converge much faster
+    prob3, B3, rowpos3 = _problem(A2, P, None)
+    try:
+        got3 = prob3.solve(prob3.reference_rhs(), t, max_iter=1000)
+        assert prob3.stat("bj_max_bandwidth") > 1.5 * band_kway
+        assert got3.iters > got.iters
+    finally:
+        prob3.close()
+
+
+# ---- configs[3]: elasticity, t = 8, Odir / Omin with dynamic reduction of the search directions ------
+@pytest.mark.parametrize("alg", ["odir", "omin", "fused"])
+def test_config3_elasticity_t8_with_block_size_reduction(alg):
+    """`-e 8 -o {0,1} -r 1`: D-Odir (SVD threshold + rotation, ecg.c:445-497) and BF-Omin (pivoted
+    Cholesky, ecg.c:361-393) on the elasticity matrix class: residuals AND block size sequence."""
+    import prealps_amd as pa
+    from oracle import oracle as O
+    A, part, nparts = _elasticity(9, (3, 3, 3))
+    prob, B, rowpos = _problem(A, nparts, part)
+    try:
+        a_gpu, a_cpu = _algs(alg)
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, 8, ortho_alg=a_gpu, bs_red=pa.ADAPT_BS, max_iter=600)
+        ref = O.ECG(B, rowpos, 8, a_cpu, O.ADAPT_BS, 1e-5, 600).solve(rhs)
+        assert got.iters == ref["iters"]
+        assert list(got.bs) == list(ref["bs"])
+        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-6)
+        if alg == "odir":
+            assert got.bs[-1] < 8          # the reduction really happened
+    finally:
+        prob.close()
+
+
+@pytest.mark.parametrize("alg", ["odir", "omin"])
+def test_config3_elasticity_t8_no_reduction(alg):
+    import prealps_amd as pa
+    from oracle import oracle as O
+    A, part, nparts = _elasticity(9, (3, 3, 3))
+    prob, B, rowpos = _problem(A, nparts, part)
+    try:
+        a_gpu, a_cpu = _algs(alg)
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, 8, ortho_alg=a_gpu, max_iter=600)
+        ref = O.ECG(B, rowpos, 8, a_cpu, O.NO_BS_RED, 1e-5, 600).solve(rhs)
+        assert got.iters == ref["iters"]
+        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-6)
+        np.testing.assert_allclose(got.x, ref["x"], rtol=1e-5, atol=1e-8 * np.abs(ref["x"]).max())
+    finally:
+        prob.close()
+
+
+# ---- configs[4]: the large elasticity-class matrix, t = 16 ------------------------------------------------
+def test_config4_elasticity_t16_odir():
+    import prealps_amd as pa
+    from oracle import oracle as O
+    A, part, nparts = _elasticity(10, (2, 4, 5))      # 5 x 3 x 2 = 30 subdomains >= t
+    prob, B, rowpos = _problem(A, nparts, part)
+    try:
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, 16, max_iter=400)
+        ref = O.ECG(B, rowpos, 16, O.ORTHODIR, O.NO_BS_RED, 1e-5, 400).solve(rhs)
+        assert got.iters == ref["iters"]
+        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-6)
+        np.testing.assert_allclose(got.x, ref["x"], rtol=1e-5, atol=1e-8 * np.abs(ref["x"]).max())
+    finally:
+        prob.close()
+
+
+# ---- the headline workload at full size: first iterations against the oracle -----------------------------
+@pytest.mark.parametrize("factor", ["device", "host"])
+def test_full_size_first_residuals_vs_oracle(factor, monkeypatch):
+    """Q1 elasticity 70^3 nodes (N = 1,029,000, nnz = 80,990,208), t = 4, 5670 subdomains of
+    2 x 4 x 8 nodes -- the bench default.  The oracle runs 16 iterations of the same problem on the
+    host cores; the residual norm after every one of them must agree to 1e-8 (observed: 1e-11),
+    with the block factors computed on the device and on the host."""
+    monkeypatch.setenv("PREALPS_BJ_FACTOR", factor)
+    import prealps_amd as pa
+    from oracle import oracle as O
+    A, part, nparts = _elasticity(70, (2, 4, 8))
+    prob, B, rowpos = _problem(A, nparts, part)
+    try:
+        assert B.nnz == 80990208 and nparts == 5670
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, 4, max_iter=16)
+        ref = O.ECG(B, rowpos, 4, O.ORTHODIR, O.NO_BS_RED, 1e-5, 16).solve(rhs)
+        assert len(got.res) == len(ref["res"]) == 16
+        assert abs(got.normb - ref["normb"]) <= 1e-13 * ref["normb"]
+        np.testing.assert_allclose(got.res, ref["res"], rtol=RTOL_HIST)
+    finally:
+        prob.close()
+
+
+# ---- dispatch paths of the block solve ---------------------------------------------------------------------
+@pytest.mark.parametrize("wide_from", ["default", "448"])
+@pytest.mark.parametrize("n,t", [(8, 8), (10, 8), (10, 16), (10, 4), (14, 4), (16, 4), (20, 4), (20, 8)])
+def test_block_solve_dispatch_by_band(n, t, wide_from, monkeypatch):
+    """Two cubes of n^3 Poisson nodes -> band n^2 after reordering: 64 (matrix cores, 6 tiles),
+    100 (8 tiles, 64 KiB of LDS), 196 / 256 / 400 (register sets 4, 5, 8 of the one-wavefront
+    kernel).  With fewer than 1024 blocks the library sends bands above 96 to the
+    workgroup-per-block kernel; PREALPS_BJ_WIDE_FROM=448 forces the wavefront-per-block kernels
+    that production sizes (>= 1024 blocks per GPU) use.  Both against the oracle's solve."""
+    if wide_from != "default":
+        monkeypatch.setenv("PREALPS_BJ_WIDE_FROM", wide_from)
+    from oracle import oracle as O
+    import scipy.sparse as sp2
+    T = sp2.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])
+    T2 = sp2.diags([-np.ones(2 * n - 1), 2 * np.ones(2 * n), -np.ones(2 * n - 1)], [-1, 0, 1])
+    I, I2 = sp2.identity(n), sp2.identity(2 * n)
+    A = sp.csr_matrix(sp2.kron(sp2.kron(T2, I), I) + sp2.kron(sp2.kron(I2, T), I) + sp2.kron(sp2.kron(I2, I), T))
+    prob, B, rowpos = _problem(A, 2)
+    try:
+        X = np.random.default_rng(n + t).standard_normal((B.shape[0], t))
+        zr = O.BlockJacobi(B, rowpos).apply(X)
+        got = prob.block_jacobi_apply(X, t)
+        np.testing.assert_allclose(got, zr, rtol=1e-9, atol=1e-10 * np.abs(zr).max())
+        assert prob.stat("bj_max_bandwidth") == n * n
+    finally:
+        prob.close()
+
+
+# ---- BF-Omin really shrinks ------------------------------------------------------------------------------------
+def test_bf_omin_shrinks_when_a_direction_dies():
+    """Breakdown-free Orthomin (ecg.c:361-393): subdomains 3, 7, 11, ... (p mod 4 == 3) are cut off
+    from the rest of the matrix.  Column 3 of the split residual lives on exactly those rows, the
+    block-Jacobi solve is exact for them, so that column converges in one iteration, its search
+    direction degenerates to rounding noise and the pivoted Cholesky of P^T P finds rank 3: the
+    block size must drop from 4 to 3 in the reference algorithm and here, at the same iteration."""
+    import prealps_amd as pa
+    from oracle import oracle as O
+    n, P, t = 16, 16, 4
+    A = sp.lil_matrix(O.poisson3d(n))
+    part = O.contiguous_partition(n ** 3, P)
+    coo = sp.coo_matrix(A)
+    cutoff = (part[coo.row] != part[coo.col]) & ((part[coo.row] % t == t - 1) | (part[coo.col] % t == t - 1))
+    A = sp.csr_matrix((coo.data[~cutoff], (coo.row[~cutoff], coo.col[~cutoff])), shape=coo.shape)
+    prob, B, rowpos = _problem(A, P, part)
+    try:
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, t, ortho_alg=pa.ORTHOMIN, bs_red=pa.ADAPT_BS, max_iter=300)
+        ref = O.ECG(B, rowpos, t, O.ORTHOMIN, O.ADAPT_BS, 1e-5, 300).solve(rhs)
+        assert min(ref["bs"]) < t, "the construction did not make the oracle shrink"
+        assert list(got.bs) == list(ref["bs"])
+        assert got.iters == ref["iters"]
+        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-6)
+        np.testing.assert_allclose(got.x, ref["x"], rtol=1e-5, atol=1e-8 * np.abs(ref["x"]).max())
+    finally:
+        prob.close()
+
+
+# ---- bench.py --gpus N starts its own ranks --------------------------------------------------------------------
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: two ranks (here both on the one GPU of
+    the test box, gloo backend -- RCCL refuses two ranks on one device) and n_gpus: 2 in the line."""
+    env = dict(os.environ, PREALPS_BENCH_BACKEND="gloo", PREALPS_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "poisson",
+                        "--n", "32", "--box", "4,4,8", "--steps", "10", "--warmup", "2", "--no-cpu",
+                        "--spmm-reps", "3", "--phase-iters", "4"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["comm"] == "torch.gloo"
+    assert len(out["config"]["halo_rows_per_rank"]) == 2 and min(out["config"]["halo_rows_per_rank"]) > 0
+    assert out["value"] > 0 and "operator" in out["phases"]["device_us_per_iteration"]
+    # a launcher that started the wrong number of ranks is refused
+    env1 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True,
+                       text=True, env=env1, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
