@@ -63,10 +63,15 @@ def test_config0_elasticity_12x10x10_t4_p8():
         np.testing.assert_array_equal(rhs, O.reference_rhs(rowpos))
         got = prob.solve(rhs, 4, ortho_alg=pa.ORTHODIR, bs_red=pa.NO_BS_RED, tol=1e-5, max_iter=1000)
         ref = O.ECG(B, rowpos, 4, O.ORTHODIR, O.NO_BS_RED, 1e-5, 1000).solve(rhs)
-        assert got.iters == ref["iters"] and got.iters < 1000
-        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-7)
-        np.testing.assert_allclose(got.x, ref["x"], rtol=1e-6, atol=1e-8 * np.abs(ref["x"]).max())
+        # Coefficient jumps of 1e10: two fp64 implementations of the same recurrence drift apart
+        # exponentially (tools/history_probe.py, profiles/r02_history_divergence.txt: 5e-13 after
+        # the first iteration, 1e-10 after 40, O(1) after 80 of ~90).  So: the first 40 residuals
+        # to 1e-8, the iteration count within 3, and both answers solve the system.
+        np.testing.assert_allclose(got.res[:40], ref["res"][:40], rtol=RTOL_HIST)
+        assert abs(got.iters - ref["iters"]) <= 3 and got.iters < 1000
         assert got.final_res <= 1e-5 * got.normb
+        for x, res in ((got.x, got.final_res), (ref["x"], ref["final_res"])):
+            assert np.linalg.norm(rhs - B @ x) <= 1.5 * res + 1e-12
     finally:
         prob.close()
 
@@ -149,13 +154,12 @@ def test_config2_unstructured_matrix_through_the_partitioner(tmp_path):
         np.testing.assert_allclose(got2.res, got.res, rtol=1e-9)
     finally:
         prob2.close()
-    # contiguous row blocks of the randomly numbered matrix are not subdomains at all: the
-    # partitioner's parts are compact (far narrower bands) and converge much faster
+    # contiguous row blocks of the randomly numbered matrix are not subdomains at all (their
+    # diagonal blocks are nearly diagonal): the partitioner's parts converge much faster
     prob3, B3, rowpos3 = _problem(A2, P, None)
     try:
         got3 = prob3.solve(prob3.reference_rhs(), t, max_iter=1000)
-        assert prob3.stat("bj_max_bandwidth") > 1.5 * band_kway
-        assert got3.iters > got.iters
+        assert got3.iters > 1.3 * got.iters and band_kway > prob3.stat("bj_max_bandwidth")
     finally:
         prob3.close()
 
@@ -244,13 +248,16 @@ def test_full_size_first_residuals_vs_oracle(factor, monkeypatch):
 
 # ---- dispatch paths of the block solve ---------------------------------------------------------------------
 @pytest.mark.parametrize("wide_from", ["default", "448"])
-@pytest.mark.parametrize("n,t", [(8, 8), (10, 8), (10, 16), (10, 4), (14, 4), (16, 4), (20, 4), (20, 8)])
-def test_block_solve_dispatch_by_band(n, t, wide_from, monkeypatch):
-    """Two cubes of n^3 Poisson nodes -> band n^2 after reordering: 64 (matrix cores, 6 tiles),
-    100 (8 tiles, 64 KiB of LDS), 196 / 256 / 400 (register sets 4, 5, 8 of the one-wavefront
-    kernel).  With fewer than 1024 blocks the library sends bands above 96 to the
-    workgroup-per-block kernel; PREALPS_BJ_WIDE_FROM=448 forces the wavefront-per-block kernels
-    that production sizes (>= 1024 blocks per GPU) use.  Both against the oracle's solve."""
+@pytest.mark.parametrize("n,t,lo,hi", [(8, 8, 49, 80), (8, 16, 49, 80), (11, 8, 81, 112), (11, 16, 81, 112), (11, 4, 81, 112),
+                                       (14, 4, 129, 192), (16, 4, 193, 256), (20, 4, 257, 320), (22, 4, 321, 384),
+                                       (24, 2, 385, 448), (20, 8, 257, 320)])
+def test_block_solve_dispatch_by_band(n, t, lo, hi, wide_from, monkeypatch):
+    """Two cubes of n^3 Poisson nodes -> band ~0.8 n^2 after reordering: 49..80 (matrix cores, 6
+    tiles at 8 / 16 columns), 81..112 (8 tiles, 64 KiB of LDS), then the register-set classes
+    R = 4, 5, 6, 7, 8 of the one-wavefront kernel (bands up to 448).  With fewer than 1024 blocks
+    the library sends bands above 96 to the workgroup-per-block kernel; PREALPS_BJ_WIDE_FROM=448
+    forces the wavefront-per-block kernels that production sizes (>= 1024 blocks per GPU) use.
+    Both against the oracle's solve."""
     if wide_from != "default":
         monkeypatch.setenv("PREALPS_BJ_WIDE_FROM", wide_from)
     from oracle import oracle as O
@@ -265,7 +272,7 @@ def test_block_solve_dispatch_by_band(n, t, wide_from, monkeypatch):
         zr = O.BlockJacobi(B, rowpos).apply(X)
         got = prob.block_jacobi_apply(X, t)
         np.testing.assert_allclose(got, zr, rtol=1e-9, atol=1e-10 * np.abs(zr).max())
-        assert prob.stat("bj_max_bandwidth") == n * n
+        assert lo <= prob.stat("bj_max_bandwidth") <= hi, prob.stat("bj_max_bandwidth")
     finally:
         prob.close()
 
@@ -280,7 +287,9 @@ def test_bf_omin_shrinks_when_a_direction_dies():
     import prealps_amd as pa
     from oracle import oracle as O
     n, P, t = 16, 16, 4
-    A = sp.lil_matrix(O.poisson3d(n))
+    # (a random diagonal: on the plain Laplacian the mirror symmetry of the slabs kills a second
+    # direction too, and which of two rounding-level pivots survives is not a property to pin)
+    A = O.poisson3d(n) + sp.diags(np.random.default_rng(1).random(n ** 3))
     part = O.contiguous_partition(n ** 3, P)
     coo = sp.coo_matrix(A)
     cutoff = (part[coo.row] != part[coo.col]) & ((part[coo.row] % t == t - 1) | (part[coo.col] % t == t - 1))
@@ -290,7 +299,7 @@ def test_bf_omin_shrinks_when_a_direction_dies():
         rhs = prob.reference_rhs()
         got = prob.solve(rhs, t, ortho_alg=pa.ORTHOMIN, bs_red=pa.ADAPT_BS, max_iter=300)
         ref = O.ECG(B, rowpos, t, O.ORTHOMIN, O.ADAPT_BS, 1e-5, 300).solve(rhs)
-        assert min(ref["bs"]) < t, "the construction did not make the oracle shrink"
+        assert list(ref["bs"][:3]) == [4, 3, 3], "the construction did not make the oracle shrink by one"
         assert list(got.bs) == list(ref["bs"])
         assert got.iters == ref["iters"]
         np.testing.assert_allclose(got.res, ref["res"], rtol=1e-6)
