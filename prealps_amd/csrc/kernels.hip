@@ -1475,8 +1475,12 @@ __device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __r
 
 // XS = panel stride: XS = TS, or a multiple of it when the panel is split by columns among XS/TS
 // wavefronts (opt-in, see bj_launch).
-template <int TS, int R, int CH, int XS>
-__global__ __launch_bounds__(256) void k_bj_apply(
+// OCC = wavefronts per SIMD the register allocation must leave room for (1: no constraint).  All
+// blocks of a class take equally long, so what counts is whether they fit the chip in ONE round:
+// 5670 blocks on 1024 SIMDs need 6 resident wavefronts per SIMD (4 meant a second, nearly empty
+// round behind the first).
+template <int TS, int R, int CH, int XS, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_bj_apply(
     const int* __restrict__ list, int count, const int* __restrict__ row0,
     const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off,
     const int* __restrict__ map_f, const int* __restrict__ map_b, const double* __restrict__ Lf,
@@ -1992,15 +1996,31 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
   case RR: {                                                                                      \
     static size_t configured = 0;                                                                 \
     if (lds > 64 * 1024 && lds > configured) {                                                    \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply<TS, RR, CH, XS>),             \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply<TS, RR, CH, XS, 1>),          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return kfail("hipFuncSetAttribute(k_bj_apply)");                                          \
       configured = lds;                                                                           \
     }                                                                                             \
-    hipLaunchKernelGGL((k_bj_apply<TS, RR, CH, XS>), dim3(blocks), dim3(64 * waves), lds,             \
+    hipLaunchKernelGGL((k_bj_apply<TS, RR, CH, XS, 1>), dim3(blocks), dim3(64 * waves), lds,          \
                        cur_stream(), list, count, pl->row0, pl->nrows, pl->bw, pl->off,           \
                        pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, per_wave, in, out); \
   } break;
+  // narrow bands at up to 4 columns: variants that leave room for 5 / 6 wavefronts per SIMD
+  if constexpr (TS <= 4 && XS == TS) {
+    static int occ = -1;
+    if (occ < 0) { const char* e = getenv("PREALPS_BJ_OCC"); occ = e ? atoi(e) : 0; }
+    if (R == 2 && occ >= 5 && lds <= 64 * 1024) {
+      if (occ == 5)
+        hipLaunchKernelGGL((k_bj_apply<TS, 2, CH, XS, 5>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
+                           pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
+                           pl->invd_b, per_wave, in, out);
+      else
+        hipLaunchKernelGGL((k_bj_apply<TS, 2, CH, XS, 6>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
+                           pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
+                           pl->invd_b, per_wave, in, out);
+      return kfail("k_bj_apply");
+    }
+  }
   switch (R) {
     BJ_CASE(1) BJ_CASE(2) BJ_CASE(3) BJ_CASE(4) BJ_CASE(5) BJ_CASE(6) BJ_CASE(7) BJ_CASE(8)
     default:
