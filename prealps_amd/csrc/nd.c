@@ -1,0 +1,467 @@
+/*
+ * nd.c -- exact solves with LARGE diagonal blocks (few subdomains, thousands of rows each: the
+ * reference's own regime, one block per rank, src/preconditioners/block_jacobi.c:26-63,93-109
+ * with PARDISO's sparse Cholesky) by a sparse supernodal factorisation instead of a band:
+ *
+ *   ordering   nested dissection of the block's graph (partition.c: pa_nd_order); leaves and
+ *              separators are the supernodes, in postorder;
+ *   symbolic   the row structure of every supernode = the separator vertices of its ancestors
+ *              that its subtree touches (merged up the tree);
+ *   numeric    multifrontal Cholesky on the host threads (one block per thread, dense fronts,
+ *              the update matrices handed from child to parent);
+ *   storage    per supernode a dense trapezoid (n columns, n + m rows) in HBM, twice: column
+ *              major with every column divided by its pivot for the forward sweep, row major for
+ *              the backward sweep -- each sweep streams its copy once with coalesced loads;
+ *   solve      level by level up the tree and down again (kernels.hip: k_nd_forward /
+ *              k_nd_backward), one workgroup per supernode, t right-hand sides at once.
+ *
+ * Against the band factor of a 18^3-node elasticity block (17.5 k rows, band 1031: 281 MB in two
+ * copies) this needs ~130 MB, and a level of the tree is thousands of independent workgroups
+ * where the band solve ran on one CU per block.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pa_host.h"
+
+typedef struct {
+  int created;
+  int nsn;                 /* supernodes of all ND blocks of this process */
+  pa_nd_plan_t plan;
+  /* device */
+  int* d_n; int* d_m; int* d_ld; long long* d_offF; long long* d_offB; int* d_rows_off;
+  int* d_coff; int* d_ccoff; int* d_rows; int* d_src; double* d_dinv; double* d_F; double* d_B;
+  double* d_contrib; size_t contrib_rows; int contrib_ts;
+  int nlaunch; int* l_height; int* l_class; int* l_count; int** l_list; const int** l_list_c;
+  double bytes;
+} pa_nd_t;
+
+static pa_nd_t g_nd;
+
+double pa_nd_factor_bytes(void) { return g_nd.created ? g_nd.bytes : 0.0; }
+int pa_nd_active(void) { return g_nd.created; }
+
+void pa_nd_free(void) {
+  pa_nd_t* s = &g_nd;
+  pa_rt_free(s->d_n); pa_rt_free(s->d_m); pa_rt_free(s->d_ld); pa_rt_free(s->d_offF); pa_rt_free(s->d_offB);
+  pa_rt_free(s->d_rows_off); pa_rt_free(s->d_coff); pa_rt_free(s->d_ccoff); pa_rt_free(s->d_rows); pa_rt_free(s->d_src);
+  pa_rt_free(s->d_dinv); pa_rt_free(s->d_F); pa_rt_free(s->d_B); pa_rt_free(s->d_contrib);
+  for (int i = 0; i < s->nlaunch; ++i) pa_rt_free(s->l_list[i]);
+  free(s->l_height); free(s->l_class); free(s->l_count); free(s->l_list); free(s->l_list_c);
+  memset(s, 0, sizeof(*s));
+}
+
+/* ---- per-block symbolic + numeric work -------------------------------------------------------------- */
+typedef struct {
+  int b;                   /* rows of the block */
+  int row0;                /* first local panel row of the block */
+  pa_nd_tree_t tree;
+  int* child;              /* 2 per supernode (-1: none) */
+  int* height;
+  int* m;                  /* rows below, per supernode */
+  int** below;             /* sorted new indices of the rows below, per supernode */
+  long long nF, nB;        /* doubles of the two panel copies of the whole block */
+  long long rows_total;    /* sum of n + m */
+  long long contrib_total; /* sum of m */
+  /* CSC of the lower triangle in the new order */
+  int* cp; int* ri; double* cv;
+} nd_block_t;
+
+static void nd_block_free(nd_block_t* B) {
+  pa_nd_tree_free(&B->tree);
+  if (B->below) for (int s = 0; s < B->tree.nsn; ++s) free(B->below[s]);
+  free(B->below); free(B->child); free(B->height); free(B->m); free(B->cp); free(B->ri); free(B->cv);
+  memset(B, 0, sizeof(*B));
+}
+
+static int cmp_int(const void* a, const void* b) {
+  int x = *(const int*)a, y = *(const int*)b;
+  return (x > y) - (x < y);
+}
+
+/* A = local row panel (global column ids), the block = rows [r0, r0 + b) x columns [g0, g0 + b) */
+static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, int b, int leaf_rows) {
+  memset(B, 0, sizeof(*B));
+  B->b = b; B->row0 = r0;
+  /* local pattern of the diagonal block */
+  int* lrp = (int*)malloc(((size_t)b + 1) * sizeof(int));
+  size_t cnt = 0;
+  if (!lrp) return 1;
+  lrp[0] = 0;
+  for (int i = 0; i < b; ++i) {
+    for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) { int c = A->colInd[k]; if (c >= g0 && c < g0 + b) ++cnt; }
+    lrp[i + 1] = (int)cnt;
+  }
+  int* lci = (int*)malloc((cnt ? cnt : 1) * sizeof(int));
+  if (!lci) { free(lrp); return 1; }
+  cnt = 0;
+  for (int i = 0; i < b; ++i)
+    for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) { int c = A->colInd[k]; if (c >= g0 && c < g0 + b) lci[cnt++] = c - g0; }
+  int rc = pa_nd_order(b, lrp, lci, leaf_rows, &B->tree);
+  free(lrp); free(lci);
+  if (rc) return 1;
+  const int nsn = B->tree.nsn;
+  const int* perm = B->tree.perm;
+  int* ip = (int*)malloc((size_t)b * sizeof(int));
+  int* sn_of = (int*)malloc((size_t)b * sizeof(int));
+  B->child = (int*)malloc((size_t)2 * nsn * sizeof(int));
+  B->height = (int*)calloc((size_t)nsn, sizeof(int));
+  B->m = (int*)calloc((size_t)nsn, sizeof(int));
+  B->below = (int**)calloc((size_t)nsn, sizeof(int*));
+  B->cp = (int*)calloc((size_t)b + 1, sizeof(int));
+  if (!ip || !sn_of || !B->child || !B->height || !B->m || !B->below || !B->cp) { free(ip); free(sn_of); return 1; }
+  for (int i = 0; i < b; ++i) ip[perm[i]] = i;
+  for (int s = 0; s < nsn; ++s) {
+    B->child[2 * s] = B->child[2 * s + 1] = -1;
+    for (int i = B->tree.first[s]; i < B->tree.first[s + 1]; ++i) sn_of[i] = s;
+  }
+  for (int s = 0; s < nsn; ++s) {
+    int p = B->tree.parent[s];
+    if (p < 0) continue;
+    if (p <= s) { free(ip); free(sn_of); return 1; }       /* postorder violated */
+    if (B->child[2 * p] < 0) B->child[2 * p] = s; else if (B->child[2 * p + 1] < 0) B->child[2 * p + 1] = s; else { free(ip); free(sn_of); return 1; }
+    if (B->height[s] + 1 > B->height[p]) B->height[p] = B->height[s] + 1;
+  }
+  /* lower triangle by columns in the new order: column j = row perm[j] of the (symmetric) block */
+  for (int j = 0; j < b; ++j) {
+    int old = perm[j], c2 = 0;
+    for (int k = A->rowPtr[r0 + old]; k < A->rowPtr[r0 + old + 1]; ++k) {
+      int c = A->colInd[k];
+      if (c >= g0 && c < g0 + b && ip[c - g0] >= j) ++c2;
+    }
+    B->cp[j + 1] = B->cp[j] + c2;
+  }
+  B->ri = (int*)malloc((size_t)(B->cp[b] ? B->cp[b] : 1) * sizeof(int));
+  B->cv = (double*)malloc((size_t)(B->cp[b] ? B->cp[b] : 1) * sizeof(double));
+  if (!B->ri || !B->cv) { free(ip); free(sn_of); return 1; }
+  {
+    typedef struct { int r; double v; } rv_t;
+    int maxc = 0;
+    for (int j = 0; j < b; ++j) if (B->cp[j + 1] - B->cp[j] > maxc) maxc = B->cp[j + 1] - B->cp[j];
+    rv_t* buf = (rv_t*)malloc((size_t)(maxc ? maxc : 1) * sizeof(rv_t));
+    if (!buf) { free(ip); free(sn_of); return 1; }
+    for (int j = 0; j < b; ++j) {
+      int old = perm[j], l = 0;
+      for (int k = A->rowPtr[r0 + old]; k < A->rowPtr[r0 + old + 1]; ++k) {
+        int c = A->colInd[k];
+        if (c >= g0 && c < g0 + b && ip[c - g0] >= j) { buf[l].r = ip[c - g0]; buf[l].v = A->val[k]; ++l; }
+      }
+      for (int a = 1; a < l; ++a) { rv_t x = buf[a]; int q = a; while (q > 0 && buf[q - 1].r > x.r) { buf[q] = buf[q - 1]; --q; } buf[q] = x; }
+      for (int a = 0; a < l; ++a) { B->ri[B->cp[j] + a] = buf[a].r; B->cv[B->cp[j] + a] = buf[a].v; }
+    }
+    free(buf);
+  }
+  /* rows below every supernode: entries of its columns and of its children's lists beyond its last column */
+  int* mark = (int*)malloc((size_t)b * sizeof(int));
+  int* tmp = (int*)malloc((size_t)b * sizeof(int));
+  if (!mark || !tmp) { free(ip); free(sn_of); free(mark); free(tmp); return 1; }
+  for (int i = 0; i < b; ++i) mark[i] = -1;
+  for (int s = 0; s < nsn; ++s) {
+    int last = B->tree.first[s + 1], l = 0;
+    for (int j = B->tree.first[s]; j < last; ++j)
+      for (int k = B->cp[j]; k < B->cp[j + 1]; ++k) { int r = B->ri[k]; if (r >= last && mark[r] != s) { mark[r] = s; tmp[l++] = r; } }
+    for (int c = 0; c < 2; ++c) {
+      int ch = B->child[2 * s + c];
+      if (ch < 0) continue;
+      for (int k = 0; k < B->m[ch]; ++k) { int r = B->below[ch][k]; if (r >= last && mark[r] != s) { mark[r] = s; tmp[l++] = r; } }
+    }
+    qsort(tmp, l, sizeof(int), cmp_int);
+    B->m[s] = l;
+    B->below[s] = (int*)malloc((size_t)(l ? l : 1) * sizeof(int));
+    if (!B->below[s]) { free(ip); free(sn_of); free(mark); free(tmp); return 1; }
+    memcpy(B->below[s], tmp, (size_t)l * sizeof(int));
+    int n = last - B->tree.first[s];
+    int ld = (n + l + 1) & ~1, ldb = (n + 1) & ~1;
+    B->nF += (long long)ld * n;
+    B->nB += (long long)ldb * (n + l);
+    B->rows_total += n + l;
+    B->contrib_total += l;
+  }
+  free(ip); free(sn_of); free(mark); free(tmp);
+  return 0;
+}
+
+/* Dense partial Cholesky of the first n columns of the f x f front (lower triangle, column
+ * major, leading dimension f): L11 L11^T = F11, L21 = F21 L11^-T, F22 <- F22 - L21 L21^T.
+ * Returns 0 or 1 + the failing column. */
+static int front_factor(int f, int n, double* F) {
+  const int NB = 32;
+  for (int jb = 0; jb < n; jb += NB) {
+    int nb = n - jb < NB ? n - jb : NB;
+    for (int j = jb; j < jb + nb; ++j) {
+      double* cj = F + (size_t)j * f;
+      for (int k = jb; k < j; ++k) {
+        const double* ck = F + (size_t)k * f;
+        const double l = ck[j];
+        for (int i = j; i < f; ++i) cj[i] -= ck[i] * l;
+      }
+      if (!(cj[j] > 0.0)) return j + 1;
+      const double d = sqrt(cj[j]), id = 1.0 / d;
+      cj[j] = d;
+      for (int i = j + 1; i < f; ++i) cj[i] *= id;
+    }
+    /* trailing columns c >= jb + nb: F[c:, c] -= sum_k F[c:, k] F[c, k] */
+    for (int c = jb + nb; c < f; ++c) {
+      double* cc = F + (size_t)c * f;
+      for (int k = jb; k < jb + nb; ++k) {
+        const double* ck = F + (size_t)k * f;
+        const double l = ck[c];
+        if (l == 0.0) continue;
+        for (int i = c; i < f; ++i) cc[i] -= ck[i] * l;
+      }
+    }
+  }
+  return 0;
+}
+
+/* Multifrontal factorisation of one block into the two panel copies (host staging buffers hF, hB,
+ * laid out supernode after supernode) and dinv (1 / L_jj per new index).  *fail = 1 + new index
+ * of a non-positive pivot. */
+static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv, int* fail) {
+  const int nsn = B->tree.nsn, b = B->b;
+  double** upd = (double**)calloc((size_t)nsn, sizeof(double*));     /* update matrices waiting for the parent */
+  int* loc = (int*)malloc((size_t)b * sizeof(int));
+  if (!upd || !loc) { free(upd); free(loc); return 1; }
+  long long oF = 0, oB = 0;
+  int rc = 0;
+  *fail = 0;
+  for (int s = 0; s < nsn && !rc; ++s) {
+    const int c0 = B->tree.first[s], n = B->tree.first[s + 1] - c0, m = B->m[s], f = n + m;
+    double* F = (double*)calloc((size_t)f * f, sizeof(double));
+    if (!F) { rc = 1; break; }
+    for (int j = 0; j < n; ++j) loc[c0 + j] = j;
+    for (int k = 0; k < m; ++k) loc[B->below[s][k]] = n + k;
+    for (int j = 0; j < n; ++j)
+      for (int k = B->cp[c0 + j]; k < B->cp[c0 + j + 1]; ++k) F[(size_t)j * f + loc[B->ri[k]]] = B->cv[k];
+    for (int c = 0; c < 2; ++c) {
+      int ch = B->child[2 * s + c];
+      if (ch < 0) continue;
+      const int mc = B->m[ch];
+      const double* U = upd[ch];
+      for (int a = 0; a < mc; ++a) {
+        const int ja = loc[B->below[ch][a]];
+        for (int r = a; r < mc; ++r) F[(size_t)ja * f + loc[B->below[ch][r]]] += U[(size_t)a * mc + r];   /* (lists are sorted: ja <= row) */
+      }
+      free(upd[ch]); upd[ch] = NULL;
+    }
+    int bad = front_factor(f, n, F);
+    if (bad) { *fail = c0 + bad; free(F); rc = 2; break; }
+    /* panel copies: forward = columns divided by their pivot (unit diagonal implied), backward =
+     * row major, the n pivot rows divided by THEIR pivot, the m rows below as they are */
+    const int ld = (f + 1) & ~1, ldb = (n + 1) & ~1;
+    double* pf = hF + oF; double* pb = hB + oB;
+    memset(pf, 0, (size_t)ld * n * sizeof(double));
+    memset(pb, 0, (size_t)ldb * f * sizeof(double));
+    for (int j = 0; j < n; ++j) {
+      const double* cj = F + (size_t)j * f;
+      const double id = 1.0 / cj[j];
+      dinv[c0 + j] = id;
+      for (int i = j + 1; i < f; ++i) pf[(size_t)j * ld + i] = cj[i] * id;
+    }
+    for (int i = 0; i < f; ++i) {
+      const double sc = i < n ? 1.0 / F[(size_t)i * f + i] : 1.0;
+      const int kmax = i < n ? i : n;
+      for (int k = 0; k < kmax; ++k) pb[(size_t)i * ldb + k] = F[(size_t)k * f + i] * sc;
+    }
+    oF += (long long)ld * n; oB += (long long)ldb * f;
+    if (m > 0 && B->tree.parent[s] >= 0) {
+      double* U = (double*)malloc((size_t)m * m * sizeof(double));
+      if (!U) { free(F); rc = 1; break; }
+      for (int a = 0; a < m; ++a) memcpy(U + (size_t)a * m + a, F + (size_t)(n + a) * f + n + a, (size_t)(m - a) * sizeof(double));
+      upd[s] = U;
+    }
+    free(F);
+  }
+  for (int s = 0; s < nsn; ++s) free(upd[s]);
+  free(upd); free(loc);
+  return rc;
+}
+
+/* ---- build ------------------------------------------------------------------------------------------------- */
+/* blocks: nblk local block ids q; row0[q] / nrows[q] local panel rows; grow0[q] global first row. */
+int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int* row0, const int* nrows,
+                 const int* grow0, int m_local, int* fail_row) {
+  if (g_nd.created) pa_nd_free();
+  if (nblk <= 0) return 0;
+  pa_nd_t* S = &g_nd;
+  const char* le = getenv("PREALPS_ND_LEAF");
+  const int leaf_rows = le ? atoi(le) : 96;
+  nd_block_t* B = (nd_block_t*)calloc((size_t)nblk, sizeof(nd_block_t));
+  if (!B) return PA_FAIL("out of host memory");
+  int rc = 0;
+  *fail_row = -1;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int x = 0; x < nblk; ++x) {
+    int q = blocks[x];
+    if (nd_symbolic(&B[x], A, row0[q], grow0[q], nrows[q], leaf_rows)) {
+#pragma omp critical
+      rc = 1;
+    }
+  }
+  if (rc) { for (int x = 0; x < nblk; ++x) nd_block_free(&B[x]); free(B); return PA_FAIL("nested dissection of the diagonal blocks failed (out of memory)"); }
+  /* global numbering of the supernodes and offsets */
+  int nsn = 0, maxh = 0;
+  long long totF = 0, totB = 0, totrows = 0, totc = 0;
+  int* sn0 = (int*)malloc(((size_t)nblk + 1) * sizeof(int));
+  long long* bF = (long long*)malloc(((size_t)nblk + 1) * sizeof(long long));
+  long long* bB = (long long*)malloc(((size_t)nblk + 1) * sizeof(long long));
+  for (int x = 0; x < nblk; ++x) {
+    sn0[x] = nsn; bF[x] = totF; bB[x] = totB;
+    nsn += B[x].tree.nsn; totF += B[x].nF; totB += B[x].nB; totrows += B[x].rows_total; totc += B[x].contrib_total;
+    for (int s = 0; s < B[x].tree.nsn; ++s) if (B[x].height[s] > maxh) maxh = B[x].height[s];
+  }
+  sn0[nblk] = nsn; bF[nblk] = totF; bB[nblk] = totB;
+  if (totrows > 2147483000LL || totc > 2147483000LL) rc = PA_FAIL("block solve: index space of the fronts exceeds int32");
+  int* h_n = (int*)malloc((size_t)nsn * sizeof(int)); int* h_m = (int*)malloc((size_t)nsn * sizeof(int));
+  int* h_ld = (int*)malloc((size_t)nsn * sizeof(int));
+  long long* h_offF = (long long*)malloc((size_t)nsn * sizeof(long long));
+  long long* h_offB = (long long*)malloc((size_t)nsn * sizeof(long long));
+  int* h_rows_off = (int*)malloc((size_t)nsn * sizeof(int)); int* h_coff = (int*)malloc((size_t)nsn * sizeof(int));
+  int* h_ccoff = (int*)malloc((size_t)2 * nsn * sizeof(int));
+  int* h_rows = (int*)malloc((size_t)(totrows ? totrows : 1) * sizeof(int));
+  int* h_src = (int*)malloc((size_t)2 * (totrows ? totrows : 1) * sizeof(int));
+  int* h_height = (int*)malloc((size_t)nsn * sizeof(int));
+  double* h_dinv = (double*)calloc((size_t)(m_local ? m_local : 1), sizeof(double));
+  if (!h_n || !h_m || !h_ld || !h_offF || !h_offB || !h_rows_off || !h_coff || !h_ccoff || !h_rows || !h_src || !h_height || !h_dinv)
+    rc = PA_FAIL("out of host memory for the block-solve plan");
+  if (!rc) {
+    long long ro = 0, co = 0;
+    for (int x = 0; x < nblk; ++x) {
+      const nd_block_t* Bx = &B[x];
+      long long oF = bF[x], oB = bB[x];
+      for (int s = 0; s < Bx->tree.nsn; ++s) {
+        int g = sn0[x] + s, c0 = Bx->tree.first[s], n = Bx->tree.first[s + 1] - c0, m = Bx->m[s];
+        h_n[g] = n; h_m[g] = m; h_ld[g] = (n + m + 1) & ~1; h_offF[g] = oF; h_offB[g] = oB;
+        h_rows_off[g] = (int)ro; h_coff[g] = (int)co; h_height[g] = Bx->height[s];
+        oF += (long long)h_ld[g] * n; oB += (long long)((n + 1) & ~1) * (n + m);
+        for (int j = 0; j < n; ++j) h_rows[ro + j] = Bx->row0 + Bx->tree.perm[c0 + j];
+        for (int k = 0; k < m; ++k) h_rows[ro + n + k] = Bx->row0 + Bx->tree.perm[Bx->below[s][k]];
+        for (int r = 0; r < 2 * (n + m); ++r) h_src[2 * ro + r] = -1;
+        ro += n + m; co += m;
+      }
+      /* where every front row finds its children's contributions (and their offsets) */
+      for (int s = 0; s < Bx->tree.nsn; ++s) {
+        int g = sn0[x] + s, c0 = Bx->tree.first[s], n = h_n[g];
+        for (int c = 0; c < 2; ++c) {
+          int ch = Bx->child[2 * s + c];
+          h_ccoff[2 * g + c] = ch < 0 ? -1 : h_coff[sn0[x] + ch];
+          if (ch < 0) continue;
+          /* child's rows below are a subset of (our columns, our rows below): both sorted */
+          int pos = 0;
+          for (int k = 0; k < Bx->m[ch]; ++k) {
+            int r = Bx->below[ch][k], lr;
+            if (r < c0 + n) lr = r - c0;
+            else { while (pos < Bx->m[s] && Bx->below[s][pos] < r) ++pos; lr = n + pos; }
+            h_src[2 * ((long long)h_rows_off[g] + lr) + c] = k;
+          }
+        }
+      }
+    }
+  }
+  /* device arrays */
+  if (!rc) {
+    S->d_n = (int*)pa_rt_malloc((size_t)nsn * sizeof(int)); S->d_m = (int*)pa_rt_malloc((size_t)nsn * sizeof(int));
+    S->d_ld = (int*)pa_rt_malloc((size_t)nsn * sizeof(int));
+    S->d_offF = (long long*)pa_rt_malloc((size_t)nsn * sizeof(long long));
+    S->d_offB = (long long*)pa_rt_malloc((size_t)nsn * sizeof(long long));
+    S->d_rows_off = (int*)pa_rt_malloc((size_t)nsn * sizeof(int)); S->d_coff = (int*)pa_rt_malloc((size_t)nsn * sizeof(int));
+    S->d_ccoff = (int*)pa_rt_malloc((size_t)2 * nsn * sizeof(int));
+    S->d_rows = (int*)pa_rt_malloc((size_t)(totrows ? totrows : 1) * sizeof(int));
+    S->d_src = (int*)pa_rt_malloc((size_t)2 * (totrows ? totrows : 1) * sizeof(int));
+    S->d_dinv = (double*)pa_rt_malloc((size_t)(m_local ? m_local : 1) * sizeof(double));
+    S->d_F = (double*)pa_rt_malloc((size_t)(totF + 64) * sizeof(double));
+    S->d_B = (double*)pa_rt_malloc((size_t)(totB + 64) * sizeof(double));
+    if (!S->d_n || !S->d_m || !S->d_ld || !S->d_offF || !S->d_offB || !S->d_rows_off || !S->d_coff || !S->d_ccoff ||
+        !S->d_rows || !S->d_src || !S->d_dinv || !S->d_F || !S->d_B)
+      rc = PA_FAIL("allocating %.2f GB of block factors on the device failed: %s", 8e-9 * (double)(totF + totB), pa_rt_error());
+  }
+  /* numeric factorisation, block after block on the host threads, each block uploaded when done */
+  if (!rc) {
+    int fail_new = 0, fail_blk = -1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int x = 0; x < nblk; ++x) {
+      if (rc) continue;
+      double* hF = (double*)malloc((size_t)(B[x].nF ? B[x].nF : 1) * sizeof(double));
+      double* hB = (double*)malloc((size_t)(B[x].nB ? B[x].nB : 1) * sizeof(double));
+      double* di = (double*)malloc((size_t)B[x].b * sizeof(double));
+      int fail = 0, r2 = (!hF || !hB || !di) ? 1 : nd_numeric(&B[x], hF, hB, di, &fail);
+      if (!r2) {
+        for (int i = 0; i < B[x].b; ++i) h_dinv[B[x].row0 + B[x].tree.perm[i]] = di[i];
+#pragma omp critical
+        {
+          if (pa_rt_h2d(S->d_F + bF[x], hF, (size_t)B[x].nF * sizeof(double)) ||
+              pa_rt_h2d(S->d_B + bB[x], hB, (size_t)B[x].nB * sizeof(double))) r2 = 3;
+        }
+      }
+      if (r2) {
+#pragma omp critical
+        { if (!rc) { rc = r2; fail_new = fail; fail_blk = x; } }
+      }
+      free(hF); free(hB); free(di);
+    }
+    if (rc == 2) { *fail_row = B[fail_blk].row0 + B[fail_blk].tree.perm[fail_new - 1]; }
+    else if (rc) rc = PA_FAIL("factorising the large diagonal blocks failed (%s)", rc == 3 ? pa_rt_error() : "out of host memory");
+  }
+  if (!rc) {
+    int bad = pa_rt_h2d(S->d_n, h_n, (size_t)nsn * sizeof(int)) || pa_rt_h2d(S->d_m, h_m, (size_t)nsn * sizeof(int)) ||
+              pa_rt_h2d(S->d_ld, h_ld, (size_t)nsn * sizeof(int)) || pa_rt_h2d(S->d_offF, h_offF, (size_t)nsn * sizeof(long long)) ||
+              pa_rt_h2d(S->d_offB, h_offB, (size_t)nsn * sizeof(long long)) ||
+              pa_rt_h2d(S->d_rows_off, h_rows_off, (size_t)nsn * sizeof(int)) || pa_rt_h2d(S->d_coff, h_coff, (size_t)nsn * sizeof(int)) ||
+              pa_rt_h2d(S->d_ccoff, h_ccoff, (size_t)2 * nsn * sizeof(int)) ||
+              pa_rt_h2d(S->d_rows, h_rows, (size_t)totrows * sizeof(int)) || pa_rt_h2d(S->d_src, h_src, (size_t)2 * totrows * sizeof(int)) ||
+              pa_rt_h2d(S->d_dinv, h_dinv, (size_t)m_local * sizeof(double));
+    if (bad) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
+  }
+  /* launch lists: by height, then by size class of the front (rows per thread) */
+  if (!rc) {
+    const int ncls = pa_nd_num_classes();
+    int cap = (maxh + 1) * ncls;
+    S->l_height = (int*)calloc((size_t)cap, sizeof(int)); S->l_class = (int*)calloc((size_t)cap, sizeof(int));
+    S->l_count = (int*)calloc((size_t)cap, sizeof(int)); S->l_list = (int**)calloc((size_t)cap, sizeof(int*));
+    S->l_list_c = (const int**)calloc((size_t)cap, sizeof(int*));
+    int* tmp = (int*)malloc((size_t)nsn * sizeof(int));
+    for (int h = 0; h <= maxh && !rc; ++h)
+      for (int c = 0; c < ncls && !rc; ++c) {
+        int cntl = 0;
+        for (int g = 0; g < nsn; ++g) if (h_height[g] == h && pa_nd_class_of(h_n[g] + h_m[g]) == c) tmp[cntl++] = g;
+        if (!cntl) continue;
+        int i = S->nlaunch++;
+        S->l_height[i] = h; S->l_class[i] = c; S->l_count[i] = cntl;
+        S->l_list[i] = (int*)pa_rt_malloc((size_t)cntl * sizeof(int));
+        if (!S->l_list[i] || pa_rt_h2d(S->l_list[i], tmp, (size_t)cntl * sizeof(int))) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
+        S->l_list_c[i] = S->l_list[i];
+      }
+    for (int g = 0; g < nsn && !rc; ++g) if (pa_nd_class_of(h_n[g] + h_m[g]) < 0) rc = PA_FAIL("block solve: a front of %d rows exceeds the kernel's limit; use more subdomains", h_n[g] + h_m[g]);
+    free(tmp);
+  }
+  free(h_n); free(h_m); free(h_ld); free(h_offF); free(h_offB); free(h_rows_off); free(h_coff); free(h_ccoff);
+  free(h_rows); free(h_src); free(h_height); free(h_dinv); free(sn0); free(bF); free(bB);
+  for (int x = 0; x < nblk; ++x) nd_block_free(&B[x]);
+  free(B);
+  if (rc) { pa_nd_free(); return rc == 2 ? 2 : 1; }
+  S->nsn = nsn; S->contrib_rows = (size_t)totc; S->bytes = 8.0 * (double)(totF + totB);
+  pa_nd_plan_t* pl = &S->plan;
+  pl->n = S->d_n; pl->m = S->d_m; pl->ld = S->d_ld; pl->offF = S->d_offF; pl->offB = S->d_offB; pl->rows_off = S->d_rows_off;
+  pl->coff = S->d_coff; pl->ccoff = S->d_ccoff; pl->rows = S->d_rows; pl->src = S->d_src; pl->dinv = S->d_dinv;
+  pl->F = S->d_F; pl->B = S->d_B;
+  pl->nlaunch = S->nlaunch; pl->l_class = S->l_class; pl->l_count = S->l_count; pl->l_list = S->l_list_c;
+  S->created = 1;
+  return 0;
+}
+
+/* out(rows of the ND blocks) = blockdiag^-1 in(...) for the ts-strided panels */
+int pa_nd_apply(int ts, const double* in, double* out) {
+  pa_nd_t* S = &g_nd;
+  if (!S->created) return 0;
+  if (S->contrib_ts < ts) {
+    pa_rt_free(S->d_contrib);
+    S->d_contrib = (double*)pa_rt_malloc((S->contrib_rows ? S->contrib_rows : 1) * (size_t)ts * sizeof(double));
+    if (!S->d_contrib) return PA_FAIL("block solve: scratch of %zu rows: %s", S->contrib_rows, pa_rt_error());
+    S->contrib_ts = ts;
+  }
+  S->plan.contrib = S->d_contrib;
+  if (pa_k_nd_apply(&S->plan, ts, in, out)) return PA_FAIL("block-solve kernel launch failed");
+  return 0;
+}

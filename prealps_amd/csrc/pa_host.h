@@ -57,6 +57,16 @@ int pa_panel_stride(int enlFac);
 static inline int pa_desc_stride(const CPLM_Mat_Dense_t* A) { return A->info.lda; }
 void pa_set_desc(CPLM_Mat_Dense_t* A, int M, int N, int m, int n, int ts);
 
+/* ---- nested dissection of a diagonal block (partition.c), for the sparse block solve (nd.c) */
+typedef struct {
+  int nsn;          /* supernodes (leaves and separators) in postorder: children before parents */
+  int* first;       /* nsn + 1: rows [first[s], first[s+1]) of the new order form supernode s */
+  int* parent;      /* nsn: parent supernode, -1 for a root */
+  int* perm;        /* n: perm[new] = old (block-local row) */
+} pa_nd_tree_t;
+int pa_nd_order(int n, const int* rp, const int* ci, int leaf_rows, pa_nd_tree_t* t);
+void pa_nd_tree_free(pa_nd_tree_t* t);
+
 double pa_bj_factor_bytes(void);
 int pa_bj_max_bandwidth(void);
 double pa_bj_setup_seconds(int which);   /* 0: ordering + band Cholesky, 1: sweep layouts + upload */

@@ -121,6 +121,14 @@ static int build_graph(int N, const int* rp, const int* ci, int merge, int* cid,
 }
 
 /* ---- 2. recursive bisection in a landmark embedding ---------------------------------------------- */
+typedef struct { double key; int idx; } keyidx_t;
+static int cmp_keyidx(const void* a, const void* b) {
+  const keyidx_t* x = (const keyidx_t*)a; const keyidx_t* y = (const keyidx_t*)b;
+  if (x->key < y->key) return -1;
+  if (x->key > y->key) return 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
 #define NLM 8      /* landmarks per sub-graph */
 
 typedef struct {
@@ -130,20 +138,11 @@ typedef struct {
   int* loc;        /* position of a member vertex in the current list */
   int* queue;      /* BFS queue / scratch, n ints */
   int* dist;       /* NLM * n hop distances, list-local */
-  double* key;     /* projection, list-local */
-  int* idx;        /* sort permutation, list-local */
+  keyidx_t* ki;    /* (projection, list-local index), sorted along the axis */
   char* side;      /* list-local */
   int* tmp;        /* n ints */
-  int next_tag;
+  int next_tag, cur_tag;
 } rb_t;
-
-static const double* g_sort_key;
-static int cmp_by_key(const void* a, const void* b) {
-  double x = g_sort_key[*(const int*)a], y = g_sort_key[*(const int*)b];
-  if (x < y) return -1;
-  if (x > y) return 1;
-  return (*(const int*)a > *(const int*)b) - (*(const int*)a < *(const int*)b);
-}
 
 /* hop distances from `start` inside the current sub-graph; vertices of other components keep -1.
  * Returns the number of vertices reached; *last = the last one. */
@@ -164,12 +163,15 @@ static int rb_bfs(rb_t* c, const int* list, int len, int tag, int start, int* di
   return tail;
 }
 
-static void rb_split(rb_t* c, int* list, int len, long long wtot, int k, int base) {
+/* Cut the sub-graph `list` in two: side[i] (list-local) = 0 / 1, about `want` of the weight and
+ * at least min0 (min1) vertices on side 0 (1).  Returns the number of vertices on side 0 and
+ * its weight through *w0.  On return tag / loc still describe this list. */
+static int rb_bisect(rb_t* c, const int* list, int len, long long wtot, long long want, int min0, int min1,
+                     long long* w0) {
   const graph_t* g = c->g;
-  if (k <= 1) { for (int i = 0; i < len; ++i) c->part[list[i]] = base; return; }
   const int tag = c->next_tag++;
   for (int i = 0; i < len; ++i) { c->tag[list[i]] = tag; c->loc[list[i]] = i; }
-  const int k1 = k / 2, k2 = k - k1;
+  c->cur_tag = tag;
   /* landmarks by farthest-point sampling; a vertex another component hides from all landmarks
    * so far is infinitely far and becomes the next landmark */
   int nlm = 0, lm = list[0], last = list[0];
@@ -223,24 +225,22 @@ static void rb_split(rb_t* c, int* list, int len, long long wtot, int k, int bas
   for (int i = 0; i < len; ++i) {
     double s = 0.0;
     for (int j = 0; j < nlm; ++j) s += ax[j] * (c->dist[(size_t)j * len + i] - mean[j]);
-    c->key[i] = s;
-    c->idx[i] = i;
+    c->ki[i].key = s;
+    c->ki[i].idx = i;
   }
-  g_sort_key = c->key;
-  qsort(c->idx, len, sizeof(int), cmp_by_key);
-  /* weighted median: k1 / k of the weight to the left, at least k1 (k2) vertices per side */
-  const long long want = (long long)((double)wtot * k1 / k + 0.5);
+  qsort(c->ki, len, sizeof(keyidx_t), cmp_keyidx);
+  /* weighted median, at least min0 (min1) vertices per side */
   long long acc = 0, wl = 0;
   int cut = 0;
   for (int i = 0; i < len; ++i) {
-    long long w = g->vw[list[c->idx[i]]];
-    if (i >= k1 && (acc + w - want > want - acc || len - i <= k2)) break;
+    long long w = g->vw[list[c->ki[i].idx]];
+    if (i >= min0 && (acc + w - want > want - acc || len - i <= min1)) break;
     acc += w; cut = i + 1;
   }
-  if (cut > len - k2) cut = len - k2;
-  if (cut < k1) cut = k1;
-  for (int i = 0; i < len; ++i) c->side[c->idx[i]] = i >= cut;
-  for (int i = 0; i < cut; ++i) wl += g->vw[list[c->idx[i]]];
+  if (cut > len - min1) cut = len - min1;
+  if (cut < min0) cut = min0;
+  for (int i = 0; i < len; ++i) c->side[c->ki[i].idx] = i >= cut;
+  for (int i = 0; i < cut; ++i) wl += g->vw[list[c->ki[i].idx]];
   /* straighten the cut: a vertex with more neighbours across than on its own side changes
    * sides while the halves stay within 1 % of their targets (and keep enough vertices) */
   {
@@ -249,22 +249,31 @@ static void rb_split(rb_t* c, int* list, int len, long long wtot, int k, int bas
     for (int pass = 0; pass < 3; ++pass) {
       int moved = 0;
       for (int i = 0; i < len; ++i) {
-        int v = list[i], s = c->side[i], own = 0, other = 0;
+        int v = list[i], sd = c->side[i], own = 0, other = 0;
         for (int q = g->xadj[v]; q < g->xadj[v + 1]; ++q) {
           int u = g->adj[q];
           if (c->tag[u] != tag) continue;
-          if (c->side[c->loc[u]] == s) own += g->vw[u]; else other += g->vw[u];
+          if (c->side[c->loc[u]] == sd) own += g->vw[u]; else other += g->vw[u];
         }
         if (other <= own) continue;
-        long long w = g->vw[v], nwl = s ? wl + w : wl - w;
-        int nnl = s ? nl + 1 : nl - 1;
-        if (nwl > want + slack || nwl < want - slack || nnl < k1 || len - nnl < k2) continue;
-        c->side[i] = (char)!s; wl = nwl; nl = nnl; ++moved;
+        long long w = g->vw[v], nwl = sd ? wl + w : wl - w;
+        int nnl = sd ? nl + 1 : nl - 1;
+        if (nwl > want + slack || nwl < want - slack || nnl < min0 || len - nnl < min1) continue;
+        c->side[i] = (char)!sd; wl = nwl; nl = nnl; ++moved;
       }
       if (!moved) break;
     }
     cut = nl;
   }
+  *w0 = wl;
+  return cut;
+}
+
+static void rb_split(rb_t* c, int* list, int len, long long wtot, int k, int base) {
+  if (k <= 1) { for (int i = 0; i < len; ++i) c->part[list[i]] = base; return; }
+  const int k1 = k / 2, k2 = k - k1;
+  long long wl = 0;
+  rb_bisect(c, list, len, wtot, (long long)((double)wtot * k1 / k + 0.5), k1, k2, &wl);
   /* stable split of the list */
   int a = 0, b = 0;
   for (int i = 0; i < len; ++i) if (!c->side[i]) list[a++] = list[i]; else c->tmp[b++] = list[i];
@@ -273,23 +282,31 @@ static void rb_split(rb_t* c, int* list, int len, long long wtot, int k, int bas
   rb_split(c, list + a, b, wtot - wl, k2, base + k1);
 }
 
+static int rb_alloc(rb_t* c, const graph_t* g, int* part) {
+  int n = g->n;
+  memset(c, 0, sizeof(*c));
+  c->g = g; c->part = part; c->next_tag = 1;
+  c->tag = (int*)calloc((size_t)n, sizeof(int)); c->loc = (int*)malloc((size_t)n * sizeof(int));
+  c->queue = (int*)malloc((size_t)n * sizeof(int)); c->dist = (int*)malloc((size_t)NLM * n * sizeof(int));
+  c->ki = (keyidx_t*)malloc((size_t)n * sizeof(keyidx_t));
+  c->side = (char*)malloc((size_t)n); c->tmp = (int*)malloc((size_t)n * sizeof(int));
+  return !c->tag || !c->loc || !c->queue || !c->dist || !c->ki || !c->side || !c->tmp;
+}
+static void rb_free(rb_t* c) {
+  free(c->tag); free(c->loc); free(c->queue); free(c->dist); free(c->ki); free(c->side); free(c->tmp);
+}
+
 static int bisect(const graph_t* g, int k, int* part) {
   int n = g->n;
   rb_t c;
-  memset(&c, 0, sizeof(c));
-  c.g = g; c.part = part; c.next_tag = 1;
-  c.tag = (int*)calloc((size_t)n, sizeof(int)); c.loc = (int*)malloc((size_t)n * sizeof(int));
-  c.queue = (int*)malloc((size_t)n * sizeof(int)); c.dist = (int*)malloc((size_t)NLM * n * sizeof(int));
-  c.key = (double*)malloc((size_t)n * sizeof(double)); c.idx = (int*)malloc((size_t)n * sizeof(int));
-  c.side = (char*)malloc((size_t)n); c.tmp = (int*)malloc((size_t)n * sizeof(int));
   int* list = (int*)malloc((size_t)n * sizeof(int));
-  int rc = !c.tag || !c.loc || !c.queue || !c.dist || !c.key || !c.idx || !c.side || !c.tmp || !list;
+  int rc = rb_alloc(&c, g, part) || !list;
   if (!rc) {
     long long wtot = 0;
     for (int v = 0; v < n; ++v) { list[v] = v; wtot += g->vw[v]; }
     rb_split(&c, list, n, wtot, k, 0);
   }
-  free(c.tag); free(c.loc); free(c.queue); free(c.dist); free(c.key); free(c.idx); free(c.side); free(c.tmp); free(list);
+  rb_free(&c); free(list);
   return rc;
 }
 
@@ -351,6 +368,142 @@ static int join_fragments(const graph_t* g, int k, int* part, long long limit) {
   }
   free(comp); free(stack); free(best_w); free(best_c); free(cw);
   return 0;
+}
+
+/* ---- nested dissection of one diagonal block (for the sparse block solve, nd.c) --------------------- */
+typedef struct {
+  rb_t rb;
+  long long leaf;      /* a piece of at most this weight is not cut any further */
+  int nsn, cap;
+  int* parent;         /* per supernode */
+  int* vfirst;         /* per supernode: start in vorder */
+  int* vorder;         /* vertices in elimination order */
+  int nv;
+} nd_ctx_t;
+
+static int nd_new(nd_ctx_t* c, const int* verts, int cnt) {
+  if (c->nsn == c->cap) {
+    c->cap = c->cap ? 2 * c->cap : 256;
+    c->parent = (int*)realloc(c->parent, (size_t)c->cap * sizeof(int));
+    c->vfirst = (int*)realloc(c->vfirst, ((size_t)c->cap + 1) * sizeof(int));
+    if (!c->parent || !c->vfirst) return -1;
+  }
+  int s = c->nsn++;
+  c->parent[s] = -1;
+  c->vfirst[s] = c->nv;
+  memcpy(c->vorder + c->nv, verts, (size_t)cnt * sizeof(int));
+  c->nv += cnt;
+  c->vfirst[s + 1] = c->nv;
+  return s;
+}
+
+/* returns the supernode at the root of the piece, -1 on allocation failure */
+static int nd_rec(nd_ctx_t* c, int* list, int len, long long w) {
+  const graph_t* g = c->rb.g;
+  if (w <= c->leaf || len < 8) return nd_new(c, list, len);
+  long long w0 = 0;
+  rb_bisect(&c->rb, list, len, w, w / 2, 1, 1, &w0);
+  const int tag = c->rb.cur_tag;
+  char* side = c->rb.side;
+  /* vertex separator: the boundary of one side, whichever is lighter */
+  long long b0 = 0, b1 = 0;
+  for (int i = 0; i < len; ++i) {
+    int v = list[i], sd = side[i], bd = 0;
+    for (int q = g->xadj[v]; q < g->xadj[v + 1] && !bd; ++q) {
+      int u = g->adj[q];
+      bd = c->rb.tag[u] == tag && (side[c->rb.loc[u]] & 1) != sd;
+    }
+    if (bd) { side[i] = (char)(sd | 2); if (sd) b1 += g->vw[v]; else b0 += g->vw[v]; }
+  }
+  const int take = b0 <= b1 ? 0 : 1;
+  int nl = 0, nr = 0, ns = 0;
+  long long wl = 0, wr = 0;
+  int* tmp = c->rb.tmp;                 /* [right | separator] while the left part is compacted in place */
+  for (int i = 0; i < len; ++i) {
+    int v = list[i], sd = side[i] & 1, sep = (side[i] & 2) && sd == take;
+    if (sep) ++ns;
+    else if (sd) { ++nr; wr += g->vw[v]; }
+    else { wl += g->vw[v]; }
+  }
+  nl = len - nr - ns;
+  if (nl == 0 || nr == 0) return nd_new(c, list, len);      /* nothing left on one side: a dense leaf */
+  {
+    int a = 0, b = 0, d = 0;
+    for (int i = 0; i < len; ++i) {
+      int v = list[i], sd = side[i] & 1, sep = (side[i] & 2) && sd == take;
+      if (sep) tmp[nr + d++] = v; else if (sd) tmp[b++] = v; else list[a++] = v;
+    }
+    memcpy(list + nl, tmp, (size_t)(nr + ns) * sizeof(int));
+  }
+  int l = nd_rec(c, list, nl, wl);
+  if (l < 0) return -1;
+  int r = nd_rec(c, list + nl, nr, wr);
+  if (r < 0) return -1;
+  int s = nd_new(c, list + nl + nr, ns);
+  if (s < 0) return -1;
+  c->parent[l] = s; c->parent[r] = s;
+  return s;
+}
+
+void pa_nd_tree_free(pa_nd_tree_t* t) {
+  free(t->first); free(t->parent); free(t->perm);
+  memset(t, 0, sizeof(*t));
+}
+
+/* Nested-dissection order of an n x n block with a structurally symmetric pattern (local CSR,
+ * diagonal stored): supernodes (leaves and separators) in postorder, each a contiguous range of
+ * the new order; rows with identical patterns stay together.  Thread safe. */
+int pa_nd_order(int n, const int* rp, const int* ci, int leaf_rows, pa_nd_tree_t* t) {
+  memset(t, 0, sizeof(*t));
+  int* cid = (int*)malloc((size_t)n * sizeof(int));
+  graph_t g;
+  memset(&g, 0, sizeof(g));
+  if (!cid || build_graph(n, rp, ci, 1, cid, &g)) { free(cid); graph_free(&g); return 1; }
+  nd_ctx_t c;
+  memset(&c, 0, sizeof(c));
+  c.leaf = leaf_rows;
+  c.vorder = (int*)malloc((size_t)g.n * sizeof(int));
+  int* list = (int*)malloc((size_t)g.n * sizeof(int));
+  int rc = rb_alloc(&c.rb, &g, NULL) || !c.vorder || !list;
+  if (!rc) {
+    /* connected components are independent trees: handled by the bisection itself (a cut that
+     * separates components has an empty separator) */
+    long long w = 0;
+    for (int v = 0; v < g.n; ++v) { list[v] = v; w += g.vw[v]; }
+    rc = nd_rec(&c, list, g.n, w) < 0;
+  }
+  if (!rc) {
+    /* rows of every vertex, then the row order */
+    int* vstart = (int*)calloc((size_t)g.n + 1, sizeof(int));
+    int* vrows = (int*)malloc((size_t)n * sizeof(int));
+    t->first = (int*)malloc(((size_t)c.nsn + 1) * sizeof(int));
+    t->parent = (int*)malloc((size_t)c.nsn * sizeof(int));
+    t->perm = (int*)malloc((size_t)n * sizeof(int));
+    rc = !vstart || !vrows || !t->first || !t->parent || !t->perm;
+    if (!rc) {
+      for (int i = 0; i < n; ++i) vstart[cid[i] + 1]++;
+      for (int v = 0; v < g.n; ++v) vstart[v + 1] += vstart[v];
+      int* fill = c.rb.tmp;
+      memcpy(fill, vstart, (size_t)g.n * sizeof(int));
+      for (int i = 0; i < n; ++i) vrows[fill[cid[i]]++] = i;
+      int pos = 0;
+      for (int s = 0; s < c.nsn; ++s) {
+        t->first[s] = pos;
+        t->parent[s] = c.parent[s];
+        for (int q = c.vfirst[s]; q < c.vfirst[s + 1]; ++q) {
+          int v = c.vorder[q];
+          for (int e = vstart[v]; e < vstart[v + 1]; ++e) t->perm[pos++] = vrows[e];
+        }
+      }
+      t->first[c.nsn] = pos;
+      t->nsn = c.nsn;
+      if (pos != n) rc = 1;
+    }
+    free(vstart); free(vrows);
+  }
+  rb_free(&c.rb); free(c.parent); free(c.vfirst); free(c.vorder); free(list); free(cid); graph_free(&g);
+  if (rc) pa_nd_tree_free(t);
+  return rc;
 }
 
 /* ---- entry point ------------------------------------------------------------------------------------------ */
