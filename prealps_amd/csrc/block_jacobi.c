@@ -38,7 +38,7 @@ typedef struct {
   int nclass; int class_R[16]; int class_count[16]; int class_wmax[16]; int* class_list[16];
   const int* class_list_c[16];
   pa_bj_plan_t plan;
-  double factor_bytes; int max_bw;
+  double factor_bytes; int max_bw; int nd_blocks;
 } pa_bj_t;
 
 /* window of a wide block = record length (kernels.hip: bjw_window) */
@@ -63,6 +63,7 @@ double pa_bj_setup_seconds(int which) { return g_bj_setup_s[which ? 1 : 0]; }
 double pa_bj_factor_bytes(void) { return g_bj.created ? g_bj.factor_bytes : 0.0; }
 int pa_bj_max_bandwidth(void) { return g_bj.created ? g_bj.max_bw : 0; }
 int pa_bj_nparts(void) { return g_bj.created ? g_bj.np : 0; }
+int pa_bj_nd_blocks(void) { return g_bj.created ? g_bj.nd_blocks : 0; }
 
 void preAlps_BlockJacobiFree(void) {
   pa_bj_t* s = &g_bj;
@@ -70,6 +71,7 @@ void preAlps_BlockJacobiFree(void) {
   pa_rt_free(s->d_map_f); pa_rt_free(s->d_map_b);
   pa_rt_free(s->d_Lf); pa_rt_free(s->d_Lb); pa_rt_free(s->d_invd_f); pa_rt_free(s->d_invd_b);
   for (int c = 0; c < 16; ++c) pa_rt_free(s->class_list[c]);
+  pa_nd_free();
   memset(s, 0, sizeof(*s));
 }
 
@@ -160,6 +162,13 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   size_t* coo_n = (size_t*)calloc(np, sizeof(size_t));
   int fail_row = -1;
   for (int q = 0; q < np; ++q) { row0[q] = rowPos[op->part0 + q] - row_off; nrows[q] = rowPos[op->part0 + q + 1] - rowPos[op->part0 + q]; }
+  /* Large blocks (few subdomains of thousands of rows, the reference's own regime) get a sparse
+   * nested-dissection factor instead of a band (nd.c).  PREALPS_BJ_ND: 0 never, 1 (default) for
+   * blocks of at least PREALPS_BJ_ND_ROWS (2048) rows whose band exceeds 256, 2 for every block of
+   * at least PREALPS_BJ_ND_ROWS rows. */
+  char* is_nd = (char*)calloc(np ? np : 1, 1);
+  const int nd_mode = getenv("PREALPS_BJ_ND") ? atoi(getenv("PREALPS_BJ_ND")) : 1;
+  const int nd_rows = getenv("PREALPS_BJ_ND_ROWS") ? atoi(getenv("PREALPS_BJ_ND_ROWS")) : 2048;
 
   double t_setup0 = pa_wtime();
   /* PREALPS_BJ_FACTOR=host keeps every factorisation on the host threads */
@@ -197,6 +206,12 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
      * axis slowest) can have the narrower band -- keep whichever is narrower */
     if (wnat <= w) { w = wnat; for (int i = 0; i < b; ++i) { order[i] = i; pos[i] = i; } }
     bw[q] = w;
+    if (nd_mode && b >= nd_rows && (nd_mode >= 2 || w > 256)) {
+      is_nd[q] = 1;
+      for (int j = 0; j < b; ++j) { map_f[r0 + j] = j; map_b[r0 + j] = b - 1 - j; }
+      free(xadj); free(adj); free(deg); free(order); free(pos); free(queue); free(level);
+      continue;
+    }
     /* band[i*(w+1) + d] = A(new i, new i-d); blocks that go to the blocked device
      * factorisation (k_bj_factor_big) are assembled diagonal-major instead: band[d*b + i] */
     int big_dev = dev_factor && w > dev_wmax;
@@ -292,13 +307,16 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       if (wide_from > 64 * maxR - 64) wide_from = 64 * maxR - 64;
     }
   }
+  int maxw_all = 0;
   for (int q = 0; q < np; ++q) {
     int wide = bw[q] > wide_from;
     long long reclen = wide ? bj_wide_window(bw[q]) : ((bw[q] + 2) & ~1);
+    if (bw[q] > maxw_all) maxw_all = bw[q];
+    if (is_nd[q]) { off[q + 1] = off[q]; continue; }     /* no band records: sparse factor */
     off[q + 1] = off[q] + (long long)nrows[q] * reclen;
     if (bw[q] > maxw) maxw = bw[q];
   }
-  s->max_bw = maxw;
+  s->max_bw = maxw_all;
   if (!rc && bj_wide_window(maxw) > 4096)
     rc = PA_FAIL("block-Jacobi: a diagonal block has bandwidth %d after reordering; the workgroup-resident "
                  "solve supports up to 4032 -- use more (smaller) subdomains", maxw);
@@ -315,9 +333,9 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
         pa_rt_memset(s->d_Lf, 0, (tot + pad) * sizeof(double)) || pa_rt_memset(s->d_Lb, 0, (tot + pad) * sizeof(double)))
       rc = PA_FAIL("allocating %zu factor entries on the device failed: %s", tot, pa_rt_error());
   }
-  int ndev = 0;
-  for (int q = 0; q < np; ++q) if (dev_factor) ++ndev;
-  if (!rc && ndev < np) {
+  int ndev = 0, nnd = 0;
+  for (int q = 0; q < np; ++q) { if (is_nd[q]) ++nnd; else if (dev_factor) ++ndev; }
+  if (!rc && ndev + nnd < np) {
     /* host-factored blocks: runs of consecutive blocks (up to 64 MiB of records) are laid out
      * by the host threads into a staging buffer (256 MiB, or one block if larger) and go to
      * the device in one copy each */
@@ -326,9 +344,9 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     double* sf = NULL; double* sg = NULL;
     int q = 0;
     while (q < np && !rc) {
-      if (dev_factor) { ++q; continue; }
+      if (dev_factor || is_nd[q]) { ++q; continue; }
       int q1 = q;
-      while (q1 < np && !dev_factor && (q1 == q || (size_t)(off[q1 + 1] - off[q]) <= cap)) ++q1;
+      while (q1 < np && !dev_factor && !is_nd[q1] && (q1 == q || (size_t)(off[q1 + 1] - off[q]) <= cap)) ++q1;
       size_t len = (size_t)(off[q1] - off[q]);
       if (len > sf_cap) {
         sf_cap = len;
@@ -389,6 +407,8 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     s->nclass = 0;
     for (int q = 0; q < np; ++q) {
       int R = (bw[q] + 127) / 64, c;
+      cls[q] = -1;
+      if (is_nd[q]) continue;
       if (bw[q] > wide_from) { /* wide classes: -(register sets per lane) */
         int W = bj_wide_window(bw[q]);
         R = W <= 1024 ? -1 : (W <= 2048 ? -2 : -4);
@@ -434,6 +454,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     int ns = 0, nbig = 0, wsmall = 0, wbig = 0;
     for (int q = 0; q < np; ++q) {
       boff[q] = (long long)btot;
+      if (is_nd[q]) continue;
       btot += (size_t)nrows[q] * (bw[q] + 1);
       if (bw[q] <= dev_wmax) { slist[ns++] = q; if (bw[q] > wsmall) wsmall = bw[q]; }
       else { blist[nbig++] = q; if (bw[q] > wbig) wbig = bw[q]; }
@@ -507,11 +528,22 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     pa_rt_free(d_band); pa_rt_free(d_boff); pa_rt_free(d_slist); pa_rt_free(d_blist); pa_rt_free(d_fail);
     free(boff); free(slist); free(blist);
   }
+  if (!rc && nnd > 0) {
+    int* ndl = (int*)malloc((size_t)nnd * sizeof(int));
+    int* grow0 = (int*)malloc((size_t)np * sizeof(int));
+    int x = 0, nd_fail = -1;
+    for (int q = 0; q < np; ++q) { grow0[q] = rowPos[op->part0 + q]; if (is_nd[q]) ndl[x++] = q; }
+    int r2 = pa_nd_create(A, nnd, ndl, row0, nrows, grow0, m, &nd_fail);
+    if (r2 == 2) rc = PA_FAIL("diagonal block is not SPD (global row %d)", row_off + nd_fail);
+    else if (r2) rc = 1;
+    free(ndl); free(grow0);
+  }
   for (int q = 0; q < np; ++q) { free(bands[q]); free(coo_off[q]); free(coo_val[q]); }   /* (NULL where already released) */
   free(bands); free(coo_off); free(coo_val); free(coo_n);
-  free(row0); free(nrows); free(bw); free(off); free(map_f); free(map_b); free(invd_f); free(invd_b);
+  free(row0); free(nrows); free(bw); free(off); free(map_f); free(map_b); free(invd_f); free(invd_b); free(is_nd);
   if (rc) { preAlps_BlockJacobiFree(); return rc; }
-  s->factor_bytes = 2.0 * 8.0 * (double)tot;
+  s->factor_bytes = 2.0 * 8.0 * (double)tot + pa_nd_factor_bytes();
+  s->nd_blocks = nnd;
   pa_bj_plan_t* pl = &s->plan;
   pl->nparts = np; pl->row0 = s->d_row0; pl->nrows = s->d_nrows; pl->bw = s->d_bw; pl->off = s->d_off;
   pl->map_f = s->d_map_f; pl->map_b = s->d_map_b; pl->Lf = s->d_Lf; pl->Lb = s->d_Lb;
@@ -537,6 +569,7 @@ int preAlps_BlockJacobiApply(CPLM_Mat_Dense_t* A_in, CPLM_Mat_Dense_t* B_out) {
   B_out->info.nval = B_out->info.m * B_out->info.n;
   pa_time_begin(PA_T_PRECOND);
   if (pa_k_bj_apply(&s->plan, ts, A_in->val, B_out->val)) return PA_FAIL("block-Jacobi kernel launch failed");
+  if (s->nd_blocks > 0 && pa_nd_apply(ts, A_in->val, B_out->val)) return 1;
   pa_time_end(PA_T_PRECOND);
   return 0;
 }

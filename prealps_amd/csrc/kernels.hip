@@ -1907,6 +1907,206 @@ __global__ __launch_bounds__(NT) void k_bj_wide(
   bjw_sweep<TS, R, D>(b, W, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out, out, ybuf, dl, wave, lane, active);
 }
 
+// ------------------------------------------------ sparse block solve (large blocks) ----
+// Supernodal triangular solves for the nested-dissection factor of nd.c.  One workgroup per
+// supernode, the supernodes of one tree level per launch.  A front has n pivot columns and
+// f = n + m rows; thread `tid` keeps rows tid, tid + NT, ... of the front in registers (TS
+// right-hand sides each).  Both sweeps have one shape: a block of <= 64 finished rows is
+// published in LDS, then every thread applies it to its own rows with coalesced loads of the
+// panel (column major forward, row major backward) and LDS broadcasts of the published values.
+// The 64 pivot rows of a block settle among themselves inside the wavefront that owns them
+// (v_readlane).  Forward columns are stored divided by their pivot and the running values stay
+// unscaled (as in the band kernels above), so no division sits on the critical path.
+template <int TS, int NT, int RPT>
+__device__ __forceinline__ void nd_apply_block(double (&acc)[RPT][TS], const double* __restrict__ base, int ldm,
+                                               int nb, int lo, int hi, const double (*yb)[TS], int tid) {
+  bool on[RPT];
+  const double* p[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int r = tid + k * NT;
+    on[k] = r >= lo && r < hi;
+    p[k] = base + (on[k] ? r : lo);
+  }
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) any |= on[k];
+  if (!any) return;
+#pragma unroll 4
+  for (int j = 0; j < nb; ++j) {
+    double y[TS];
+#pragma unroll
+    for (int c = 0; c < TS / 2; ++c) { const double2 v = reinterpret_cast<const double2*>(yb[j])[c]; y[2 * c] = v.x; y[2 * c + 1] = v.y; }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const double cf = on[k] ? p[k][(size_t)j * ldm] : 0.0;
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[k][c] = fma(-cf, y[c], acc[k][c]);
+    }
+  }
+}
+
+// The 64-row group that holds the pivots of a block, inside its wavefront.  FWD: pivot j acts on
+// the lanes behind it (rows of the group that exist: lane < nvalid); backward: pivot i, taken
+// in descending order, acts on the lanes in front of it.  base = element (first row of the
+// group, first pivot) of the panel; consecutive lanes read consecutive addresses.
+template <int TS, int RPT, int K, bool FWD>
+__device__ __forceinline__ void nd_diag(double (&acc)[RPT][TS], const double* __restrict__ base, int ldm, int nb,
+                                        int nvalid, int lane) {
+  for (int q = 0; q < nb; ++q) {
+    const int j = FWD ? q : nb - 1 - q;
+    double cf = base[(size_t)j * ldm + lane];
+    const bool act = FWD ? (lane > j && lane < nvalid) : (lane < j);
+    cf = act ? cf : 0.0;
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      const double y = readlane_f64(acc[K][c], j);
+      acc[K][c] = fma(-cf, y, acc[K][c]);
+    }
+  }
+}
+
+template <int TS, int RPT, int K, bool FWD>
+__device__ __forceinline__ void nd_diag_pick(double (&acc)[RPT][TS], int ok, const double* __restrict__ base, int ldm,
+                                             int nb, int nvalid, int lane, double (*yb)[TS]) {
+  if constexpr (K < RPT) {
+    if (ok == K) {
+      nd_diag<TS, RPT, K, FWD>(acc, base, ldm, nb, nvalid, lane);
+      double2* q = reinterpret_cast<double2*>(yb[lane]);
+#pragma unroll
+      for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(acc[K][2 * c], acc[K][2 * c + 1]);
+    } else {
+      nd_diag_pick<TS, RPT, K + 1, FWD>(acc, ok, base, ldm, nb, nvalid, lane, yb);
+    }
+  }
+}
+
+struct nd_args {
+  const int* n; const int* m; const int* ld; const long long* offF; const long long* offB; const int* rows_off;
+  const int* coff; const int* ccoff; const int* rows; const int* src; const double* dinv; const double* F;
+  const double* B; double* contrib;
+};
+
+// Forward: w = [x(columns) ; 0] + the children's contributions; L y = w on the n columns; the m rows
+// below leave as this supernode's contribution to its parent.  XS = panel stride, TS = columns
+// handled by this workgroup (blockIdx.y picks the column group).
+template <int TS, int XS, int NT, int RPT>
+__global__ __launch_bounds__(NT) void k_nd_forward(nd_args a, const int* __restrict__ list,
+                                                   const double* __restrict__ in, double* __restrict__ out) {
+  __shared__ double ybuf[2][64][TS];
+  const int s = list[blockIdx.x], coff = blockIdx.y * TS;
+  const int n = a.n[s], f = n + a.m[s], ld = a.ld[s];
+  const double* __restrict__ L = a.F + a.offF[s];
+  const int* __restrict__ rows = a.rows + a.rows_off[s];
+  const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
+  const int cc0 = a.ccoff[2 * s], cc1 = a.ccoff[2 * s + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double acc[RPT][TS];
+  int grow[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int r = tid + k * NT;
+    grow[k] = -1;
+#pragma unroll
+    for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
+    if (r < f) {
+      grow[k] = rows[r];
+      if (r < n) load_row_s<TS, XS>(in + coff, (size_t)grow[k], acc[k]);
+      const int s0 = src[2 * r], s1 = src[2 * r + 1];
+      double t[TS];
+      if (s0 >= 0) {
+        load_row_s<TS, XS>(a.contrib + coff, (size_t)(cc0 + s0), t);
+#pragma unroll
+        for (int c = 0; c < TS; ++c) acc[k][c] += t[c];
+      }
+      if (s1 >= 0) {
+        load_row_s<TS, XS>(a.contrib + coff, (size_t)(cc1 + s1), t);
+#pragma unroll
+        for (int c = 0; c < TS; ++c) acc[k][c] += t[c];
+      }
+    }
+  }
+  int par = 0;
+  for (int jb = 0; jb < n; jb += 64, par ^= 1) {
+    const int nb = min(64, n - jb);
+    if (wave == ((jb % NT) >> 6))
+      nd_diag_pick<TS, RPT, 0, true>(acc, jb / NT, L + (size_t)jb * ld + jb, ld, nb, min(64, f - jb), lane, ybuf[par]);
+    __syncthreads();
+    nd_apply_block<TS, NT, RPT>(acc, L + (size_t)jb * ld, ld, nb, jb + 64, f, ybuf[par], tid);
+  }
+  const int c0 = a.coff[s];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int r = tid + k * NT;
+    if (r < n) {
+      const double id = a.dinv[grow[k]];
+      double y[TS];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) y[c] = acc[k][c] * id;
+      store_row_s<TS, XS>(out + coff, (size_t)grow[k], y);
+    } else if (r < f) {
+      store_row_s<TS, XS>(a.contrib + coff, (size_t)(c0 + r - n), acc[k]);
+    }
+  }
+}
+
+// Backward: L^T z = y on the n columns, the m rows below are ancestors whose z is final.
+// b_k = L_kk z_k is carried unscaled; the row-major copy holds L(i,k) for the rows below and
+// L(i,k) / L(i,i) for the pivot rows.
+template <int TS, int XS, int NT, int RPT>
+__global__ __launch_bounds__(NT) void k_nd_backward(nd_args a, const int* __restrict__ list, double* __restrict__ out) {
+  __shared__ double ybuf[2][64][TS];
+  const int s = list[blockIdx.x], coff = blockIdx.y * TS;
+  const int n = a.n[s], f = n + a.m[s], ldb = (n + 1) & ~1;
+  const double* __restrict__ U = a.B + a.offB[s];
+  const int* __restrict__ rows = a.rows + a.rows_off[s];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double acc[RPT][TS];
+  int grow[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int r = tid + k * NT;
+    grow[k] = -1;
+#pragma unroll
+    for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
+    if (r < n) { grow[k] = rows[r]; load_row_s<TS, XS>(out + coff, (size_t)grow[k], acc[k]); }
+  }
+  int par = 0;
+  // the rows below, 64 at a time: z from the solution panel into LDS, then everyone applies them
+  for (int i0 = n; i0 < f; i0 += 64, par ^= 1) {
+    const int nb = min(64, f - i0);
+    if (tid < 64) {
+      double z[TS];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) z[c] = 0.0;
+      if (tid < nb) load_row_s<TS, XS>(out + coff, (size_t)rows[i0 + tid], z);
+      double2* q = reinterpret_cast<double2*>(ybuf[par][tid]);
+#pragma unroll
+      for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(z[2 * c], z[2 * c + 1]);
+    }
+    __syncthreads();
+    nd_apply_block<TS, NT, RPT>(acc, U + (size_t)i0 * ldb, ldb, nb, 0, n, ybuf[par], tid);
+  }
+  // the pivot blocks, last first
+  for (int jb = ((n - 1) >> 6) << 6; jb >= 0; jb -= 64, par ^= 1) {
+    const int nb = min(64, n - jb);
+    if (wave == ((jb % NT) >> 6))
+      nd_diag_pick<TS, RPT, 0, false>(acc, jb / NT, U + (size_t)jb * ldb + jb, ldb, nb, nb, lane, ybuf[par]);
+    __syncthreads();
+    nd_apply_block<TS, NT, RPT>(acc, U + (size_t)jb * ldb, ldb, nb, 0, jb, ybuf[par], tid);
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    if (grow[k] >= 0) {
+      const double id = a.dinv[grow[k]];
+      double z[TS];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) z[c] = acc[k][c] * id;
+      store_row_s<TS, XS>(out + coff, (size_t)grow[k], z);
+    }
+  }
+}
+
 inline int grid_rows(int m, int per_thread_rows = 1) {
   long long blocks = ((long long)m + (long long)WG * per_thread_rows - 1) / ((long long)WG * per_thread_rows);
   if (blocks < 1) blocks = 1;
@@ -2120,6 +2320,40 @@ static int bj_factor_big_launch(const int* list, int count, int wmax, const int*
   hipLaunchKernelGGL((k_bj_factor_big<NB>), dim3(count), dim3(1024), lds, cur_stream(), list, row0, nrows, bw,
                      boff, band, fail);
   return kfail("k_bj_factor_big");
+}
+
+// size classes of the fronts: NT threads keep up to RPT rows each
+constexpr int ND_NCLASS = 6;
+constexpr int ND_NT[ND_NCLASS] = {256, 256, 512, 1024, 1024, 1024};
+constexpr int ND_RPT[ND_NCLASS] = {1, 2, 2, 2, 4, 8};
+
+template <int TS, int XS, int NT, int RPT>
+static int nd_launch_one(const nd_args& a, const int* list, int count, bool fwd, const double* in, double* out) {
+  const dim3 grid(count, XS / TS);
+  if (fwd) hipLaunchKernelGGL((k_nd_forward<TS, XS, NT, RPT>), grid, dim3(NT), 0, cur_stream(), a, list, in, out);
+  else hipLaunchKernelGGL((k_nd_backward<TS, XS, NT, RPT>), grid, dim3(NT), 0, cur_stream(), a, list, out);
+  return kfail(fwd ? "k_nd_forward" : "k_nd_backward");
+}
+
+// a thread keeps RPT * TS doubles: at most 32 (64 VGPRs); wider panels go in column groups
+template <int XS, int NT, int RPT>
+static int nd_launch_cls(const nd_args& a, const int* list, int count, bool fwd, const double* in, double* out) {
+  constexpr int TSMAX = 32 / RPT;
+  constexpr int TS = XS <= TSMAX ? XS : (TSMAX < 2 ? 2 : TSMAX);
+  return nd_launch_one<TS, XS, NT, RPT>(a, list, count, fwd, in, out);
+}
+
+template <int XS>
+static int nd_launch(const nd_args& a, int cls, const int* list, int count, bool fwd, const double* in, double* out) {
+  switch (cls) {
+    case 0: return nd_launch_cls<XS, 256, 1>(a, list, count, fwd, in, out);
+    case 1: return nd_launch_cls<XS, 256, 2>(a, list, count, fwd, in, out);
+    case 2: return nd_launch_cls<XS, 512, 2>(a, list, count, fwd, in, out);
+    case 3: return nd_launch_cls<XS, 1024, 2>(a, list, count, fwd, in, out);
+    case 4: return nd_launch_cls<XS, 1024, 4>(a, list, count, fwd, in, out);
+    case 5: return nd_launch_cls<XS, 1024, 8>(a, list, count, fwd, in, out);
+  }
+  return 1;
 }
 
 extern "C" {
@@ -2364,6 +2598,26 @@ int pa_k_bj_factor_big(const int* list, int count, int wmax, int wide_from, cons
   hipLaunchKernelGGL(k_bj_layout_big, dim3(512, count), dim3(WG), 0, cur_stream(), list, row0, nrows, bw, off,
                      boff, band, wide_from, Lf, Lb, invd_f, invd_b);
   return kfail("k_bj_layout_big");
+}
+
+int pa_nd_num_classes(void) { return ND_NCLASS; }
+int pa_nd_class_of(int front_rows) {
+  for (int c = 0; c < ND_NCLASS; ++c) if (front_rows <= ND_NT[c] * ND_RPT[c]) return c;
+  return -1;
+}
+
+// launches are listed bottom-up (height, then class): forward in that order, backward reversed
+int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out) {
+  nd_args a{pl->n, pl->m, pl->ld, pl->offF, pl->offB, pl->rows_off, pl->coff, pl->ccoff, pl->rows, pl->src,
+            pl->dinv, pl->F, pl->B, pl->contrib};
+  for (int pass = 0; pass < 2; ++pass)
+    for (int q = 0; q < pl->nlaunch; ++q) {
+      const int i = pass == 0 ? q : pl->nlaunch - 1 - q;
+      int rc = 1;
+      TS_DISPATCH(ts, rc = nd_launch<TS_>(a, pl->l_class[i], pl->l_list[i], pl->l_count[i], pass == 0, in, out));
+      if (rc) return rc;
+    }
+  return 0;
 }
 
 int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out) {

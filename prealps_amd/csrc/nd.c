@@ -165,7 +165,11 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
     for (int c = 0; c < 2; ++c) {
       int ch = B->child[2 * s + c];
       if (ch < 0) continue;
-      for (int k = 0; k < B->m[ch]; ++k) { int r = B->below[ch][k]; if (r >= last && mark[r] != s) { mark[r] = s; tmp[l++] = r; } }
+      for (int k = 0; k < B->m[ch]; ++k) {
+        int r = B->below[ch][k];
+        if (r < B->tree.first[s]) { free(ip); free(sn_of); free(mark); free(tmp); return 2; }   /* not a separator tree */
+        if (r >= last && mark[r] != s) { mark[r] = s; tmp[l++] = r; }
+      }
     }
     qsort(tmp, l, sizeof(int), cmp_int);
     B->m[s] = l;
@@ -229,7 +233,7 @@ static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv,
   *fail = 0;
   for (int s = 0; s < nsn && !rc; ++s) {
     const int c0 = B->tree.first[s], n = B->tree.first[s + 1] - c0, m = B->m[s], f = n + m;
-    double* F = (double*)calloc((size_t)f * f, sizeof(double));
+    double* F = (double*)calloc((size_t)f * f + 1, sizeof(double));
     if (!F) { rc = 1; break; }
     for (int j = 0; j < n; ++j) loc[c0 + j] = j;
     for (int k = 0; k < m; ++k) loc[B->below[s][k]] = n + k;
@@ -267,7 +271,7 @@ static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv,
     }
     oF += (long long)ld * n; oB += (long long)ldb * f;
     if (m > 0 && B->tree.parent[s] >= 0) {
-      double* U = (double*)malloc((size_t)m * m * sizeof(double));
+      double* U = (double*)calloc((size_t)m * m, sizeof(double));
       if (!U) { free(F); rc = 1; break; }
       for (int a = 0; a < m; ++a) memcpy(U + (size_t)a * m + a, F + (size_t)(n + a) * f + n + a, (size_t)(m - a) * sizeof(double));
       upd[s] = U;
@@ -464,4 +468,93 @@ int pa_nd_apply(int ts, const double* in, double* out) {
   S->plan.contrib = S->d_contrib;
   if (pa_k_nd_apply(&S->plan, ts, in, out)) return PA_FAIL("block-solve kernel launch failed");
   return 0;
+}
+
+/* ---- host-side self check (no GPU): ordering, symbolic and numeric phases on one matrix -------------- */
+/* Factors the n x n SPD matrix (CSR, full symmetric pattern, sorted or not) as ONE block exactly
+ * like pa_nd_create does and reports: stats[0] supernodes, [1] doubles of one panel copy,
+ * [2] rows of the largest front, [3] height of the tree, [4] ||L L^T x - A x|| / ||A x|| for a
+ * fixed pseudo-random x with L rebuilt from the forward panels, [5] the largest relative
+ * difference between the backward panels and the same entries of the forward panels.
+ * It multiplies with the factor, it does not solve: there is no CPU solve path in this library. */
+int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const double* val, int leaf_rows,
+                             double* stats) {
+  if (n < 1 || !rowPtr || !colInd || !val || !stats) return PA_FAIL("invalid arguments");
+  CPLM_Mat_CSR_t A;
+  memset(&A, 0, sizeof(A));
+  A.rowPtr = (int*)rowPtr; A.colInd = (int*)colInd; A.val = (double*)val;
+  nd_block_t B;
+  int rc = nd_symbolic(&B, &A, 0, 0, n, leaf_rows > 0 ? leaf_rows : 96);
+  if (rc) { nd_block_free(&B); return PA_FAIL("nested dissection failed (%s)", rc == 2 ? "a separator does not separate" : "out of memory"); }
+  double* hF = (double*)malloc((size_t)(B.nF ? B.nF : 1) * sizeof(double));
+  double* hB = (double*)malloc((size_t)(B.nB ? B.nB : 1) * sizeof(double));
+  double* di = (double*)malloc((size_t)n * sizeof(double));
+  double* x = (double*)malloc((size_t)n * sizeof(double));
+  double* u = (double*)calloc((size_t)n, sizeof(double));
+  double* w = (double*)calloc((size_t)n, sizeof(double));
+  double* ax = (double*)calloc((size_t)n, sizeof(double));
+  int fail = 0;
+  if (!hF || !hB || !di || !x || !u || !w || !ax) rc = PA_FAIL("out of host memory");
+  if (!rc) {
+    rc = nd_numeric(&B, hF, hB, di, &fail);
+    if (rc == 2) rc = PA_FAIL("matrix is not SPD (row %d)", B.tree.perm[fail - 1]);
+    else if (rc) rc = PA_FAIL("out of host memory");
+  }
+  if (!rc) {
+    unsigned long long st = 88172645463325252ULL;
+    for (int i = 0; i < n; ++i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; x[i] = (double)(st >> 11) / 9007199254740992.0 - 0.5; }
+    int maxf = 0, maxh = 0;
+    long long oF = 0, oB = 0;
+    double dmax = 0.0;
+    for (int s = 0; s < B.tree.nsn; ++s) {       /* u = L^T x */
+      int c0 = B.tree.first[s], ns = B.tree.first[s + 1] - c0, m = B.m[s], f = ns + m, ld = (f + 1) & ~1, ldb = (ns + 1) & ~1;
+      if (f > maxf) maxf = f;
+      if (B.height[s] > maxh) maxh = B.height[s];
+      for (int j = 0; j < ns; ++j) {
+        double ljj = 1.0 / di[c0 + j], acc = ljj * x[c0 + j];
+        for (int i = j + 1; i < f; ++i) {
+          int gi = i < ns ? c0 + i : B.below[s][i - ns];
+          double lij = hF[oF + (size_t)j * ld + i] * ljj;
+          acc += lij * x[gi];
+          /* the same entry in the backward copy */
+          double want = i < ns ? lij * di[c0 + i] : lij, got = hB[oB + (size_t)i * ldb + j];
+          double d = fabs(got - want) / (fabs(want) + 1e-300);
+          if (want != 0.0 && d > dmax) dmax = d;
+        }
+        u[c0 + j] = acc;
+      }
+      oF += (long long)ld * ns; oB += (long long)ldb * f;
+    }
+    oF = 0;
+    for (int s = 0; s < B.tree.nsn; ++s) {       /* w = L u */
+      int c0 = B.tree.first[s], ns = B.tree.first[s + 1] - c0, m = B.m[s], f = ns + m, ld = (f + 1) & ~1;
+      for (int j = 0; j < ns; ++j) {
+        double ljj = 1.0 / di[c0 + j];
+        w[c0 + j] += ljj * u[c0 + j];
+        for (int i = j + 1; i < f; ++i) {
+          int gi = i < ns ? c0 + i : B.below[s][i - ns];
+          w[gi] += hF[oF + (size_t)j * ld + i] * ljj * u[c0 + j];
+        }
+      }
+      oF += (long long)ld * ns;
+    }
+    for (int j = 0; j < n; ++j)                  /* A x from the permuted lower triangle */
+      for (int k = B.cp[j]; k < B.cp[j + 1]; ++k) {
+        int i = B.ri[k];
+        ax[i] += B.cv[k] * x[j];
+        if (i != j) ax[j] += B.cv[k] * x[i];
+      }
+    double num = 0.0, den = 0.0;
+    for (int i = 0; i < n; ++i) { num += (w[i] - ax[i]) * (w[i] - ax[i]); den += ax[i] * ax[i]; }
+    if (getenv("PREALPS_ND_TRACE"))
+      for (int s2 = B.tree.nsn - 1; s2 >= 0 && s2 >= B.tree.nsn - 40; --s2)
+        if (B.height[s2] >= maxh - 2)
+          fprintf(stderr, "[nd] supernode %d height %d: %d columns, %d rows below\n", s2, B.height[s2],
+                  B.tree.first[s2 + 1] - B.tree.first[s2], B.m[s2]);
+    stats[0] = B.tree.nsn; stats[1] = (double)B.nF; stats[2] = maxf; stats[3] = maxh;
+    stats[4] = sqrt(num / (den > 0.0 ? den : 1.0)); stats[5] = dmax;
+  }
+  free(hF); free(hB); free(di); free(x); free(u); free(w); free(ax);
+  nd_block_free(&B);
+  return rc;
 }

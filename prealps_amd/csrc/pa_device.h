@@ -197,6 +197,28 @@ int pa_k_bj_factor(const int* list, int count, int wmax, const int* row0, const 
                    double* invd_f, double* invd_b, int* fail);
 int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out);
 
+/* ---- sparse block solve for large diagonal blocks (nd.c) --------------------------------- */
+/* Supernodes of a nested-dissection Cholesky factor, all blocks of the process in one numbering.
+ * Supernode s: n[s] pivot columns, m[s] rows below; forward panel F + offF[s], column major,
+ * leading dimension ld[s] >= n + m, column j divided by its pivot; backward panel B + offB[s],
+ * row major with row length (n + 1) & ~1: L(i, k) for the rows below, L(i, k) / L(i, i) for the
+ * pivot rows.  rows[rows_off[s] + r] = local panel row of front row r; src[2 (rows_off[s] + r) + c]
+ * = where front row r finds the contribution of child c (row of its vector, -1: none), that
+ * vector starting at row ccoff[2 s + c] of `contrib`; this supernode's own contribution starts
+ * at row coff[s].  dinv[local row] = 1 / L(row, row). */
+typedef struct {
+  const int* n; const int* m; const int* ld; const long long* offF; const long long* offB; const int* rows_off;
+  const int* coff; const int* ccoff; const int* rows; const int* src; const double* dinv;
+  const double* F; const double* B; double* contrib;
+  int nlaunch;                 /* launches in bottom-up order: (tree height, size class) */
+  const int* l_class;          /* host arrays */
+  const int* l_count;
+  const int* const* l_list;    /* host array of device pointers to supernode ids */
+} pa_nd_plan_t;
+int pa_nd_num_classes(void);
+int pa_nd_class_of(int front_rows);   /* -1: front too large for the kernels */
+int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out);
+
 #ifdef __cplusplus
 }
 #endif

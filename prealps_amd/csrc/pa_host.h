@@ -67,9 +67,19 @@ typedef struct {
 int pa_nd_order(int n, const int* rp, const int* ci, int leaf_rows, pa_nd_tree_t* t);
 void pa_nd_tree_free(pa_nd_tree_t* t);
 
+/* sparse block solve for large blocks (nd.c); returns 0, 1 (error reported) or 2 (*fail_row = local
+ * panel row of a non-positive pivot) */
+int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int* row0, const int* nrows,
+                 const int* grow0, int m_local, int* fail_row);
+int pa_nd_apply(int ts, const double* in, double* out);
+void pa_nd_free(void);
+double pa_nd_factor_bytes(void);
+int pa_nd_active(void);
+
 double pa_bj_factor_bytes(void);
 int pa_bj_max_bandwidth(void);
 double pa_bj_setup_seconds(int which);   /* 0: ordering + band Cholesky, 1: sweep layouts + upload */
 int pa_bj_nparts(void);
+int pa_bj_nd_blocks(void);
 
 #endif

@@ -277,6 +277,71 @@ def test_block_solve_dispatch_by_band(n, t, lo, hi, wide_from, monkeypatch):
         prob.close()
 
 
+# ---- large blocks: sparse (nested dissection) factor against the band factor and the oracle -----------
+@pytest.mark.parametrize("t", [1, 4, 8, 16])
+@pytest.mark.parametrize("kind", ["poisson", "elasticity"])
+def test_large_blocks_sparse_factor(kind, t, monkeypatch):
+    """Few large subdomains (nparts = 64 on 1M rows, the reference's one block per
+    rank): blocks of >= 2048 rows with a wide band get the supernodal factor of nd.c, solved level
+    by level (k_nd_forward / k_nd_backward).  Same answer as the oracle's exact block solve and as
+    the band kernels (PREALPS_BJ_ND=0) on the same blocks."""
+    from oracle import oracle as O
+    if kind == "poisson":
+        A, P, part = O.poisson3d(24), 3, None          # slabs of 8 x 24 x 24 = 4608 rows
+    else:
+        A, part, P = _elasticity(14, (14, 14, 7))      # 2 blocks of 14 x 14 x 7 nodes = 4116 rows
+    X = np.random.default_rng(t).standard_normal((A.shape[0], t))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PREALPS_BJ_ND", mode)
+        prob, B, rowpos = _problem(A, P, part)
+        try:
+            out[mode] = prob.block_jacobi_apply(X, t)
+            assert prob.stat("bj_nd_blocks") == (P if mode == "1" else 0)
+            if mode == "1":
+                nd_bytes = prob.stat("bj_factor_bytes")
+            else:
+                assert nd_bytes < prob.stat("bj_factor_bytes")          # the sparse factor is the smaller one
+        finally:
+            prob.close()
+    zr = O.BlockJacobi(B, rowpos).apply(X)
+    tol = 1e-9 if kind == "poisson" else 1e-7       # (coefficient jumps of 1e10 in the elasticity blocks)
+    for mode in out:
+        np.testing.assert_allclose(out[mode], zr, rtol=tol, atol=tol * np.abs(zr).max())
+
+
+def test_large_blocks_ecg_and_mixed_sizes(monkeypatch):
+    """ECG on a partition that mixes one large block (sparse factor) with many small ones (band
+    kernels), every leaf size of the dissection, and a non-SPD large block reported as such."""
+    import prealps_amd as pa
+    from oracle import oracle as O
+    n = 20
+    A = O.poisson3d(n)
+    idx = np.arange(n ** 3)
+    i = idx // (n * n)
+    part = np.where(i < 10, 0, 1 + (idx - 10 * n * n) // 200).astype(np.int32)      # 4000 rows, then blocks of 200
+    P = int(part.max()) + 1
+    monkeypatch.setenv("PREALPS_ND_LEAF", "40")
+    prob, B, rowpos = _problem(A, P, part)
+    try:
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, 4)
+        assert prob.stat("bj_nd_blocks") == 1
+        ref = O.ECG(B, rowpos, 4).solve(rhs)
+        assert got.iters == ref["iters"]
+        np.testing.assert_allclose(got.res, ref["res"], rtol=RTOL_HIST)
+    finally:
+        prob.close()
+    Ab = sp.lil_matrix(A)
+    Ab[777, 777] = -5.0
+    prob, B, rowpos = _problem(sp.csr_matrix(Ab), P, part)
+    try:
+        with pytest.raises(pa.PreAlpsError, match="not SPD"):
+            prob.create_block_jacobi()
+    finally:
+        prob.close()
+
+
 # ---- BF-Omin really shrinks ------------------------------------------------------------------------------------
 def test_bf_omin_shrinks_when_a_direction_dies():
     """Breakdown-free Orthomin (ecg.c:361-393): subdomains 3, 7, 11, ... (p mod 4 == 3) are cut off
