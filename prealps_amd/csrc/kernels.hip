@@ -1932,16 +1932,28 @@ __device__ __forceinline__ void nd_apply_block(double (&acc)[RPT][TS], const dou
 #pragma unroll
   for (int k = 0; k < RPT; ++k) any |= on[k];
   if (!any) return;
-#pragma unroll 4
-  for (int j = 0; j < nb; ++j) {
-    double y[TS];
+  // UN * RPT panel loads in flight per thread before the first one is used: a workgroup runs alone
+  // on its CU at the upper levels of the tree, so the memory latency has to be covered from inside
+  constexpr int UN = NT >= 1024 ? (RPT >= 8 ? 1 : 8 / RPT) : (RPT >= 16 ? 1 : 16 / RPT);   // (128 VGPRs per thread at 1024 threads)
+#pragma unroll 1
+  for (int j0 = 0; j0 < nb; j0 += UN) {
+    double cf[UN][RPT];
 #pragma unroll
-    for (int c = 0; c < TS / 2; ++c) { const double2 v = reinterpret_cast<const double2*>(yb[j])[c]; y[2 * c] = v.x; y[2 * c + 1] = v.y; }
+    for (int u = 0; u < UN; ++u)
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      const double cf = on[k] ? p[k][(size_t)j * ldm] : 0.0;
+      for (int k = 0; k < RPT; ++k) cf[u][k] = (on[k] && j0 + u < nb) ? p[k][(size_t)(j0 + u) * ldm] : 0.0;
+    constexpr int YB = TS >= 8 ? 1 : 8 / TS;   // published rows read from LDS at a time (the compiler would otherwise fetch all UN up front: registers)
 #pragma unroll
-      for (int c = 0; c < TS; ++c) acc[k][c] = fma(-cf, y[c], acc[k][c]);
+    for (int u = 0; u < UN; ++u) {
+      if (u % YB == 0) asm volatile("" ::: "memory");
+      double y[TS];
+      const int j = min(j0 + u, 63);
+#pragma unroll
+      for (int c = 0; c < TS / 2; ++c) { const double2 v = reinterpret_cast<const double2*>(yb[j])[c]; y[2 * c] = v.x; y[2 * c + 1] = v.y; }
+#pragma unroll
+      for (int k = 0; k < RPT; ++k)
+#pragma unroll
+        for (int c = 0; c < TS; ++c) acc[k][c] = fma(-cf[u][k], y[c], acc[k][c]);
     }
   }
 }
@@ -1950,34 +1962,54 @@ __device__ __forceinline__ void nd_apply_block(double (&acc)[RPT][TS], const dou
 // the lanes behind it (rows of the group that exist: lane < nvalid); backward: pivot i, taken
 // in descending order, acts on the lanes in front of it.  base = element (first row of the
 // group, first pivot) of the panel; consecutive lanes read consecutive addresses.
+// The 64 x 64 block the pivots of a step settle in was copied to LDS by the whole workgroup
+// (dblk[j][i] = coefficient of pivot j for the row in lane i, zero where it does not apply), so
+// the serial chain below meets LDS latency, not HBM latency, at each of its 64 links.
 template <int TS, int RPT, int K, bool FWD>
-__device__ __forceinline__ void nd_diag(double (&acc)[RPT][TS], const double* __restrict__ base, int ldm, int nb,
-                                        int nvalid, int lane) {
-  for (int q = 0; q < nb; ++q) {
-    const int j = FWD ? q : nb - 1 - q;
-    double cf = base[(size_t)j * ldm + lane];
-    const bool act = FWD ? (lane > j && lane < nvalid) : (lane < j);
-    cf = act ? cf : 0.0;
+__device__ __forceinline__ void nd_diag(double (&acc)[RPT][TS], const double (*dblk)[65], int nb, int lane) {
+  // four coefficients read ahead of the chain (rows of dblk past nb are zero: harmless steps)
+  const int q1 = (nb + 3) & ~3;
+#pragma unroll 1
+  for (int q0 = 0; q0 < q1; q0 += 4) {
+    double cf[4];
 #pragma unroll
-    for (int c = 0; c < TS; ++c) {
-      const double y = readlane_f64(acc[K][c], j);
-      acc[K][c] = fma(-cf, y, acc[K][c]);
+    for (int u = 0; u < 4; ++u) cf[u] = dblk[FWD ? q0 + u : q1 - 1 - (q0 + u)][lane];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = FWD ? q0 + u : q1 - 1 - (q0 + u);
+#pragma unroll
+      for (int c = 0; c < TS; ++c) {
+        const double y = readlane_f64(acc[K][c], j);
+        acc[K][c] = fma(-cf[u], y, acc[K][c]);
+      }
     }
   }
 }
 
 template <int TS, int RPT, int K, bool FWD>
-__device__ __forceinline__ void nd_diag_pick(double (&acc)[RPT][TS], int ok, const double* __restrict__ base, int ldm,
-                                             int nb, int nvalid, int lane, double (*yb)[TS]) {
+__device__ __forceinline__ void nd_diag_pick(double (&acc)[RPT][TS], int ok, const double (*dblk)[65], int nb,
+                                             int lane, double (*yb)[TS]) {
   if constexpr (K < RPT) {
     if (ok == K) {
-      nd_diag<TS, RPT, K, FWD>(acc, base, ldm, nb, nvalid, lane);
+      nd_diag<TS, RPT, K, FWD>(acc, dblk, nb, lane);
       double2* q = reinterpret_cast<double2*>(yb[lane]);
 #pragma unroll
       for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(acc[K][2 * c], acc[K][2 * c + 1]);
     } else {
-      nd_diag_pick<TS, RPT, K + 1, FWD>(acc, ok, base, ldm, nb, nvalid, lane, yb);
+      nd_diag_pick<TS, RPT, K + 1, FWD>(acc, ok, dblk, nb, lane, yb);
     }
+  }
+}
+
+// dblk <- the pivot block of a step.  FWD: column jb + j of the column-major panel, rows jb + i
+// (i > j, row inside the front); backward: row jb + j of the row-major panel, columns jb + i (i < j).
+template <int NT, bool FWD>
+__device__ __forceinline__ void nd_load_diag(double (*dblk)[65], const double* __restrict__ base, int ldm, int nb,
+                                             int nvalid, int tid) {
+  for (int e = tid; e < 64 * 64; e += NT) {
+    const int j = e >> 6, i = e & 63;
+    const bool act = j < nb && (FWD ? (i > j && i < nvalid) : (i < j));
+    dblk[j][i] = act ? base[(size_t)j * ldm + i] : 0.0;
   }
 }
 
@@ -1994,6 +2026,7 @@ template <int TS, int XS, int NT, int RPT>
 __global__ __launch_bounds__(NT) void k_nd_forward(nd_args a, const int* __restrict__ list,
                                                    const double* __restrict__ in, double* __restrict__ out) {
   __shared__ double ybuf[2][64][TS];
+  __shared__ double dblk[64][65];
   const int s = list[blockIdx.x], coff = blockIdx.y * TS;
   const int n = a.n[s], f = n + a.m[s], ld = a.ld[s];
   const double* __restrict__ L = a.F + a.offF[s];
@@ -2029,8 +2062,9 @@ __global__ __launch_bounds__(NT) void k_nd_forward(nd_args a, const int* __restr
   int par = 0;
   for (int jb = 0; jb < n; jb += 64, par ^= 1) {
     const int nb = min(64, n - jb);
-    if (wave == ((jb % NT) >> 6))
-      nd_diag_pick<TS, RPT, 0, true>(acc, jb / NT, L + (size_t)jb * ld + jb, ld, nb, min(64, f - jb), lane, ybuf[par]);
+    nd_load_diag<NT, true>(dblk, L + (size_t)jb * ld + jb, ld, nb, min(64, f - jb), tid);
+    __syncthreads();
+    if (wave == ((jb % NT) >> 6)) nd_diag_pick<TS, RPT, 0, true>(acc, jb / NT, dblk, nb, lane, ybuf[par]);
     __syncthreads();
     nd_apply_block<TS, NT, RPT>(acc, L + (size_t)jb * ld, ld, nb, jb + 64, f, ybuf[par], tid);
   }
@@ -2056,6 +2090,8 @@ __global__ __launch_bounds__(NT) void k_nd_forward(nd_args a, const int* __restr
 template <int TS, int XS, int NT, int RPT>
 __global__ __launch_bounds__(NT) void k_nd_backward(nd_args a, const int* __restrict__ list, double* __restrict__ out) {
   __shared__ double ybuf[2][64][TS];
+  __shared__ double dblk[64][65];
+  __shared__ double zbuf[2048];
   const int s = list[blockIdx.x], coff = blockIdx.y * TS;
   const int n = a.n[s], f = n + a.m[s], ldb = (n + 1) & ~1;
   const double* __restrict__ U = a.B + a.offB[s];
@@ -2072,8 +2108,60 @@ __global__ __launch_bounds__(NT) void k_nd_backward(nd_args a, const int* __rest
     if (r < n) { grow[k] = rows[r]; load_row_s<TS, XS>(out + coff, (size_t)grow[k], acc[k]); }
   }
   int par = 0;
-  // the rows below, 64 at a time: z from the solution panel into LDS, then everyone applies them
-  for (int i0 = n; i0 < f; i0 += 64, par ^= 1) {
+  // The rows below (ancestors, final).  A supernode low in the tree has few columns and many rows
+  // below: with one thread per column most of the workgroup would idle while the panel streams by.
+  // When the columns fill at most half the workgroup, G groups of threads share the source rows
+  // (z staged in LDS ZR rows at a time) and their partial sums are added up through LDS.
+  const int npad = (n + 63) & ~63;
+  const int G = (n > 0 && 2 * npad <= NT) ? NT / npad : 1;
+  if (G > 1) {
+    constexpr int ZR = 2048 / TS;
+    const int g = tid / npad, k = tid - g * npad;
+    const bool on = g < G && k < n;
+    double part[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) part[c] = 0.0;
+    for (int i0 = n; i0 < f; i0 += ZR) {
+      const int nb = min(ZR, f - i0);
+      for (int r = tid; r < nb; r += NT) {
+        double z[TS];
+        load_row_s<TS, XS>(out + coff, (size_t)rows[i0 + r], z);
+        double2* q = reinterpret_cast<double2*>(zbuf + (size_t)r * TS);
+#pragma unroll
+        for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(z[2 * c], z[2 * c + 1]);
+      }
+      __syncthreads();
+      if (on) {
+        const double* __restrict__ p = U + (size_t)i0 * ldb + k;
+#pragma unroll 4
+        for (int r = g; r < nb; r += G) {
+          const double cf = p[(size_t)r * ldb];
+          const double2* zq = reinterpret_cast<const double2*>(zbuf + (size_t)r * TS);
+#pragma unroll
+          for (int c = 0; c < TS / 2; ++c) {
+            const double2 zv = zq[c];
+            part[2 * c] = fma(-cf, zv.x, part[2 * c]);
+            part[2 * c + 1] = fma(-cf, zv.y, part[2 * c + 1]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    double* red = &dblk[0][0];            /* NT <= 64 * 65 doubles */
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      red[tid] = part[c];
+      __syncthreads();
+      if (tid < n) {
+        double sm = 0.0;
+        for (int g2 = 0; g2 < G; ++g2) sm += red[g2 * npad + tid];
+        acc[0][c] += sm;
+      }
+      __syncthreads();
+    }
+  }
+  // (otherwise) 64 at a time: z from the solution panel into LDS, then everyone applies them
+  for (int i0 = n; G == 1 && i0 < f; i0 += 64, par ^= 1) {
     const int nb = min(64, f - i0);
     if (tid < 64) {
       double z[TS];
@@ -2090,8 +2178,9 @@ __global__ __launch_bounds__(NT) void k_nd_backward(nd_args a, const int* __rest
   // the pivot blocks, last first
   for (int jb = ((n - 1) >> 6) << 6; jb >= 0; jb -= 64, par ^= 1) {
     const int nb = min(64, n - jb);
-    if (wave == ((jb % NT) >> 6))
-      nd_diag_pick<TS, RPT, 0, false>(acc, jb / NT, U + (size_t)jb * ldb + jb, ldb, nb, nb, lane, ybuf[par]);
+    nd_load_diag<NT, false>(dblk, U + (size_t)jb * ldb + jb, ldb, nb, nb, tid);
+    __syncthreads();
+    if (wave == ((jb % NT) >> 6)) nd_diag_pick<TS, RPT, 0, false>(acc, jb / NT, dblk, nb, lane, ybuf[par]);
     __syncthreads();
     nd_apply_block<TS, NT, RPT>(acc, U + (size_t)jb * ldb, ldb, nb, 0, jb, ybuf[par], tid);
   }

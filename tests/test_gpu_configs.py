@@ -282,14 +282,14 @@ def test_block_solve_dispatch_by_band(n, t, lo, hi, wide_from, monkeypatch):
 @pytest.mark.parametrize("kind", ["poisson", "elasticity"])
 def test_large_blocks_sparse_factor(kind, t, monkeypatch):
     """Few large subdomains (nparts = 64 on 1M rows, the reference's one block per
-    rank): blocks of >= 2048 rows with a wide band get the supernodal factor of nd.c, solved level
+    rank): blocks of >= 4096 rows with a wide band get the supernodal factor of nd.c, solved level
     by level (k_nd_forward / k_nd_backward).  Same answer as the oracle's exact block solve and as
     the band kernels (PREALPS_BJ_ND=0) on the same blocks."""
     from oracle import oracle as O
     if kind == "poisson":
-        A, P, part = O.poisson3d(24), 3, None          # slabs of 8 x 24 x 24 = 4608 rows
+        A, P, part = O.poisson3d(24), 2, None          # slabs of 12 x 24 x 24 = 6912 rows, band 288
     else:
-        A, part, P = _elasticity(14, (14, 14, 7))      # 2 blocks of 14 x 14 x 7 nodes = 4116 rows
+        A, part, P = _elasticity(14, (14, 14, 7))      # 2 blocks of 14 x 14 x 7 nodes = 4116 rows, band ~300
     X = np.random.default_rng(t).standard_normal((A.shape[0], t))
     out = {}
     for mode in ("1", "0"):
@@ -319,9 +319,10 @@ def test_large_blocks_ecg_and_mixed_sizes(monkeypatch):
     A = O.poisson3d(n)
     idx = np.arange(n ** 3)
     i = idx // (n * n)
-    part = np.where(i < 10, 0, 1 + (idx - 10 * n * n) // 200).astype(np.int32)      # 4000 rows, then blocks of 200
+    part = np.where(i < 14, 0, 1 + (idx - 14 * n * n) // 200).astype(np.int32)      # 5600 rows (band 280), then blocks of 200
     P = int(part.max()) + 1
     monkeypatch.setenv("PREALPS_ND_LEAF", "40")
+    monkeypatch.setenv("PREALPS_BJ_ND", "2")
     prob, B, rowpos = _problem(A, P, part)
     try:
         rhs = prob.reference_rhs()
