@@ -1042,6 +1042,153 @@ __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, const 
   block_sum_cols<TS>(rr, rtr + (size_t)blockIdx.x * TS);
 }
 
+// The same pass for panels of 8 and 16 columns on the f64 matrix cores.  With Ui = U^-1 (formed
+// once per workgroup, t <= 16) and B = Ui alpha, all four results are products of the OLD tiles:
+//   P <- P Ui,  AP <- AP Ui,  X += P B,  R -= AP B,
+// so a tile of 16 rows of P / AP is loaded once in the A layout of v_mfma_f64_16x16x4 (lane l:
+// row l&15, k = 4s + (l>>4)) and multiplied by per-lane constants (B layout: k = 4s + (l>>4),
+// column l&15); X and R pass through the accumulator (C/D layout: four coalesced 512-byte rows).
+// Columns beyond t ride along unchanged (Ui is padded with the identity, B with zeros).
+// TS = 16: one tile per panel.  TS = 8: [P | AP] is one 16-wide A operand, blockdiag(Ui, Ui) and
+// [B 0; 0 -B] the B operands, [X | R] the accumulator.
+template <int TS>
+__global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, const double* __restrict__ U,
+                                                         const double* __restrict__ alpha,
+                                                         double* __restrict__ P, double* __restrict__ AP,
+                                                         double* __restrict__ X, double* __restrict__ R,
+                                                         double* __restrict__ rtr) {
+  static_assert(TS == 8 || TS == 16, "matrix-core variant: panels of 8 or 16 columns");
+  __shared__ double su[16 * 16];    // U (column major, leading dimension 16, identity beyond t)
+  __shared__ double si[16 * 16];    // Ui = U^-1
+  __shared__ double sb[16 * 16];    // B = Ui alpha (16 x 16, zero beyond t x nc)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+  for (int e = tid; e < 256; e += WG) {
+    const int i = e & 15, j = e >> 4;
+    su[e] = (i < t && j < t) ? U[i + t * j] : (i == j ? 1.0 : 0.0);
+    sb[e] = 0.0;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    // column tid of Ui by back substitution: U x = e_tid (upper triangular)
+    double x[16];
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+      double sv = (i == tid) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = i + 1; k < 16; ++k) sv -= su[i + 16 * k] * x[k];
+      x[i] = sv / su[i + 16 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) si[i + 16 * tid] = x[i];
+  }
+  __syncthreads();
+  for (int e = tid; e < 256; e += WG) {
+    const int i = e & 15, c = e >> 4;
+    double sv = 0.0;
+    if (i < t && c < nc) for (int k = i; k < t; ++k) sv += si[i + 16 * k] * alpha[k + t * c];
+    sb[e] = sv;
+  }
+  __syncthreads();
+  // per-lane B operands: k = 4 s + hi
+  double bu[4], bb[4];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+    const int k = 4 * s2 + hi;
+    if (TS == 16) { bu[s2] = si[k + 16 * lo]; bb[s2] = sb[k + 16 * lo]; }
+    else {
+      // blockdiag(Ui, Ui): rows / columns 0..7 act on P, 8..15 on AP;  [B 0; 0 -B]
+      const int kk = k & 7, cc = lo & 7;
+      const bool same = (k < 8) == (lo < 8);
+      bu[s2] = same ? si[kk + 16 * cc] : 0.0;
+      bb[s2] = same ? (k < 8 ? sb[kk + 16 * cc] : -sb[kk + 16 * cc]) : 0.0;
+    }
+  }
+  double rr = 0.0;   // sum of squares of the new R in column lo (TS = 8: lo - 8)
+  const size_t ntile = ((size_t)m + 15) >> 4;
+  const size_t tstride = (size_t)gridDim.x * (WG / 64);
+  for (size_t tl = (size_t)blockIdx.x * (WG / 64) + wave; tl < ntile; tl += tstride) {
+    const size_t r0 = tl << 4;
+    const size_t arow = r0 + lo;
+    const bool aok = arow < (size_t)m;
+    if (TS == 16) {
+      double ap_[4], aap[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        ap_[s2] = aok ? P[arow * 16 + 4 * s2 + hi] : 0.0;
+        aap[s2] = aok ? AP[arow * 16 + 4 * s2 + hi] : 0.0;
+      }
+      mfma_d4 x, r, pn = mfma_d4{0.0, 0.0, 0.0, 0.0}, apn = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t row = r0 + hi + 4 * q;
+        const bool ok = row < (size_t)m;
+        x[q] = ok ? X[row * 16 + lo] : 0.0;
+        r[q] = ok ? R[row * 16 + lo] : 0.0;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        pn = __builtin_amdgcn_mfma_f64_16x16x4f64(ap_[s2], bu[s2], pn, 0, 0, 0);
+        apn = __builtin_amdgcn_mfma_f64_16x16x4f64(aap[s2], bu[s2], apn, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ap_[s2], bb[s2], x, 0, 0, 0);
+        r = __builtin_amdgcn_mfma_f64_16x16x4f64(aap[s2], -bb[s2], r, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t row = r0 + hi + 4 * q;
+        if (row < (size_t)m) {
+          P[row * 16 + lo] = pn[q]; AP[row * 16 + lo] = apn[q];
+          X[row * 16 + lo] = x[q]; R[row * 16 + lo] = r[q];
+          if (lo < nc) rr = fma(r[q], r[q], rr);
+        }
+      }
+    } else {
+      double a[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const int k = 4 * s2 + hi;
+        a[s2] = aok ? (k < 8 ? P[arow * 8 + k] : AP[arow * 8 + k - 8]) : 0.0;
+      }
+      mfma_d4 xr, pn = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      double* __restrict__ XR = lo < 8 ? X : R;
+      double* __restrict__ PA = lo < 8 ? P : AP;
+      const int cc = lo & 7;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t row = r0 + hi + 4 * q;
+        xr[q] = row < (size_t)m ? XR[row * 8 + cc] : 0.0;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        pn = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bu[s2], pn, 0, 0, 0);
+        xr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bb[s2], xr, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t row = r0 + hi + 4 * q;
+        if (row < (size_t)m) {
+          PA[row * 8 + cc] = pn[q];
+          XR[row * 8 + cc] = xr[q];
+          if (lo >= 8 && cc < nc) rr = fma(xr[q], xr[q], rr);
+        }
+      }
+    }
+  }
+  // column sums of R^2: lanes with the same column (4 per wave), then the waves
+  __shared__ double red[WG / 64][TS];
+  rr += __shfl_xor(rr, 16);
+  rr += __shfl_xor(rr, 32);
+  if (TS == 16) { if (hi == 0) red[wave][lo] = rr; }
+  else if (hi == 0 && lo >= 8) red[wave][lo - 8] = rr;
+  __syncthreads();
+  if (tid < TS) {
+    double sv = red[0][tid];
+#pragma unroll
+    for (int w2 = 1; w2 < WG / 64; ++w2) sv += red[w2][tid];
+    rtr[(size_t)blockIdx.x * TS + tid] = sv;
+  }
+}
+
 template <int TS>
 __global__ __launch_bounds__(WG) void k_colnorm2(int m, const double* __restrict__ R,
                                                  double* __restrict__ rtr) {
@@ -2578,8 +2725,17 @@ int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double
   int blocks = grid_rows(m, 2);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
-                                     t, nc, U, alpha, P, AP, X, R, rtr_partials));
+  // PREALPS_TRSM_MFMA=0: lane-per-row substitution at every width (the matrix-core variant forms U^-1)
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("PREALPS_TRSM_MFMA"); use_mfma = e ? atoi(e) : 1; }
+  if (ts == 16 && use_mfma)
+    hipLaunchKernelGGL((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials);
+  else if (ts == 8 && use_mfma)
+    hipLaunchKernelGGL((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials);
+  else {
+    TS_DISPATCH(ts, hipLaunchKernelGGL((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+                                       t, nc, U, alpha, P, AP, X, R, rtr_partials));
+  }
   if (kfail("k_trsm_update")) return 1;
   if (trace_nc <= 0) return 0;
   hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, blocks, ts, trace_nc,
