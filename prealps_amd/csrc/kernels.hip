@@ -2501,6 +2501,16 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
   if constexpr (TS >= 8) {
     if (split) return bj_launch_ch<4, 8, TS>(pl, R, wmax, list, count, in, out);
   }
+  // Few blocks (a GPU of a multi-GPU run holds 1/8 of them): below one wavefront per SIMD the
+  // sweep is latency bound, so a 4-column panel is shared by two wavefronts of 2 columns each
+  // (half the FMAs and pivot broadcasts per wavefront; the band is read twice, from L2).
+  // PREALPS_BJ_SPLIT4: -1 (default) when a class has fewer blocks than the chip has SIMDs, 0 never, 1 always.
+  if constexpr (TS == 4) {
+    static int split4 = -2;
+    if (split4 == -2) { const char* e = getenv("PREALPS_BJ_SPLIT4"); split4 = e ? atoi(e) : -1; }
+    const int simds = 4 * (pa_rt_num_cus() > 0 ? pa_rt_num_cus() : 256);
+    if (split4 == 1 || (split4 < 0 && count < simds)) return bj_launch_ch<2, 8, 4>(pl, R, wmax, list, count, in, out);
+  }
   return bj_launch_ch<TS, 8, TS>(pl, R, wmax, list, count, in, out);
 }
 

@@ -64,10 +64,12 @@ def test_config0_elasticity_12x10x10_t4_p8():
         got = prob.solve(rhs, 4, ortho_alg=pa.ORTHODIR, bs_red=pa.NO_BS_RED, tol=1e-5, max_iter=1000)
         ref = O.ECG(B, rowpos, 4, O.ORTHODIR, O.NO_BS_RED, 1e-5, 1000).solve(rhs)
         # Coefficient jumps of 1e10: two fp64 implementations of the same recurrence drift apart
-        # exponentially (tools/history_probe.py, profiles/r02_history_divergence.txt: 5e-13 after
-        # the first iteration, 1e-10 after 40, O(1) after 80 of ~90).  So: the first 40 residuals
-        # to 1e-8, the iteration count within 3, and both answers solve the system.
-        np.testing.assert_allclose(got.res[:40], ref["res"][:40], rtol=RTOL_HIST)
+        # exponentially (tools/history_probe.py, profiles/r02_history_divergence.txt: 1e-13 after
+        # the first iteration, a factor ~10 every 10 iterations).  So: the first 20 residuals to
+        # 1e-8, the rest to 1e-4, the iteration count within 3, and both answers solve the system.
+        k = min(len(got.res), len(ref["res"]))
+        np.testing.assert_allclose(got.res[:20], ref["res"][:20], rtol=RTOL_HIST)
+        np.testing.assert_allclose(got.res[:k - 3], ref["res"][:k - 3], rtol=1e-4)
         assert abs(got.iters - ref["iters"]) <= 3 and got.iters < 1000
         assert got.final_res <= 1e-5 * got.normb
         for x, res in ((got.x, got.final_res), (ref["x"], ref["final_res"])):
