@@ -166,14 +166,13 @@ def main():
                   "torch.distributed callbacks" % prob.comm_kind, file=sys.stderr)
     rhs = prob.reference_rhs()
     alg = {"odir": pl.ORTHODIR, "omin": pl.ORTHOMIN, "fused": pl.ORTHODIR_FUSED}[a.alg]
-    if alg == pl.ORTHODIR_FUSED:
-        raise SystemExit("bench.py times the two-phase RCI loop; use --alg odir|omin")
     e = prob.new_ecg(a.t, alg, pl.NO_BS_RED, 1e-5, 100000)
     rci = C.c_int(0)
     prhs = rhs.ctypes.data_as(C.POINTER(C.c_double))
     check(L.preAlps_ECGInitialize(C.byref(e), prhs, C.byref(rci)), "ECGInitialize")
     check(L.preAlps_BlockJacobiApply(e.R, e.P), "BlockJacobiApply")
-    check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
+    if alg != pl.ORTHODIR_FUSED:     # (the fused loop starts every iteration with the product, test_ecg_bench_fused.c:252)
+        check(L.preAlps_BlockOperator(e.P, e.AP), "BlockOperator")
     state = {"rci": rci, "restarts": 0, "last_iters": 0, "last_res": float("nan")}
 
     def barrier():
@@ -304,8 +303,8 @@ def main():
                            "syncs after every phase, so its total is above ms_per_step"},
     }
     if rank == 0 and phases:
-        phase_table("ODIR on %d x MI355X (device time, %d iterations)" % (world, a.phase_iters)
-                    if a.alg == "odir" else "OMIN on %d x MI355X" % world, world, a.phase_iters, phases, ecg_fields)
+        phase_table("%s on %d x MI355X (device time, %d iterations)" % ({"odir": "ODIR", "omin": "OMIN", "fused": "F-ODIR"}[a.alg], world, a.phase_iters),
+                    world, a.phase_iters, phases, ecg_fields)
 
     # ---- CPU baseline on the host cores, rank 0, N=1.  Two ports of the same algorithm are timed on
     #      a bounded sample and the FASTER one is reported: (a) oracle/ecg_oracle.c, plain C + OpenMP,
@@ -321,7 +320,8 @@ def main():
         B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), prob.part_vector(), nparts)
         rhs_cpu = O.reference_rhs(rowpos)
         tf0 = time.perf_counter()
-        ecg = O.ECG(B, rowpos, a.t, O.ORTHODIR if a.alg == "odir" else O.ORTHOMIN, O.NO_BS_RED, 1e-5, a.cpu_iters)
+        ecg = O.ECG(B, rowpos, a.t, {"odir": O.ORTHODIR, "omin": O.ORTHOMIN, "fused": O.ORTHODIR_FUSED}[a.alg],
+                    O.NO_BS_RED, 1e-5, a.cpu_iters)
         tfac = time.perf_counter() - tf0
         r = ecg.solve(rhs_cpu)
         k = min(len(gpu.res), len(r["res"]))
@@ -381,7 +381,8 @@ def main():
             p2 = rhs2.ctypes.data_as(C.POINTER(C.c_double))
             check(L.preAlps_ECGInitialize(C.byref(e2), p2, C.byref(rci2)), "ECGInitialize")
             check(L.preAlps_BlockJacobiApply(e2.R, e2.P), "BlockJacobiApply")
-            check(L.preAlps_BlockOperator(e2.P, e2.AP), "BlockOperator")
+            if alg != pl.ORTHODIR_FUSED:
+                check(L.preAlps_BlockOperator(e2.P, e2.AP), "BlockOperator")
             st2 = {"rci": rci2, "restarts": 0, "last_iters": 0, "last_res": float("nan")}
             n2 = max(5, a.steps // 5)
             run_iterations(prob2, e2, rhs2, L, 3, st2)

@@ -753,11 +753,28 @@ int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_h
 
 /* Advance the driver loop (examples/test_ecg_prealps_op.c:208-221) by nsteps full
  * iterations, restarting from the same rhs (as after preAlps_ECGInitialize) whenever the
- * stopping test fires; what bench.py times.  Two-phase variants only. */
+ * stopping test fires; what bench.py times. */
 int preAlps_ECGAdvance(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int nsteps, int* restarts,
                        int* last_iters, double* last_res) {
   int stop = 0, done = 0;
-  if (ecg->ortho_alg == ORTHODIR_FUSED) return PA_FAIL("preAlps_ECGAdvance drives the two-phase variants");
+  if (ecg->ortho_alg == ORTHODIR_FUSED) {
+    /* the loop of examples/test_ecg_bench_fused.c:252-259: one reduction per iteration; *rci_request
+     * becomes 1 when converged (then: restart from the same rhs) */
+    while (done < nsteps) {
+      if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+      if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+      if (preAlps_ECGIterate(ecg, rci_request)) return 1;
+      ++done;
+      if (*rci_request == 1) {
+        if (restarts) ++*restarts;
+        if (last_iters) *last_iters = ecg->iter;
+        if (last_res) *last_res = ecg->res;
+        if (_preAlps_ECGReset(ecg, rhs, rci_request)) return 1;
+        if (preAlps_BlockJacobiApply(ecg->R, ecg->P)) return 1;
+      }
+    }
+    return 0;
+  }
   while (done < nsteps) {
     if (preAlps_ECGIterate(ecg, rci_request)) return 1;
     if (*rci_request == 0) {

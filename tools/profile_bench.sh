@@ -10,9 +10,9 @@ OUT=${1:-gpurun_out}
 WORKLOAD=${2:-elasticity}
 rm -rf "$OUT"/prof_stats "$OUT"/prof_fetch "$OUT"/prof_write
 rocprofv3 --kernel-trace --stats -d "$OUT"/prof_stats -o stats --output-format csv -- \
-  python3 bench.py --workload "$WORKLOAD" --steps 50 --warmup 5 --no-cpu > "$OUT"/prof_stats_bench.json
+  python3 bench.py --workload "$WORKLOAD" --steps 50 --warmup 5 --no-cpu --survey-nparts 0 > "$OUT"/prof_stats_bench.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT"/prof_fetch -o fetch --output-format csv -- \
-  python3 bench.py --workload "$WORKLOAD" --steps 10 --warmup 2 --no-cpu --spmm-reps 10 > "$OUT"/prof_fetch_bench.json
+  python3 bench.py --workload "$WORKLOAD" --steps 10 --warmup 2 --no-cpu --spmm-reps 10 --survey-nparts 0 --phase-iters 0 > "$OUT"/prof_fetch_bench.json
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT"/prof_write -o write --output-format csv -- \
-  python3 bench.py --workload "$WORKLOAD" --steps 10 --warmup 2 --no-cpu --spmm-reps 10 > "$OUT"/prof_write_bench.json
+  python3 bench.py --workload "$WORKLOAD" --steps 10 --warmup 2 --no-cpu --spmm-reps 10 --survey-nparts 0 --phase-iters 0 > "$OUT"/prof_write_bench.json
 python3 tools/summarize_profiles.py "$OUT" "$WORKLOAD"

@@ -29,7 +29,7 @@ def find(d, pattern):
 
 # 1. kernel statistics: copy the rocprofv3 summary as it is (names shortened)
 rows = list(csv.reader(open(find("prof_stats", "*kernel_stats.csv"))))
-dst = os.path.join(root, "profiles", "r01_bench_%s_kernel_stats.csv" % workload)
+dst = os.path.join(root, "profiles", "r02_bench_%s_kernel_stats.csv" % workload)
 with open(dst, "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(rows[0])
@@ -60,7 +60,7 @@ spmm = [k for k in summary if k.startswith("k_spmm")]
 bench = json.loads(open(os.path.join(out, "prof_stats_bench.json")).read().strip().splitlines()[-1])
 doc = {
     "command": "tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace "
-               "--output-format csv -- python3 bench.py --workload %s --steps 10 --warmup 2 --no-cpu --spmm-reps 10" % workload,
+               "--output-format csv -- python3 bench.py --workload %s --steps 10 --warmup 2 --no-cpu --spmm-reps 10 --survey-nparts 0 --phase-iters 0" % workload,
     "workload": bench["config"]["workload"],
     "units": "counter values are KiB; FETCH_SIZE is doubled (gfx950 reports half of the bytes of wide coalesced "
              "reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE is exact",
@@ -72,7 +72,7 @@ doc = {
     "raw": raw,
     "bench_line_of_the_profiled_run": bench,
 }
-dst = os.path.join(root, "profiles", "r01_pmc_hbm_traffic_%s.json" % workload)
+dst = os.path.join(root, "profiles", "r02_pmc_hbm_traffic_%s.json" % workload)
 with open(dst, "w") as f:
     json.dump(doc, f, indent=1)
 print("wrote", dst)
