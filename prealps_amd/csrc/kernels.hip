@@ -2079,20 +2079,24 @@ __device__ __forceinline__ void nd_apply_block(double (&acc)[RPT][TS], const dou
 #pragma unroll
   for (int k = 0; k < RPT; ++k) any |= on[k];
   if (!any) return;
-  // UN * RPT panel loads in flight per thread before the first one is used: a workgroup runs alone
-  // on its CU at the upper levels of the tree, so the memory latency has to be covered from inside
+  // Software pipeline: the UN * RPT panel loads of the next batch are issued before the current
+  // batch is used -- a workgroup runs alone on its CU at the upper levels of the tree, so the
+  // memory latency has to be covered from inside the thread.
   constexpr int UN = NT >= 1024 ? (RPT >= 8 ? 1 : 8 / RPT) : (RPT >= 16 ? 1 : 16 / RPT);   // (128 VGPRs per thread at 1024 threads)
+  double cur[UN][RPT], nxt[UN][RPT];
+#pragma unroll
+  for (int u = 0; u < UN; ++u)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) cur[u][k] = (on[k] && u < nb) ? p[k][(size_t)u * ldm] : 0.0;
 #pragma unroll 1
   for (int j0 = 0; j0 < nb; j0 += UN) {
-    double cf[UN][RPT];
+    const int j1 = j0 + UN;
 #pragma unroll
     for (int u = 0; u < UN; ++u)
 #pragma unroll
-      for (int k = 0; k < RPT; ++k) cf[u][k] = (on[k] && j0 + u < nb) ? p[k][(size_t)(j0 + u) * ldm] : 0.0;
-    constexpr int YB = TS >= 8 ? 1 : 8 / TS;   // published rows read from LDS at a time (the compiler would otherwise fetch all UN up front: registers)
+      for (int k = 0; k < RPT; ++k) nxt[u][k] = (on[k] && j1 + u < nb) ? p[k][(size_t)(j1 + u) * ldm] : 0.0;
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (u % YB == 0) asm volatile("" ::: "memory");
       double y[TS];
       const int j = min(j0 + u, 63);
 #pragma unroll
@@ -2100,15 +2104,15 @@ __device__ __forceinline__ void nd_apply_block(double (&acc)[RPT][TS], const dou
 #pragma unroll
       for (int k = 0; k < RPT; ++k)
 #pragma unroll
-        for (int c = 0; c < TS; ++c) acc[k][c] = fma(-cf[u][k], y[c], acc[k][c]);
+        for (int c = 0; c < TS; ++c) acc[k][c] = fma(-cur[u][k], y[c], acc[k][c]);
     }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) cur[u][k] = nxt[u][k];
   }
 }
 
-// The 64-row group that holds the pivots of a block, inside its wavefront.  FWD: pivot j acts on
-// the lanes behind it (rows of the group that exist: lane < nvalid); backward: pivot i, taken
-// in descending order, acts on the lanes in front of it.  base = element (first row of the
-// group, first pivot) of the panel; consecutive lanes read consecutive addresses.
 // The 64 x 64 block the pivots of a step settle in was copied to LDS by the whole workgroup
 // (dblk[j][i] = coefficient of pivot j for the row in lane i, zero where it does not apply), so
 // the serial chain below meets LDS latency, not HBM latency, at each of its 64 links.
@@ -2164,18 +2168,21 @@ struct nd_args {
   const int* n; const int* m; const int* ld; const long long* offF; const long long* offB; const int* rows_off;
   const int* coff; const int* ccoff; const int* rows; const int* src; const double* dinv; const double* F;
   const double* B; double* contrib;
+  const long long* poff; double* partial;     /* split fronts: partial sums of the backward sweep, [chunk][column] */
 };
+constexpr int ND_CHUNK = 256;                 /* rows below of a split front handled by one workgroup */
 
 // Forward: w = [x(columns) ; 0] + the children's contributions; L y = w on the n columns; the m rows
 // below leave as this supernode's contribution to its parent.  XS = panel stride, TS = columns
 // handled by this workgroup (blockIdx.y picks the column group).
 template <int TS, int XS, int NT, int RPT>
-__global__ __launch_bounds__(NT) void k_nd_forward(nd_args a, const int* __restrict__ list,
+__global__ __launch_bounds__(NT) void k_nd_forward(nd_args a, const int* __restrict__ list, int split,
                                                    const double* __restrict__ in, double* __restrict__ out) {
   __shared__ double ybuf[2][64][TS];
   __shared__ double dblk[64][65];
   const int s = list[blockIdx.x], coff = blockIdx.y * TS;
-  const int n = a.n[s], f = n + a.m[s], ld = a.ld[s];
+  // split: only the triangular part (the n pivot rows); the rows below belong to k_nd_rect_fwd
+  const int n = a.n[s], f = split ? n : n + a.m[s], ld = a.ld[s];
   const double* __restrict__ L = a.F + a.offF[s];
   const int* __restrict__ rows = a.rows + a.rows_off[s];
   const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
@@ -2231,16 +2238,152 @@ __global__ __launch_bounds__(NT) void k_nd_forward(nd_args a, const int* __restr
   }
 }
 
+// The rectangular part of a large front on its own grid: ND_CHUNK rows below per workgroup, so
+// that the upper levels of the tree -- 64..256 fronts of 1000..2000 rows -- fill the chip instead
+// of one CU each.  Forward: contribution(r) = children's contributions - sum_j Lhat(r, j) a_j with
+// a_j = y_j L_jj (the unscaled pivot values; y was written by the triangular kernel of the level).
+template <int TS, int XS>
+__global__ __launch_bounds__(ND_CHUNK) void k_nd_rect_fwd(nd_args a, const int* __restrict__ cfront,
+                                                          const int* __restrict__ crow0,
+                                                          const double* __restrict__ out) {
+  __shared__ double ys[64][TS];
+  const int s = cfront[blockIdx.x], r0 = crow0[blockIdx.x], coff = blockIdx.y * TS;
+  const int n = a.n[s], m = a.m[s], ld = a.ld[s];
+  const double* __restrict__ L = a.F + a.offF[s];
+  const int* __restrict__ rows = a.rows + a.rows_off[s];
+  const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
+  const int tid = threadIdx.x;
+  const int rr = r0 + tid;                    // row below, 0-based
+  const bool on = rr < m;
+  const int r = n + (on ? rr : 0);            // front row
+  double acc[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+  if (on) {
+    const int s0 = src[2 * r], s1 = src[2 * r + 1];
+    double t[TS];
+    if (s0 >= 0) {
+      load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s] + s0), t);
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[c] += t[c];
+    }
+    if (s1 >= 0) {
+      load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s + 1] + s1), t);
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[c] += t[c];
+    }
+  }
+  for (int jb = 0; jb < n; jb += 64) {
+    const int nb = min(64, n - jb);
+    if (tid < 64) {
+      double y[TS];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) y[c] = 0.0;
+      if (tid < nb) {
+        const int g = rows[jb + tid];
+        load_row_s<TS, XS>(out + coff, (size_t)g, y);
+        const double ljj = 1.0 / a.dinv[g];
+#pragma unroll
+        for (int c = 0; c < TS; ++c) y[c] *= ljj;
+      }
+      double2* q = reinterpret_cast<double2*>(ys[tid]);
+#pragma unroll
+      for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(y[2 * c], y[2 * c + 1]);
+    }
+    __syncthreads();
+    if (on) {
+      const double* __restrict__ p = L + (size_t)jb * ld + r;
+      double cf[16], nx[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) cf[u] = u < nb ? p[(size_t)u * ld] : 0.0;
+#pragma unroll 1
+      for (int j0 = 0; j0 < nb; j0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) nx[u] = j0 + 16 + u < nb ? p[(size_t)(j0 + 16 + u) * ld] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const double2* yq = reinterpret_cast<const double2*>(ys[min(j0 + u, 63)]);
+#pragma unroll
+          for (int c = 0; c < TS / 2; ++c) {
+            const double2 yv = yq[c];
+            acc[2 * c] = fma(-cf[u], yv.x, acc[2 * c]);
+            acc[2 * c + 1] = fma(-cf[u], yv.y, acc[2 * c + 1]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) cf[u] = nx[u];
+      }
+    }
+    __syncthreads();
+  }
+  if (on) store_row_s<TS, XS>(a.contrib + coff, (size_t)(a.coff[s] + rr), acc);
+}
+
+// Backward: partial(chunk, k) = sum over the chunk's rows i of L(i, k) z_i for 256 columns k per
+// workgroup (blockIdx.y); the triangular kernel of the level subtracts the chunks in order.
+template <int TS, int XS>
+__global__ __launch_bounds__(ND_CHUNK) void k_nd_rect_bwd(nd_args a, const int* __restrict__ cfront,
+                                                          const int* __restrict__ crow0,
+                                                          const double* __restrict__ out, int ncg) {
+  __shared__ double zs[ND_CHUNK][TS];
+  const int s = cfront[blockIdx.x], r0 = crow0[blockIdx.x];
+  const int kb = blockIdx.y / ncg, coff = (blockIdx.y % ncg) * TS;
+  const int n = a.n[s], m = a.m[s], ldb = (n + 1) & ~1;
+  if (kb * ND_CHUNK >= n) return;             // (uniform: this front has fewer columns than the widest of the launch)
+  const double* __restrict__ U = a.B + a.offB[s];
+  const int* __restrict__ rows = a.rows + a.rows_off[s];
+  const int tid = threadIdx.x;
+  const int nr = min(ND_CHUNK, m - r0);
+  {
+    double z[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) z[c] = 0.0;
+    if (tid < nr) load_row_s<TS, XS>(out + coff, (size_t)rows[n + r0 + tid], z);
+    double2* q = reinterpret_cast<double2*>(zs[tid]);
+#pragma unroll
+    for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(z[2 * c], z[2 * c + 1]);
+  }
+  __syncthreads();
+  const int k = kb * ND_CHUNK + tid;
+  if (k >= n) return;
+  double acc[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+  const double* __restrict__ p = U + (size_t)(n + r0) * ldb + k;
+  double cf[16], nx[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) cf[u] = u < nr ? p[(size_t)u * ldb] : 0.0;
+#pragma unroll 1
+  for (int i0 = 0; i0 < nr; i0 += 16) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) nx[u] = i0 + 16 + u < nr ? p[(size_t)(i0 + 16 + u) * ldb] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const double2* zq = reinterpret_cast<const double2*>(zs[min(i0 + u, ND_CHUNK - 1)]);
+#pragma unroll
+      for (int c = 0; c < TS / 2; ++c) {
+        const double2 zv = zq[c];
+        acc[2 * c] = fma(cf[u], zv.x, acc[2 * c]);
+        acc[2 * c + 1] = fma(cf[u], zv.y, acc[2 * c + 1]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) cf[u] = nx[u];
+  }
+  store_row_s<TS, XS>(a.partial + coff, (size_t)(a.poff[s] + (long long)(r0 / ND_CHUNK) * n + k), acc);
+}
+
 // Backward: L^T z = y on the n columns, the m rows below are ancestors whose z is final.
 // b_k = L_kk z_k is carried unscaled; the row-major copy holds L(i,k) for the rows below and
 // L(i,k) / L(i,i) for the pivot rows.
 template <int TS, int XS, int NT, int RPT>
-__global__ __launch_bounds__(NT) void k_nd_backward(nd_args a, const int* __restrict__ list, double* __restrict__ out) {
+__global__ __launch_bounds__(NT) void k_nd_backward(nd_args a, const int* __restrict__ list, int split,
+                                                    double* __restrict__ out) {
   __shared__ double ybuf[2][64][TS];
   __shared__ double dblk[64][65];
   __shared__ double zbuf[2048];
   const int s = list[blockIdx.x], coff = blockIdx.y * TS;
-  const int n = a.n[s], f = n + a.m[s], ldb = (n + 1) & ~1;
+  const int n = a.n[s], mrows = a.m[s], f = split ? n : n + mrows, ldb = (n + 1) & ~1;
   const double* __restrict__ U = a.B + a.offB[s];
   const int* __restrict__ rows = a.rows + a.rows_off[s];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2253,6 +2396,23 @@ __global__ __launch_bounds__(NT) void k_nd_backward(nd_args a, const int* __rest
 #pragma unroll
     for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
     if (r < n) { grow[k] = rows[r]; load_row_s<TS, XS>(out + coff, (size_t)grow[k], acc[k]); }
+  }
+  if (split) {
+    // the rows below were multiplied in by k_nd_rect_bwd, ND_CHUNK of them per workgroup: add the
+    // partial sums (fixed order)
+    const int nch = (mrows + ND_CHUNK - 1) / ND_CHUNK;
+    const long long p0 = a.poff[s];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int r = tid + k * NT;
+      if (r < n)
+        for (int ch = 0; ch < nch; ++ch) {
+          double t[TS];
+          load_row_s<TS, XS>(a.partial + coff, (size_t)(p0 + (long long)ch * n + r), t);
+#pragma unroll
+          for (int c = 0; c < TS; ++c) acc[k][c] -= t[c];
+        }
+    }
   }
   int par = 0;
   // The rows below (ancestors, final).  A supernode low in the tree has few columns and many rows
@@ -2574,32 +2734,48 @@ constexpr int ND_NT[ND_NCLASS] = {256, 256, 512, 1024, 1024, 1024};
 constexpr int ND_RPT[ND_NCLASS] = {1, 2, 2, 2, 4, 8};
 
 template <int TS, int XS, int NT, int RPT>
-static int nd_launch_one(const nd_args& a, const int* list, int count, bool fwd, const double* in, double* out) {
+static int nd_launch_one(const nd_args& a, const int* list, int count, int split, bool fwd, const double* in, double* out) {
   const dim3 grid(count, XS / TS);
-  if (fwd) hipLaunchKernelGGL((k_nd_forward<TS, XS, NT, RPT>), grid, dim3(NT), 0, cur_stream(), a, list, in, out);
-  else hipLaunchKernelGGL((k_nd_backward<TS, XS, NT, RPT>), grid, dim3(NT), 0, cur_stream(), a, list, out);
+  if (fwd) hipLaunchKernelGGL((k_nd_forward<TS, XS, NT, RPT>), grid, dim3(NT), 0, cur_stream(), a, list, split, in, out);
+  else hipLaunchKernelGGL((k_nd_backward<TS, XS, NT, RPT>), grid, dim3(NT), 0, cur_stream(), a, list, split, out);
   return kfail(fwd ? "k_nd_forward" : "k_nd_backward");
 }
 
 // a thread keeps RPT * TS doubles: at most 32 (64 VGPRs); wider panels go in column groups
 template <int XS, int NT, int RPT>
-static int nd_launch_cls(const nd_args& a, const int* list, int count, bool fwd, const double* in, double* out) {
+static int nd_launch_cls(const nd_args& a, const int* list, int count, int split, bool fwd, const double* in, double* out) {
   constexpr int TSMAX = 32 / RPT;
   constexpr int TS = XS <= TSMAX ? XS : (TSMAX < 2 ? 2 : TSMAX);
-  return nd_launch_one<TS, XS, NT, RPT>(a, list, count, fwd, in, out);
+  return nd_launch_one<TS, XS, NT, RPT>(a, list, count, split, fwd, in, out);
 }
 
 template <int XS>
-static int nd_launch(const nd_args& a, int cls, const int* list, int count, bool fwd, const double* in, double* out) {
+static int nd_launch(const nd_args& a, int cls, const int* list, int count, int split, bool fwd, const double* in, double* out) {
   switch (cls) {
-    case 0: return nd_launch_cls<XS, 256, 1>(a, list, count, fwd, in, out);
-    case 1: return nd_launch_cls<XS, 256, 2>(a, list, count, fwd, in, out);
-    case 2: return nd_launch_cls<XS, 512, 2>(a, list, count, fwd, in, out);
-    case 3: return nd_launch_cls<XS, 1024, 2>(a, list, count, fwd, in, out);
-    case 4: return nd_launch_cls<XS, 1024, 4>(a, list, count, fwd, in, out);
-    case 5: return nd_launch_cls<XS, 1024, 8>(a, list, count, fwd, in, out);
+    case 0: return nd_launch_cls<XS, 256, 1>(a, list, count, split, fwd, in, out);
+    case 1: return nd_launch_cls<XS, 256, 2>(a, list, count, split, fwd, in, out);
+    case 2: return nd_launch_cls<XS, 512, 2>(a, list, count, split, fwd, in, out);
+    case 3: return nd_launch_cls<XS, 1024, 2>(a, list, count, split, fwd, in, out);
+    case 4: return nd_launch_cls<XS, 1024, 4>(a, list, count, split, fwd, in, out);
+    case 5: return nd_launch_cls<XS, 1024, 8>(a, list, count, split, fwd, in, out);
   }
   return 1;
+}
+
+// the rows below of the split fronts of one launch: `nchunk` (front, first row) pairs
+template <int XS>
+static int nd_launch_rect(const nd_args& a, const int* cfront, const int* crow0, int nchunk, int nmax, bool fwd,
+                          const double* out) {
+  if (nchunk <= 0) return 0;
+  constexpr int TS = XS <= 8 ? XS : 8;        // 16-column panels in two column groups (LDS, registers)
+  constexpr int ncg = XS / TS;
+  if (fwd) {
+    hipLaunchKernelGGL((k_nd_rect_fwd<TS, XS>), dim3(nchunk, ncg), dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, out);
+    return kfail("k_nd_rect_fwd");
+  }
+  const int nkb = (nmax + ND_CHUNK - 1) / ND_CHUNK;
+  hipLaunchKernelGGL((k_nd_rect_bwd<TS, XS>), dim3(nchunk, nkb * ncg), dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, out, ncg);
+  return kfail("k_nd_rect_bwd");
 }
 
 extern "C" {
@@ -2862,14 +3038,23 @@ int pa_nd_class_of(int front_rows) {
 }
 
 // launches are listed bottom-up (height, then class): forward in that order, backward reversed
+int pa_nd_chunk_rows(void) { return ND_CHUNK; }
+
 int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out) {
   nd_args a{pl->n, pl->m, pl->ld, pl->offF, pl->offB, pl->rows_off, pl->coff, pl->ccoff, pl->rows, pl->src,
-            pl->dinv, pl->F, pl->B, pl->contrib};
+            pl->dinv, pl->F, pl->B, pl->contrib, pl->poff, pl->partial};
   for (int pass = 0; pass < 2; ++pass)
     for (int q = 0; q < pl->nlaunch; ++q) {
       const int i = pass == 0 ? q : pl->nlaunch - 1 - q;
-      int rc = 1;
-      TS_DISPATCH(ts, rc = nd_launch<TS_>(a, pl->l_class[i], pl->l_list[i], pl->l_count[i], pass == 0, in, out));
+      const bool fwd = pass == 0;
+      const int split = pl->l_split[i];
+      int rc = 0;
+      // forward: pivots first, then the rows below; backward: rows below first, then the pivots
+      if (split && !fwd) { TS_DISPATCH(ts, rc = nd_launch_rect<TS_>(a, pl->l_cfront[i], pl->l_crow0[i], pl->l_nchunk[i], pl->l_nmax[i], false, out)); }
+      if (rc) return rc;
+      TS_DISPATCH(ts, rc = nd_launch<TS_>(a, pl->l_class[i], pl->l_list[i], pl->l_count[i], split, fwd, in, out));
+      if (rc) return rc;
+      if (split && fwd) { TS_DISPATCH(ts, rc = nd_launch_rect<TS_>(a, pl->l_cfront[i], pl->l_crow0[i], pl->l_nchunk[i], pl->l_nmax[i], true, out)); }
       if (rc) return rc;
     }
   return 0;

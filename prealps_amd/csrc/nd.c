@@ -35,6 +35,9 @@ typedef struct {
   int* d_coff; int* d_ccoff; int* d_rows; int* d_src; double* d_dinv; double* d_F; double* d_B;
   double* d_contrib; size_t contrib_rows; int contrib_ts;
   int nlaunch; int* l_height; int* l_class; int* l_count; int** l_list; const int** l_list_c;
+  /* split fronts */
+  int* l_split; int* l_nchunk; int* l_nmax; int** l_cfront; int** l_crow0; const int** l_cfront_c; const int** l_crow0_c;
+  long long* d_poff; double* d_partial; size_t partial_rows;
   double bytes;
 } pa_nd_t;
 
@@ -48,8 +51,10 @@ void pa_nd_free(void) {
   pa_rt_free(s->d_n); pa_rt_free(s->d_m); pa_rt_free(s->d_ld); pa_rt_free(s->d_offF); pa_rt_free(s->d_offB);
   pa_rt_free(s->d_rows_off); pa_rt_free(s->d_coff); pa_rt_free(s->d_ccoff); pa_rt_free(s->d_rows); pa_rt_free(s->d_src);
   pa_rt_free(s->d_dinv); pa_rt_free(s->d_F); pa_rt_free(s->d_B); pa_rt_free(s->d_contrib);
-  for (int i = 0; i < s->nlaunch; ++i) pa_rt_free(s->l_list[i]);
+  for (int i = 0; i < s->nlaunch; ++i) { pa_rt_free(s->l_list[i]); if (s->l_cfront) pa_rt_free(s->l_cfront[i]); if (s->l_crow0) pa_rt_free(s->l_crow0[i]); }
   free(s->l_height); free(s->l_class); free(s->l_count); free(s->l_list); free(s->l_list_c);
+  free(s->l_split); free(s->l_nchunk); free(s->l_nmax); free(s->l_cfront); free(s->l_crow0); free(s->l_cfront_c); free(s->l_crow0_c);
+  pa_rt_free(s->d_poff); pa_rt_free(s->d_partial);
   memset(s, 0, sizeof(*s));
 }
 
@@ -102,6 +107,46 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
   int rc = pa_nd_order(b, lrp, lci, leaf_rows, &B->tree);
   free(lrp); free(lci);
   if (rc) return 1;
+  /* Wide supernodes (the separators at the top of the tree: 1000-2000 columns) are cut into chains
+   * of at most `width` columns, each piece the only child of the next.  The triangular part of a
+   * piece is a handful of pivot blocks on one workgroup and everything below it -- the later
+   * pieces included -- is rectangular work that the split kernels spread over the chip; one
+   * workgroup marching through 30 pivot blocks of a 2000-column front was the longest chain of
+   * the whole sweep.  Same entries, same arithmetic. */
+  {
+    const char* we = getenv("PREALPS_ND_WIDTH");
+    const int width = we ? atoi(we) : 256;
+    const int n0 = B->tree.nsn;
+    int extra_tot = 0;
+    int* base = (int*)malloc(((size_t)n0 + 1) * sizeof(int));
+    if (!base) return 1;
+    for (int s = 0; s < n0; ++s) {
+      int ns = B->tree.first[s + 1] - B->tree.first[s];
+      base[s] = s + extra_tot;
+      if (width >= 64 && ns > width) extra_tot += (ns + width - 1) / width - 1;
+    }
+    base[n0] = n0 + extra_tot;
+    if (extra_tot > 0) {
+      int n2 = n0 + extra_tot;
+      int* first2 = (int*)malloc(((size_t)n2 + 1) * sizeof(int));
+      int* parent2 = (int*)malloc((size_t)n2 * sizeof(int));
+      if (!first2 || !parent2) { free(base); free(first2); free(parent2); return 1; }
+      for (int s = 0; s < n0; ++s) {
+        int c0 = B->tree.first[s], ns = B->tree.first[s + 1] - c0, np = base[s + 1] - base[s];
+        int w = ((ns + np - 1) / np + 63) & ~63;              /* piece width: even shares, multiples of 64 */
+        for (int k = 0; k < np; ++k) {
+          int id = base[s] + k, lo = c0 + k * w;
+          if (lo > c0 + ns) lo = c0 + ns;
+          first2[id] = lo;
+          parent2[id] = k + 1 < np ? id + 1 : (B->tree.parent[s] >= 0 ? base[B->tree.parent[s]] : -1);
+        }
+      }
+      first2[n2] = B->tree.first[n0];
+      free(B->tree.first); free(B->tree.parent);
+      B->tree.first = first2; B->tree.parent = parent2; B->tree.nsn = n2;
+    }
+    free(base);
+  }
   const int nsn = B->tree.nsn;
   const int* perm = B->tree.perm;
   int* ip = (int*)malloc((size_t)b * sizeof(int));
@@ -418,39 +463,81 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
               pa_rt_h2d(S->d_dinv, h_dinv, (size_t)m_local * sizeof(double));
     if (bad) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
   }
-  /* launch lists: by height, then by size class of the front (rows per thread) */
+  /* launch lists: by height, then by size class.  Fronts above PREALPS_ND_SPLIT rows (512) are
+   * split: their class is that of the n pivot rows alone (the triangular part, one workgroup),
+   * and the rows below go to a second grid in chunks of pa_nd_chunk_rows() rows, so that the few
+   * large fronts at the top of the tree occupy the whole chip. */
+  long long totp = 0;
   if (!rc) {
-    const int ncls = pa_nd_num_classes();
-    int cap = (maxh + 1) * ncls;
+    const int ncls = pa_nd_num_classes(), CH = pa_nd_chunk_rows();
+    const char* se = getenv("PREALPS_ND_SPLIT");
+    const int split_from = se ? atoi(se) : 512;
+    int cap = 2 * (maxh + 1) * ncls;
     S->l_height = (int*)calloc((size_t)cap, sizeof(int)); S->l_class = (int*)calloc((size_t)cap, sizeof(int));
     S->l_count = (int*)calloc((size_t)cap, sizeof(int)); S->l_list = (int**)calloc((size_t)cap, sizeof(int*));
     S->l_list_c = (const int**)calloc((size_t)cap, sizeof(int*));
+    S->l_split = (int*)calloc((size_t)cap, sizeof(int)); S->l_nchunk = (int*)calloc((size_t)cap, sizeof(int));
+    S->l_nmax = (int*)calloc((size_t)cap, sizeof(int));
+    S->l_cfront = (int**)calloc((size_t)cap, sizeof(int*)); S->l_crow0 = (int**)calloc((size_t)cap, sizeof(int*));
+    S->l_cfront_c = (const int**)calloc((size_t)cap, sizeof(int*)); S->l_crow0_c = (const int**)calloc((size_t)cap, sizeof(int*));
     int* tmp = (int*)malloc((size_t)nsn * sizeof(int));
+    int* cls_of = (int*)malloc((size_t)nsn * sizeof(int));
+    char* is_split = (char*)calloc((size_t)nsn, 1);
+    long long* h_poff = (long long*)calloc((size_t)nsn, sizeof(long long));
+    for (int g = 0; g < nsn && !rc; ++g) {
+      int f = h_n[g] + h_m[g];
+      is_split[g] = split_from > 0 && f > split_from && h_m[g] > 0;
+      cls_of[g] = pa_nd_class_of(is_split[g] ? h_n[g] : f);
+      if (cls_of[g] < 0) rc = PA_FAIL("block solve: a front of %d rows exceeds the kernel's limit; use more subdomains", f);
+      if (is_split[g]) { h_poff[g] = totp; totp += (long long)((h_m[g] + CH - 1) / CH) * h_n[g]; }
+    }
     for (int h = 0; h <= maxh && !rc; ++h)
-      for (int c = 0; c < ncls && !rc; ++c) {
-        int cntl = 0;
-        for (int g = 0; g < nsn; ++g) if (h_height[g] == h && pa_nd_class_of(h_n[g] + h_m[g]) == c) tmp[cntl++] = g;
-        if (!cntl) continue;
-        int i = S->nlaunch++;
-        S->l_height[i] = h; S->l_class[i] = c; S->l_count[i] = cntl;
-        S->l_list[i] = (int*)pa_rt_malloc((size_t)cntl * sizeof(int));
-        if (!S->l_list[i] || pa_rt_h2d(S->l_list[i], tmp, (size_t)cntl * sizeof(int))) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
-        S->l_list_c[i] = S->l_list[i];
-      }
-    for (int g = 0; g < nsn && !rc; ++g) if (pa_nd_class_of(h_n[g] + h_m[g]) < 0) rc = PA_FAIL("block solve: a front of %d rows exceeds the kernel's limit; use more subdomains", h_n[g] + h_m[g]);
-    free(tmp);
+      for (int sp = 0; sp < 2 && !rc; ++sp)
+        for (int c = 0; c < ncls && !rc; ++c) {
+          int cntl = 0, nchunk = 0, nmax = 0;
+          for (int g = 0; g < nsn; ++g) if (h_height[g] == h && cls_of[g] == c && is_split[g] == sp) {
+            tmp[cntl++] = g;
+            if (sp) { nchunk += (h_m[g] + CH - 1) / CH; if (h_n[g] > nmax) nmax = h_n[g]; }
+          }
+          if (!cntl) continue;
+          int i = S->nlaunch++;
+          S->l_height[i] = h; S->l_class[i] = c; S->l_count[i] = cntl; S->l_split[i] = sp; S->l_nchunk[i] = nchunk; S->l_nmax[i] = nmax;
+          S->l_list[i] = (int*)pa_rt_malloc((size_t)cntl * sizeof(int));
+          if (!S->l_list[i] || pa_rt_h2d(S->l_list[i], tmp, (size_t)cntl * sizeof(int))) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
+          S->l_list_c[i] = S->l_list[i];
+          if (sp && nchunk > 0 && !rc) {
+            int* cf = (int*)malloc((size_t)nchunk * sizeof(int));
+            int* cr = (int*)malloc((size_t)nchunk * sizeof(int));
+            int x = 0;
+            for (int q = 0; q < cntl; ++q) for (int r0 = 0; r0 < h_m[tmp[q]]; r0 += CH) { cf[x] = tmp[q]; cr[x++] = r0; }
+            S->l_cfront[i] = (int*)pa_rt_malloc((size_t)nchunk * sizeof(int));
+            S->l_crow0[i] = (int*)pa_rt_malloc((size_t)nchunk * sizeof(int));
+            if (!S->l_cfront[i] || !S->l_crow0[i] || pa_rt_h2d(S->l_cfront[i], cf, (size_t)nchunk * sizeof(int)) ||
+                pa_rt_h2d(S->l_crow0[i], cr, (size_t)nchunk * sizeof(int)))
+              rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
+            S->l_cfront_c[i] = S->l_cfront[i]; S->l_crow0_c[i] = S->l_crow0[i];
+            free(cf); free(cr);
+          }
+        }
+    if (!rc) {
+      S->d_poff = (long long*)pa_rt_malloc((size_t)nsn * sizeof(long long));
+      if (!S->d_poff || pa_rt_h2d(S->d_poff, h_poff, (size_t)nsn * sizeof(long long))) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
+    }
+    free(tmp); free(cls_of); free(is_split); free(h_poff);
   }
   free(h_n); free(h_m); free(h_ld); free(h_offF); free(h_offB); free(h_rows_off); free(h_coff); free(h_ccoff);
   free(h_rows); free(h_src); free(h_height); free(h_dinv); free(sn0); free(bF); free(bB);
   for (int x = 0; x < nblk; ++x) nd_block_free(&B[x]);
   free(B);
   if (rc) { pa_nd_free(); return rc == 2 ? 2 : 1; }
-  S->nsn = nsn; S->contrib_rows = (size_t)totc; S->bytes = 8.0 * (double)(totF + totB);
+  S->nsn = nsn; S->contrib_rows = (size_t)totc; S->partial_rows = (size_t)totp; S->bytes = 8.0 * (double)(totF + totB);
   pa_nd_plan_t* pl = &S->plan;
   pl->n = S->d_n; pl->m = S->d_m; pl->ld = S->d_ld; pl->offF = S->d_offF; pl->offB = S->d_offB; pl->rows_off = S->d_rows_off;
   pl->coff = S->d_coff; pl->ccoff = S->d_ccoff; pl->rows = S->d_rows; pl->src = S->d_src; pl->dinv = S->d_dinv;
   pl->F = S->d_F; pl->B = S->d_B;
   pl->nlaunch = S->nlaunch; pl->l_class = S->l_class; pl->l_count = S->l_count; pl->l_list = S->l_list_c;
+  pl->l_split = S->l_split; pl->l_nchunk = S->l_nchunk; pl->l_nmax = S->l_nmax;
+  pl->l_cfront = S->l_cfront_c; pl->l_crow0 = S->l_crow0_c; pl->poff = S->d_poff;
   S->created = 1;
   return 0;
 }
@@ -461,11 +548,14 @@ int pa_nd_apply(int ts, const double* in, double* out) {
   if (!S->created) return 0;
   if (S->contrib_ts < ts) {
     pa_rt_free(S->d_contrib);
+    pa_rt_free(S->d_partial);
     S->d_contrib = (double*)pa_rt_malloc((S->contrib_rows ? S->contrib_rows : 1) * (size_t)ts * sizeof(double));
-    if (!S->d_contrib) return PA_FAIL("block solve: scratch of %zu rows: %s", S->contrib_rows, pa_rt_error());
+    S->d_partial = (double*)pa_rt_malloc((S->partial_rows ? S->partial_rows : 1) * (size_t)ts * sizeof(double));
+    if (!S->d_contrib || !S->d_partial) return PA_FAIL("block solve: scratch of %zu + %zu rows: %s", S->contrib_rows, S->partial_rows, pa_rt_error());
     S->contrib_ts = ts;
   }
   S->plan.contrib = S->d_contrib;
+  S->plan.partial = S->d_partial;
   if (pa_k_nd_apply(&S->plan, ts, in, out)) return PA_FAIL("block-solve kernel launch failed");
   return 0;
 }

@@ -214,7 +214,15 @@ typedef struct {
   const int* l_class;          /* host arrays */
   const int* l_count;
   const int* const* l_list;    /* host array of device pointers to supernode ids */
+  /* Large fronts are split: the launch above handles their n pivot rows only, the rows below go to
+   * a second grid in chunks of pa_nd_chunk_rows() rows: l_nchunk[i] (front, first row) pairs.  The
+   * backward sweep leaves per chunk and column a partial sum at row poff[s] + chunk * n + column of
+   * `partial`. */
+  const int* l_split; const int* l_nchunk; const int* l_nmax;
+  const int* const* l_cfront; const int* const* l_crow0;
+  const long long* poff; double* partial;
 } pa_nd_plan_t;
+int pa_nd_chunk_rows(void);
 int pa_nd_num_classes(void);
 int pa_nd_class_of(int front_rows);   /* -1: front too large for the kernels */
 int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out);
