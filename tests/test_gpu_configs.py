@@ -401,3 +401,42 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True,
                        text=True, env=env1, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+# ---- opt-in kernel variants (their switches are read once per process: run in a child) ---------------
+_VARIANT_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import prealps_amd
+from oracle import oracle as O
+A = O.poisson3d(16)
+part = O.contiguous_partition(16 ** 3, 16)
+rp, ci, v = O.as_csr(A)
+prob = prealps_amd.EcgProblem(rp, ci, v, 16, part, scale=True, device=0)
+B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, 16)
+for t in (4, 8, 16):
+    X = np.random.default_rng(t).standard_normal((B.shape[0], t))
+    ref = O.spmm(B, X)
+    np.testing.assert_allclose(prob.block_operator(X, t), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    zr = O.BlockJacobi(B, rowpos).apply(X)
+    np.testing.assert_allclose(prob.block_jacobi_apply(X, t), zr, rtol=1e-9, atol=1e-10 * np.abs(zr).max())
+rhs = prob.reference_rhs()
+got = prob.solve(rhs, 8)
+ref = O.ECG(B, rowpos, 8).solve(rhs)
+assert got.iters == ref["iters"]
+np.testing.assert_allclose(got.res, ref["res"], rtol=1e-8)
+print("variant ok", prob.stat("spmm_staged"), prob.stat("bj_max_bandwidth"))
+"""
+
+
+@pytest.mark.parametrize("env", [{"PREALPS_SPMM_NT": "1", "PREALPS_SPMM_STAGED": "0"},
+                                 {"PREALPS_BJ_SPLIT": "1", "PREALPS_BJ_MFMA": "0", "PREALPS_BJ_WIDE_FROM": "448"},
+                                 {"PREALPS_BJ_MFMA": "2", "PREALPS_BJ_WIDE_FROM": "448", "PREALPS_TRSM_MFMA": "0"},
+                                 {"PREALPS_BJ_SPLIT4": "0", "PREALPS_ECG_FUSE": "0"}])
+def test_opt_in_kernel_variants(env):
+    """Non-temporal SpMM loads (k_spmm<TS,true>), the column-split block solve (PREALPS_BJ_SPLIT),
+    the matrix-core block solve at every width, the unsplit 4-column sweep and the four-pass first
+    half: same answers as the oracle (Poisson 16^3, 16 slabs, band 256 -> register-set class 5)."""
+    r = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET % ROOT], capture_output=True, text=True,
+                       env=dict(os.environ, **env), timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -70,13 +70,15 @@ def _worker(rank, world, port, alg, q):
         q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize("alg", ["odir", "odir_eager", "omin", "fused", "dodir"])
-def test_two_ranks_one_gpu_match_oracle(alg):
+@pytest.mark.parametrize("alg,world", [("odir", 2), ("odir_eager", 2), ("omin", 2), ("fused", 2), ("dodir", 2),
+                                       ("odir", 4), ("fused", 4)])
+def test_two_ranks_one_gpu_match_oracle(alg, world):
+    """(world = 4: every rank has more than one neighbour in the halo exchange)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, alg, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, alg, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
