@@ -1515,15 +1515,34 @@ __device__ __forceinline__ void bj_chunk_fast(double (&acc)[R][TS], const double
   }
 }
 
+// The chunks of a sweep go through a ring of `nbuf` LDS buffers (`lstride` doubles apart).  Two
+// buffers: chunk c+1 is in flight while chunk c is consumed, and c has landed once every
+// outstanding VMEM operation of the wave is done.  Three buffers (narrow bands): c+1 AND c+2 are in
+// flight -- at 5 TB/s the loaded memory latency is longer than the 8 steps a chunk lasts, so one
+// chunk of look-ahead left the wave waiting -- and c has landed once at most the `nld` load
+// instructions of chunk c+1 are outstanding (loads return in order; younger ones only make the
+// wait stricter).
+__device__ __forceinline__ void bj_wait_chunk(int nld_allowed) {
+  switch (nld_allowed) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
 template <int TS, int R, int CH, int K>
 __device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chunk, int b, int w, int wr,
-                                         const double* __restrict__ rec, double* lds0, double* lds1,
-                                         int lane) {
+                                         const double* __restrict__ rec, double* lds0, int lstride, int nbuf,
+                                         int nld, int lane) {
   for (int lc = 0; lc < lim; lc += CH, ++chunk) {
-    // chunk `chunk` has landed once every outstanding VMEM op of this wave is done
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const double* cur = (chunk & 1) ? lds1 : lds0;
-    if ((chunk + 1) * CH < b) bj_issue_chunk<CH>(rec, wr, chunk + 1, (chunk & 1) ? lds0 : lds1, lane);
+    bj_wait_chunk((nbuf == 3 && (chunk + 1) * CH < b) ? nld : 0);
+    const double* cur = lds0 + (size_t)(chunk % nbuf) * lstride;
+    {
+      const int ahead = chunk + nbuf - 1;
+      if (ahead * CH < b) bj_issue_chunk<CH>(rec, wr, ahead, lds0 + (size_t)(ahead % nbuf) * lstride, lane);
+    }
     const int send = (lim - lc) < CH ? (lim - lc) : CH;
     if constexpr (R <= 3 && TS <= 4) {   // (no gain measured at 8 columns; 16 would spill)
       if (send == CH) {
@@ -1563,7 +1582,7 @@ __device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R],
                                           const double* __restrict__ invd,
                                           const int* __restrict__ iomap, size_t rowbase,
                                           const double* __restrict__ src, double* __restrict__ dst,
-                                          double* lds0, double* lds1, int lane) {
+                                          double* lds0, int lstride, int nbuf, int nld, int lane) {
   if constexpr (K < R) {
     constexpr int W = 64 * R;
     const int j0 = jb + K * 64;
@@ -1578,7 +1597,7 @@ __device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R],
 #pragma unroll
         for (int c = 0; c < TS; ++c) nxt[c] = 0.0;
       const int lim = (b - j0) < 64 ? (b - j0) : 64;
-      bj_block<TS, R, CH, K>(acc, lim, chunk, b, w, wr, rec, lds0, lds1, lane);
+      bj_block<TS, R, CH, K>(acc, lim, chunk, b, w, wr, rec, lds0, lstride, nbuf, nld, lane);
       if (lane < lim) {
         double y[TS];
 #pragma unroll
@@ -1590,7 +1609,7 @@ __device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R],
       rowid[K] = nrow;
     }
     bj_blocks<TS, R, CH, K + 1, XS>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0,
-                                lds1, lane);
+                                lstride, nbuf, nld, lane);
   }
 }
 
@@ -1599,7 +1618,7 @@ __device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __r
                                          const double* __restrict__ invd,
                                          const int* __restrict__ iomap, size_t rowbase,
                                          const double* __restrict__ src, double* __restrict__ dst,
-                                         double* lds0, double* lds1, int lane) {
+                                         double* lds0, int lstride, int nbuf, int nld, int lane) {
   constexpr int W = 64 * R;
   double acc[R][TS];
   int rowid[R];
@@ -1613,10 +1632,11 @@ __device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __r
       for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
   }
   bj_issue_chunk<CH>(rec, wr, 0, lds0, lane);
+  if (nbuf == 3 && CH < b) bj_issue_chunk<CH>(rec, wr, 1, lds0 + lstride, lane);
   int chunk = 0;
   for (int jb = 0; jb < b; jb += W)
-    bj_blocks<TS, R, CH, 0, XS>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lds1,
-                            lane);
+    bj_blocks<TS, R, CH, 0, XS>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lstride,
+                            nbuf, nld, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -1632,7 +1652,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_apply(
     const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off,
     const int* __restrict__ map_f, const int* __restrict__ map_b, const double* __restrict__ Lf,
     const double* __restrict__ Lb, const double* __restrict__ invd_f,
-    const double* __restrict__ invd_b, int lds_per_wave, const double* __restrict__ in,
+    const double* __restrict__ invd_b, int lds_per_wave, int nbuf, const double* __restrict__ in,
     double* __restrict__ out) {
   extern __shared__ double smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1651,11 +1671,13 @@ __global__ __launch_bounds__(256, OCC) void k_bj_apply(
   const size_t o = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(o64 >> 32)) << 32) |
                    (unsigned)__builtin_amdgcn_readfirstlane((int)o64);
   double* lds0 = smem + (size_t)wave * lds_per_wave;
-  double* lds1 = lds0 + (lds_per_wave >> 1);
+  const int lstride = lds_per_wave / nbuf;
+  const int nld = (CH * wr * 8 + 1023) >> 10;      // load instructions per chunk of THIS block
+  const int nb = nld <= 4 ? nbuf : 2;               // (the counted wait knows 1..4)
   // forward: L y = x (y goes to `out`), backward: L^T z = y in place
-  bj_sweep<TS, R, CH, XS>(b, w, wr, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in + coff, out + coff, lds0, lds1, lane);
+  bj_sweep<TS, R, CH, XS>(b, w, wr, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in + coff, out + coff, lds0, lstride, nb, nld, lane);
   __threadfence_block();
-  bj_sweep<TS, R, CH, XS>(b, w, wr, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out + coff, out + coff, lds0, lds1, lane);
+  bj_sweep<TS, R, CH, XS>(b, w, wr, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out + coff, out + coff, lds0, lstride, nb, nld, lane);
 }
 
 // Wide bands (RCM bandwidth > 448: few, large subdomains).  One workgroup of up to 16
@@ -2581,7 +2603,15 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
                         const double* in, double* out) {
   // LDS per wave: two chunk buffers of CH records of the widest band in this class
   const int wr = (wmax + 2) & ~1;
-  int per_wave = 2 * ((CH * wr + 127) & ~127);  // doubles, each buffer a multiple of 1 KiB
+  // PREALPS_BJ_RING=1: a ring of three buffers for narrow bands (two chunks in flight, counted
+  // waits).  Measured neutral (183.6 vs 187.1 us on elasticity, 173.6 vs 172.1 on Poisson, same box):
+  // the sweep does not wait for its band -- the counters show the VALU busy 62 % of the time and the
+  // waves waiting on LDS reads and lane moves, not on VMEM -- so two buffers stay the default.
+  static int ring = -1;
+  if (ring < 0) { const char* e = getenv("PREALPS_BJ_RING"); ring = e ? atoi(e) : 0; }
+  const int cbuf = (CH * wr + 127) & ~127;      // doubles, each buffer a multiple of 1 KiB
+  const int nbuf = (ring && (CH * wr * 8 + 1023) / 1024 <= 4 && 3 * cbuf * 8 * 16 <= 160 * 1024) ? 3 : 2;
+  int per_wave = nbuf * cbuf;
   int waves = (160 * 1024) / (per_wave * 8);
   if (waves > 4) waves = 4;
   if (waves < 1) { snprintf(g_kerr, sizeof(g_kerr), "block-Jacobi band too wide for LDS (R=%d)", R); return 1; }
@@ -2599,7 +2629,7 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
     }                                                                                             \
     hipLaunchKernelGGL((k_bj_apply<TS, RR, CH, XS, 1>), dim3(blocks), dim3(64 * waves), lds,          \
                        cur_stream(), list, count, pl->row0, pl->nrows, pl->bw, pl->off,           \
-                       pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, per_wave, in, out); \
+                       pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, per_wave, nbuf, in, out); \
   } break;
   // narrow bands at up to 4 columns: variants that leave room for 5 / 6 wavefronts per SIMD
   if constexpr (TS <= 4 && XS == TS) {
@@ -2609,11 +2639,11 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
       if (occ == 5)
         hipLaunchKernelGGL((k_bj_apply<TS, 2, CH, XS, 5>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
                            pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
-                           pl->invd_b, per_wave, in, out);
+                           pl->invd_b, per_wave, nbuf, in, out);
       else
         hipLaunchKernelGGL((k_bj_apply<TS, 2, CH, XS, 6>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
                            pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
-                           pl->invd_b, per_wave, in, out);
+                           pl->invd_b, per_wave, nbuf, in, out);
       return kfail("k_bj_apply");
     }
   }
