@@ -461,7 +461,13 @@ static int join_fragments(const graph_t* g, int k, int* part, long long limit) {
     if (w > best_w[p]) { best_w[p] = w; best_c[p] = nc; }
     ++nc;
   }
-  /* fragments: collect their vertices again and vote */
+  /* fragments: collect their vertices again and vote; a part takes fragments only up to 1.25 times the
+   * average weight (a star-shaped graph -- one dense row -- is all fragments around its centre) */
+  long long* pw = (long long*)calloc((size_t)k, sizeof(long long));
+  long long wtot = 0;
+  if (!pw) { free(comp); free(stack); free(best_w); free(best_c); free(cw); return 1; }
+  for (int v = 0; v < n; ++v) { pw[part[v]] += g->vw[v]; wtot += g->vw[v]; }
+  const long long wcap = wtot / k + wtot / (4 * (long long)k) + 1;
   int cp[64]; long long cc[64];
   for (int v0 = 0; v0 < n; ++v0) {
     int c = comp[v0], p = part[v0];
@@ -483,10 +489,13 @@ static int join_fragments(const graph_t* g, int k, int* part, long long limit) {
       if (top + cnt >= n) break;                       /* (cannot happen: a fragment is not the whole graph) */
     }
     if (ncand == 0) continue;                          /* an isolated piece of the graph: stays */
-    int bi = 0;
-    for (int i = 1; i < ncand; ++i) if (cc[i] > cc[bi]) bi = i;
+    int bi = -1;
+    for (int i = 0; i < ncand; ++i) if (pw[cp[i]] + cw[c] <= wcap && (bi < 0 || cc[i] > cc[bi])) bi = i;
+    if (bi < 0) continue;                              /* every neighbour is full: the fragment stays */
     for (int i = 0; i < cnt; ++i) part[stack[n - 1 - i]] = cp[bi];
+    pw[cp[bi]] += cw[c]; pw[p] -= cw[c];
   }
+  free(pw);
   free(comp); free(stack); free(best_w); free(best_c); free(cw);
   return 0;
 }

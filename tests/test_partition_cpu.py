@@ -85,6 +85,17 @@ def test_more_components_than_parts_and_tiny_graphs():
     part = partition_kway(A.indptr, A.indices, 4)
     sizes = np.bincount(part, minlength=4)
     assert sizes.min() > 0 and sizes.sum() == 300
+    # a star (one dense row and column): every vertex but the centre is a fragment of its part
+    n = 2000
+    rows = np.concatenate([np.arange(n), np.zeros(n - 1, int), np.arange(1, n)])
+    cols = np.concatenate([np.arange(n), np.arange(1, n), np.zeros(n - 1, int)])
+    S = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+    S.sort_indices()
+    sizes = np.bincount(partition_kway(S.indptr, S.indices, 16), minlength=16)
+    assert sizes.min() >= 0.7 * n / 16 and sizes.max() <= 1.3 * n / 16
+    # no edges at all
+    sizes = np.bincount(partition_kway(sp.identity(1000, format="csr").indptr, np.arange(1000, dtype=np.int32), 10))
+    assert sizes.min() == sizes.max() == 100
     # the reference's own 14 x 14 fixture, 2 parts
     from oracle import oracle as O
     L = O.load_mtx(os.path.join(ROOT, "tests", "golden", "LFAT5.mtx"))
