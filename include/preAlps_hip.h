@@ -80,8 +80,10 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd,
 int preAlps_hip_partition_kway(int N, const int* rowPtr, const int* colInd, int nparts, int* part);
 /* Host-side self check of the sparse factorisation that large diagonal blocks get (nested
  * dissection + multifrontal Cholesky, nd.c), on one SPD matrix taken as a single block; no GPU
- * needed.  stats[0..5] = supernodes, doubles of one panel copy, rows of the largest front, tree
- * height, ||L L^T x - A x|| / ||A x||, largest relative mismatch between the two panel copies. */
+ * needed.  stats[0..7] = supernodes, doubles of one panel copy, rows of the largest front, tree
+ * height, ||L L^T x - A x|| / ||A x||, largest relative mismatch between the two panel copies,
+ * largest entry of T (I + Lhat) - I over the explicit inverses of the pivot triangles, number of
+ * fronts handled as split fronts (triangle and rows below on separate grids). */
 int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const double* val, int leaf_rows,
                              double* stats);
 /* Cut the SpMM plan (slices, LDS staging lists) for this enlarging factor now rather than

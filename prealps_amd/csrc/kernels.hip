@@ -2260,141 +2260,6 @@ __global__ __launch_bounds__(NT) void k_nd_forward(nd_args a, const int* __restr
   }
 }
 
-// The rectangular part of a large front on its own grid: ND_CHUNK rows below per workgroup, so
-// that the upper levels of the tree -- 64..256 fronts of 1000..2000 rows -- fill the chip instead
-// of one CU each.  Forward: contribution(r) = children's contributions - sum_j Lhat(r, j) a_j with
-// a_j = y_j L_jj (the unscaled pivot values; y was written by the triangular kernel of the level).
-template <int TS, int XS>
-__global__ __launch_bounds__(ND_CHUNK) void k_nd_rect_fwd(nd_args a, const int* __restrict__ cfront,
-                                                          const int* __restrict__ crow0,
-                                                          const double* __restrict__ out) {
-  __shared__ double ys[64][TS];
-  const int s = cfront[blockIdx.x], r0 = crow0[blockIdx.x], coff = blockIdx.y * TS;
-  const int n = a.n[s], m = a.m[s], ld = a.ld[s];
-  const double* __restrict__ L = a.F + a.offF[s];
-  const int* __restrict__ rows = a.rows + a.rows_off[s];
-  const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
-  const int tid = threadIdx.x;
-  const int rr = r0 + tid;                    // row below, 0-based
-  const bool on = rr < m;
-  const int r = n + (on ? rr : 0);            // front row
-  double acc[TS];
-#pragma unroll
-  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-  if (on) {
-    const int s0 = src[2 * r], s1 = src[2 * r + 1];
-    double t[TS];
-    if (s0 >= 0) {
-      load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s] + s0), t);
-#pragma unroll
-      for (int c = 0; c < TS; ++c) acc[c] += t[c];
-    }
-    if (s1 >= 0) {
-      load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s + 1] + s1), t);
-#pragma unroll
-      for (int c = 0; c < TS; ++c) acc[c] += t[c];
-    }
-  }
-  for (int jb = 0; jb < n; jb += 64) {
-    const int nb = min(64, n - jb);
-    if (tid < 64) {
-      double y[TS];
-#pragma unroll
-      for (int c = 0; c < TS; ++c) y[c] = 0.0;
-      if (tid < nb) {
-        const int g = rows[jb + tid];
-        load_row_s<TS, XS>(out + coff, (size_t)g, y);
-        const double ljj = 1.0 / a.dinv[g];
-#pragma unroll
-        for (int c = 0; c < TS; ++c) y[c] *= ljj;
-      }
-      double2* q = reinterpret_cast<double2*>(ys[tid]);
-#pragma unroll
-      for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(y[2 * c], y[2 * c + 1]);
-    }
-    __syncthreads();
-    if (on) {
-      const double* __restrict__ p = L + (size_t)jb * ld + r;
-      double cf[16], nx[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) cf[u] = u < nb ? p[(size_t)u * ld] : 0.0;
-#pragma unroll 1
-      for (int j0 = 0; j0 < nb; j0 += 16) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) nx[u] = j0 + 16 + u < nb ? p[(size_t)(j0 + 16 + u) * ld] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const double2* yq = reinterpret_cast<const double2*>(ys[min(j0 + u, 63)]);
-#pragma unroll
-          for (int c = 0; c < TS / 2; ++c) {
-            const double2 yv = yq[c];
-            acc[2 * c] = fma(-cf[u], yv.x, acc[2 * c]);
-            acc[2 * c + 1] = fma(-cf[u], yv.y, acc[2 * c + 1]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) cf[u] = nx[u];
-      }
-    }
-    __syncthreads();
-  }
-  if (on) store_row_s<TS, XS>(a.contrib + coff, (size_t)(a.coff[s] + rr), acc);
-}
-
-// Backward: partial(chunk, k) = sum over the chunk's rows i of L(i, k) z_i for 256 columns k per
-// workgroup (blockIdx.y); the triangular kernel of the level subtracts the chunks in order.
-template <int TS, int XS>
-__global__ __launch_bounds__(ND_CHUNK) void k_nd_rect_bwd(nd_args a, const int* __restrict__ cfront,
-                                                          const int* __restrict__ crow0,
-                                                          const double* __restrict__ out, int ncg) {
-  __shared__ double zs[ND_CHUNK][TS];
-  const int s = cfront[blockIdx.x], r0 = crow0[blockIdx.x];
-  const int kb = blockIdx.y / ncg, coff = (blockIdx.y % ncg) * TS;
-  const int n = a.n[s], m = a.m[s], ldb = (n + 1) & ~1;
-  if (kb * ND_CHUNK >= n) return;             // (uniform: this front has fewer columns than the widest of the launch)
-  const double* __restrict__ U = a.B + a.offB[s];
-  const int* __restrict__ rows = a.rows + a.rows_off[s];
-  const int tid = threadIdx.x;
-  const int nr = min(ND_CHUNK, m - r0);
-  {
-    double z[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) z[c] = 0.0;
-    if (tid < nr) load_row_s<TS, XS>(out + coff, (size_t)rows[n + r0 + tid], z);
-    double2* q = reinterpret_cast<double2*>(zs[tid]);
-#pragma unroll
-    for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(z[2 * c], z[2 * c + 1]);
-  }
-  __syncthreads();
-  const int k = kb * ND_CHUNK + tid;
-  if (k >= n) return;
-  double acc[TS];
-#pragma unroll
-  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-  const double* __restrict__ p = U + (size_t)(n + r0) * ldb + k;
-  double cf[16], nx[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) cf[u] = u < nr ? p[(size_t)u * ldb] : 0.0;
-#pragma unroll 1
-  for (int i0 = 0; i0 < nr; i0 += 16) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) nx[u] = i0 + 16 + u < nr ? p[(size_t)(i0 + 16 + u) * ldb] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const double2* zq = reinterpret_cast<const double2*>(zs[min(i0 + u, ND_CHUNK - 1)]);
-#pragma unroll
-      for (int c = 0; c < TS / 2; ++c) {
-        const double2 zv = zq[c];
-        acc[2 * c] = fma(cf[u], zv.x, acc[2 * c]);
-        acc[2 * c + 1] = fma(cf[u], zv.y, acc[2 * c + 1]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) cf[u] = nx[u];
-  }
-  store_row_s<TS, XS>(a.partial + coff, (size_t)(a.poff[s] + (long long)(r0 / ND_CHUNK) * n + k), acc);
-}
-
 // Backward: L^T z = y on the n columns, the m rows below are ancestors whose z is final.
 // b_k = L_kk z_k is carried unscaled; the row-major copy holds L(i,k) for the rows below and
 // L(i,k) / L(i,i) for the pivot rows.
@@ -2522,6 +2387,310 @@ __global__ __launch_bounds__(NT) void k_nd_backward(nd_args a, const int* __rest
       for (int c = 0; c < TS; ++c) z[c] = acc[k][c] * id;
       store_row_s<TS, XS>(out + coff, (size_t)grow[k], z);
     }
+  }
+}
+
+// Dot products of the split-front kernels.  A thread adds coefficient(j) * ys[j] over the 16-wide
+// groups g = g0 + q, g0 + q + Q, ... < g1 of an index range (j = 16 g + u, kept to lo <= j < hi);
+// consecutive j are `stride` doubles apart at p.  Q threads share one output and are added up
+// through LDS afterwards.  The first group is requested by nd_dot_first (before the barrier that
+// publishes ys), every other group one round ahead of its use.
+__device__ __forceinline__ void nd_dot_load(double (&cf)[16], const double* __restrict__ p, size_t stride, int g, int g1,
+                                            int lo, int hi, bool on) {
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int j = 16 * g + u;
+    cf[u] = (on && g < g1 && j >= lo && j < hi) ? p[(size_t)j * stride] : 0.0;
+  }
+}
+
+template <int TS, int Q, int YN>
+__device__ __forceinline__ void nd_dot(double (&acc)[TS], double (&cf)[16], const double* __restrict__ p, size_t stride,
+                                       int g, int g1, int lo, int hi, bool on, const double (*ys)[TS]) {
+  double nx[16];
+#pragma unroll 1
+  for (; g < g1; g += Q) {
+    nd_dot_load(nx, p, stride, g + Q, g1, lo, hi, on);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const double2* yq = reinterpret_cast<const double2*>(ys[min(16 * g + u, YN - 1)]);
+#pragma unroll
+      for (int c = 0; c < TS / 2; ++c) {
+        const double2 yv = yq[c];
+        acc[2 * c] = fma(cf[u], yv.x, acc[2 * c]);
+        acc[2 * c + 1] = fma(cf[u], yv.y, acc[2 * c + 1]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) cf[u] = nx[u];
+  }
+}
+
+// The triangular part of a split front as a product with the explicit inverse (nd.c, nd_invert_tri):
+// no recurrence, no step-by-step barriers -- the n <= R pivot rows are staged in LDS once, Q threads
+// share a row (16-column groups dealt round robin) and their sums meet in LDS.  R * Q threads keep
+// 16 coefficients in flight each, requested before the staging barrier, so one CU pulls the
+// triangle in a few microseconds (the recurrence this replaces took 15 us per 64 pivots).
+constexpr int ND_TRI = 256;
+
+// Forward: w = x(columns) + the children's contributions; a = T w; y = a / L_jj leaves in `out`
+// (k_nd_rect_fwd of the same level reads it there).
+template <int TS, int XS, int R, int Q>
+__global__ __launch_bounds__(R * Q) void k_nd_tri_fwd(nd_args a, const int* __restrict__ list,
+                                                      const double* __restrict__ in, double* __restrict__ out) {
+  __shared__ double ws[R][TS];
+  __shared__ double red[Q - 1][R][TS];
+  const int s = list[blockIdx.x], coff = blockIdx.y * TS;
+  const int n = a.n[s], ld = a.ld[s];
+  const double* __restrict__ T = a.F + a.offF[s];
+  const int tid = threadIdx.x, r = tid % R, q = tid / R;
+  const bool on = r < n;
+  const int g1 = (r + 15) >> 4;                              // columns 0 .. r - 1
+  const double* __restrict__ p = T + r;
+  double cf[16];
+  nd_dot_load(cf, p, (size_t)ld, q, g1, 0, r, on);
+  double w[TS];
+  int grow = -1;
+  double id = 0.0;
+#pragma unroll
+  for (int c = 0; c < TS; ++c) w[c] = 0.0;
+  if (q == 0) {
+    if (on) {
+      const int* __restrict__ rows = a.rows + a.rows_off[s];
+      const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
+      grow = rows[r];
+      const int s0 = src[2 * r], s1 = src[2 * r + 1];
+      load_row_s<TS, XS>(in + coff, (size_t)grow, w);
+      id = a.dinv[grow];
+      double t[TS];
+      if (s0 >= 0) {
+        load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s] + s0), t);
+#pragma unroll
+        for (int c = 0; c < TS; ++c) w[c] += t[c];
+      }
+      if (s1 >= 0) {
+        load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s + 1] + s1), t);
+#pragma unroll
+        for (int c = 0; c < TS; ++c) w[c] += t[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < TS; ++c) ws[r][c] = w[c];           // (rows >= n: zeros, met by zero coefficients only)
+  }
+  __syncthreads();
+  double acc[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+  nd_dot<TS, Q, R>(acc, cf, p, (size_t)ld, q, g1, 0, r, on, ws);
+  if (q > 0) {
+#pragma unroll
+    for (int c = 0; c < TS; ++c) red[q - 1][r][c] = acc[c];
+  }
+  __syncthreads();
+  if (q == 0 && on) {
+    double y[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      double sm = w[c] + acc[c];
+#pragma unroll
+      for (int k = 0; k < Q - 1; ++k) sm += red[k][r][c];
+      y[c] = sm * id;
+    }
+    store_row_s<TS, XS>(out + coff, (size_t)grow, y);
+  }
+}
+
+// Backward: rhs = y(columns) - the partial sums k_nd_rect_bwd left for the rows below (fixed order);
+// u = rhs / L_kk; z = T^T u.
+template <int TS, int XS, int R, int Q>
+__global__ __launch_bounds__(R * Q) void k_nd_tri_bwd(nd_args a, const int* __restrict__ list, double* __restrict__ out) {
+  __shared__ double us[R][TS];
+  __shared__ double red[Q - 1][R][TS];
+  const int s = list[blockIdx.x], coff = blockIdx.y * TS;
+  const int n = a.n[s], mrows = a.m[s], ldb = (n + 1) & ~1;
+  const double* __restrict__ U = a.B + a.offB[s];
+  const int tid = threadIdx.x, k = tid % R, q = tid / R;
+  const bool on = k < n;
+  const int g0 = (k + 1) >> 4, g1 = (n + 15) >> 4;           // rows k + 1 .. n - 1
+  const double* __restrict__ p = U + k;
+  double cf[16];
+  nd_dot_load(cf, p, (size_t)ldb, g0 + q, g1, k + 1, n, on);
+  double uk[TS];
+  int grow = -1;
+#pragma unroll
+  for (int c = 0; c < TS; ++c) uk[c] = 0.0;
+  if (q == 0) {
+    if (on) {
+      grow = (a.rows + a.rows_off[s])[k];
+      load_row_s<TS, XS>(out + coff, (size_t)grow, uk);
+      const double id = a.dinv[grow];
+      const int nch = (mrows + ND_CHUNK - 1) / ND_CHUNK;
+      const long long p0 = a.poff[s];
+#pragma unroll 4
+      for (int ch = 0; ch < nch; ++ch) {
+        double t[TS];
+        load_row_s<TS, XS>(a.partial + coff, (size_t)(p0 + (long long)ch * n + k), t);
+#pragma unroll
+        for (int c = 0; c < TS; ++c) uk[c] -= t[c];
+      }
+#pragma unroll
+      for (int c = 0; c < TS; ++c) uk[c] *= id;
+    }
+#pragma unroll
+    for (int c = 0; c < TS; ++c) us[k][c] = uk[c];
+  }
+  __syncthreads();
+  double acc[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+  nd_dot<TS, Q, R>(acc, cf, p, (size_t)ldb, g0 + q, g1, k + 1, n, on, us);
+  if (q > 0) {
+#pragma unroll
+    for (int c = 0; c < TS; ++c) red[q - 1][k][c] = acc[c];
+  }
+  __syncthreads();
+  if (q == 0 && on) {
+    double z[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      double sm = uk[c] + acc[c];
+#pragma unroll
+      for (int j = 0; j < Q - 1; ++j) sm += red[j][k][c];
+      z[c] = sm;
+    }
+    store_row_s<TS, XS>(out + coff, (size_t)grow, z);
+  }
+}
+
+// The rectangular part of a split front on its own grid: ND_CHUNK rows below per workgroup, so
+// that the upper levels of the tree -- 64..256 fronts of 1000..2000 rows -- fill the chip instead
+// of one CU each; Q threads share a row (launches of few chunks: a workgroup is then alone on its
+// CU and needs the loads of 1024 threads in flight).  Forward: contribution(r) = children's
+// contributions - sum_j Lhat(r, j) a_j with a_j = y_j L_jj (the unscaled pivot values; y was
+// written by the triangular kernel of the level).
+template <int TS, int XS, int Q>
+__global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_rect_fwd(nd_args a, const int* __restrict__ cfront,
+                                                              const int* __restrict__ crow0,
+                                                              const double* __restrict__ out) {
+  __shared__ double ys[ND_TRI][TS];
+  __shared__ double red[Q > 1 ? Q - 1 : 1][ND_CHUNK][TS];
+  const int s = cfront[blockIdx.x], r0 = crow0[blockIdx.x], coff = blockIdx.y * TS;
+  const int n = a.n[s], m = a.m[s], ld = a.ld[s];
+  const double* __restrict__ L = a.F + a.offF[s];
+  const int* __restrict__ rows = a.rows + a.rows_off[s];
+  const int tid = threadIdx.x, rl = tid % ND_CHUNK, q = tid / ND_CHUNK;
+  const int rr = r0 + rl;                     // row below, 0-based
+  const bool on = rr < m;
+  const int r = n + (on ? rr : 0);            // front row
+  const int g1 = (n + 15) >> 4;
+  const double* __restrict__ p = L + r;
+  double cf[16];
+  nd_dot_load(cf, p, (size_t)ld, q, g1, 0, n, on);
+  if (tid < ND_TRI) {
+    double y[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) y[c] = 0.0;
+    if (tid < n) {
+      const int g = rows[tid];
+      load_row_s<TS, XS>(out + coff, (size_t)g, y);
+      const double ljj = 1.0 / a.dinv[g];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) y[c] *= ljj;
+    }
+    double2* yq = reinterpret_cast<double2*>(ys[tid]);
+#pragma unroll
+    for (int c = 0; c < TS / 2; ++c) yq[c] = make_double2(y[2 * c], y[2 * c + 1]);
+  }
+  double acc[TS], part[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) { acc[c] = 0.0; part[c] = 0.0; }
+  if (on && q == 0) {
+    const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
+    const int s0 = src[2 * r], s1 = src[2 * r + 1];
+    double t[TS];
+    if (s0 >= 0) {
+      load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s] + s0), t);
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[c] += t[c];
+    }
+    if (s1 >= 0) {
+      load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s + 1] + s1), t);
+#pragma unroll
+      for (int c = 0; c < TS; ++c) acc[c] += t[c];
+    }
+  }
+  __syncthreads();
+  nd_dot<TS, Q, ND_TRI>(part, cf, p, (size_t)ld, q, g1, 0, n, on, ys);
+  if constexpr (Q > 1) {
+    if (q > 0) {
+#pragma unroll
+      for (int c = 0; c < TS; ++c) red[q - 1][rl][c] = part[c];
+    }
+    __syncthreads();
+  }
+  if (on && q == 0) {
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      double sm = part[c];
+      if constexpr (Q > 1) {
+#pragma unroll
+        for (int k = 0; k < Q - 1; ++k) sm += red[k][rl][c];
+      }
+      acc[c] -= sm;
+    }
+    store_row_s<TS, XS>(a.contrib + coff, (size_t)(a.coff[s] + rr), acc);
+  }
+}
+
+// Backward: partial(chunk, k) = sum over the chunk's rows i of L(i, k) z_i for the n <= 256 columns k;
+// the triangular kernel of the level subtracts the chunks in order.
+template <int TS, int XS, int Q>
+__global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_rect_bwd(nd_args a, const int* __restrict__ cfront,
+                                                              const int* __restrict__ crow0,
+                                                              const double* __restrict__ out) {
+  __shared__ double zs[ND_CHUNK][TS];
+  __shared__ double red[Q > 1 ? Q - 1 : 1][ND_CHUNK][TS];
+  const int s = cfront[blockIdx.x], r0 = crow0[blockIdx.x], coff = blockIdx.y * TS;
+  const int n = a.n[s], m = a.m[s], ldb = (n + 1) & ~1;
+  const double* __restrict__ U = a.B + a.offB[s];
+  const int* __restrict__ rows = a.rows + a.rows_off[s];
+  const int tid = threadIdx.x, k = tid % ND_CHUNK, q = tid / ND_CHUNK;
+  const int nr = min(ND_CHUNK, m - r0);
+  const bool on = k < n;
+  const int g1 = (nr + 15) >> 4;
+  const double* __restrict__ p = U + (size_t)(n + r0) * ldb + k;
+  double cf[16];
+  nd_dot_load(cf, p, (size_t)ldb, q, g1, 0, nr, on);
+  if (tid < ND_CHUNK) {
+    double z[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) z[c] = 0.0;
+    if (tid < nr) load_row_s<TS, XS>(out + coff, (size_t)rows[n + r0 + tid], z);
+    double2* zq = reinterpret_cast<double2*>(zs[tid]);
+#pragma unroll
+    for (int c = 0; c < TS / 2; ++c) zq[c] = make_double2(z[2 * c], z[2 * c + 1]);
+  }
+  __syncthreads();
+  double acc[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+  nd_dot<TS, Q, ND_CHUNK>(acc, cf, p, (size_t)ldb, q, g1, 0, nr, on, zs);
+  if constexpr (Q > 1) {
+    if (q > 0) {
+#pragma unroll
+      for (int c = 0; c < TS; ++c) red[q - 1][k][c] = acc[c];
+    }
+    __syncthreads();
+  }
+  if (on && q == 0) {
+    if constexpr (Q > 1) {
+#pragma unroll
+      for (int c = 0; c < TS; ++c) {
+#pragma unroll
+        for (int j = 0; j < Q - 1; ++j) acc[c] += red[j][k][c];
+      }
+    }
+    store_row_s<TS, XS>(a.partial + coff, (size_t)(a.poff[s] + (long long)(r0 / ND_CHUNK) * n + k), acc);
   }
 }
 
@@ -2792,20 +2961,39 @@ static int nd_launch(const nd_args& a, int cls, const int* list, int count, int 
   return 1;
 }
 
+// the triangular parts of the split fronts of one level
+template <int XS>
+static int nd_launch_tri(const nd_args& a, const int* list, int count, int nmax, bool fwd, const double* in, double* out) {
+  constexpr int TS = XS <= 4 ? XS : 4;
+  const dim3 grid(count, XS / TS);
+  if (nmax <= 128) {      // (the many small fronts just above the leaves)
+    if (fwd) hipLaunchKernelGGL((k_nd_tri_fwd<TS, XS, 128, 4>), grid, dim3(512), 0, cur_stream(), a, list, in, out);
+    else hipLaunchKernelGGL((k_nd_tri_bwd<TS, XS, 128, 4>), grid, dim3(512), 0, cur_stream(), a, list, out);
+  } else {
+    if (fwd) hipLaunchKernelGGL((k_nd_tri_fwd<TS, XS, ND_TRI, 4>), grid, dim3(1024), 0, cur_stream(), a, list, in, out);
+    else hipLaunchKernelGGL((k_nd_tri_bwd<TS, XS, ND_TRI, 4>), grid, dim3(1024), 0, cur_stream(), a, list, out);
+  }
+  return kfail(fwd ? "k_nd_tri_fwd" : "k_nd_tri_bwd");
+}
+
 // the rows below of the split fronts of one launch: `nchunk` (front, first row) pairs
 template <int XS>
-static int nd_launch_rect(const nd_args& a, const int* cfront, const int* crow0, int nchunk, int nmax, bool fwd,
-                          const double* out) {
+static int nd_launch_rect(const nd_args& a, const int* cfront, const int* crow0, int nchunk, bool fwd, const double* out) {
   if (nchunk <= 0) return 0;
-  constexpr int TS = XS <= 8 ? XS : 8;        // 16-column panels in two column groups (LDS, registers)
-  constexpr int ncg = XS / TS;
-  if (fwd) {
-    hipLaunchKernelGGL((k_nd_rect_fwd<TS, XS>), dim3(nchunk, ncg), dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, out);
-    return kfail("k_nd_rect_fwd");
+  static int few = -1;          // launches of fewer chunks than this put four threads on a row
+  if (few < 0) { const char* e = getenv("PREALPS_ND_RECT_FEW"); few = e ? atoi(e) : 1024; }
+  if (nchunk < few) {
+    constexpr int TS = XS <= 4 ? XS : 4;
+    const dim3 grid(nchunk, XS / TS);
+    if (fwd) hipLaunchKernelGGL((k_nd_rect_fwd<TS, XS, 4>), grid, dim3(ND_CHUNK * 4), 0, cur_stream(), a, cfront, crow0, out);
+    else hipLaunchKernelGGL((k_nd_rect_bwd<TS, XS, 4>), grid, dim3(ND_CHUNK * 4), 0, cur_stream(), a, cfront, crow0, out);
+  } else {
+    constexpr int TS = XS <= 8 ? XS : 8;        // 16-column panels in two column groups (LDS, registers)
+    const dim3 grid(nchunk, XS / TS);
+    if (fwd) hipLaunchKernelGGL((k_nd_rect_fwd<TS, XS, 1>), grid, dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, out);
+    else hipLaunchKernelGGL((k_nd_rect_bwd<TS, XS, 1>), grid, dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, out);
   }
-  const int nkb = (nmax + ND_CHUNK - 1) / ND_CHUNK;
-  hipLaunchKernelGGL((k_nd_rect_bwd<TS, XS>), dim3(nchunk, nkb * ncg), dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, out, ncg);
-  return kfail("k_nd_rect_bwd");
+  return kfail(fwd ? "k_nd_rect_fwd" : "k_nd_rect_bwd");
 }
 
 extern "C" {
@@ -3069,6 +3257,7 @@ int pa_nd_class_of(int front_rows) {
 
 // launches are listed bottom-up (height, then class): forward in that order, backward reversed
 int pa_nd_chunk_rows(void) { return ND_CHUNK; }
+int pa_nd_tri_cols(void) { return ND_TRI; }
 
 int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out) {
   nd_args a{pl->n, pl->m, pl->ld, pl->offF, pl->offB, pl->rows_off, pl->coff, pl->ccoff, pl->rows, pl->src,
@@ -3080,11 +3269,12 @@ int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out)
       const int split = pl->l_split[i];
       int rc = 0;
       // forward: pivots first, then the rows below; backward: rows below first, then the pivots
-      if (split && !fwd) { TS_DISPATCH(ts, rc = nd_launch_rect<TS_>(a, pl->l_cfront[i], pl->l_crow0[i], pl->l_nchunk[i], pl->l_nmax[i], false, out)); }
+      if (split && !fwd) { TS_DISPATCH(ts, rc = nd_launch_rect<TS_>(a, pl->l_cfront[i], pl->l_crow0[i], pl->l_nchunk[i], false, out)); }
       if (rc) return rc;
-      TS_DISPATCH(ts, rc = nd_launch<TS_>(a, pl->l_class[i], pl->l_list[i], pl->l_count[i], split, fwd, in, out));
+      if (split) { TS_DISPATCH(ts, rc = nd_launch_tri<TS_>(a, pl->l_list[i], pl->l_count[i], pl->l_nmax[i], fwd, in, out)); }
+      else { TS_DISPATCH(ts, rc = nd_launch<TS_>(a, pl->l_class[i], pl->l_list[i], pl->l_count[i], 0, fwd, in, out)); }
       if (rc) return rc;
-      if (split && fwd) { TS_DISPATCH(ts, rc = nd_launch_rect<TS_>(a, pl->l_cfront[i], pl->l_crow0[i], pl->l_nchunk[i], pl->l_nmax[i], true, out)); }
+      if (split && fwd) { TS_DISPATCH(ts, rc = nd_launch_rect<TS_>(a, pl->l_cfront[i], pl->l_crow0[i], pl->l_nchunk[i], true, out)); }
       if (rc) return rc;
     }
   return 0;

@@ -115,7 +115,8 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
    * the whole sweep.  Same entries, same arithmetic. */
   {
     const char* we = getenv("PREALPS_ND_WIDTH");
-    const int width = we ? atoi(we) : 256;
+    int width = we ? atoi(we) : 256;
+    if (width > pa_nd_tri_cols()) width = pa_nd_tri_cols();      /* (what k_nd_tri_* takes) */
     const int n0 = B->tree.nsn;
     int extra_tot = 0;
     int* base = (int*)malloc(((size_t)n0 + 1) * sizeof(int));
@@ -265,10 +266,63 @@ static int front_factor(int f, int n, double* F) {
   return 0;
 }
 
+/* Which fronts the device handles in two grids (k_nd_tri_* for the n pivot rows, k_nd_rect_* for the
+ * m rows below): every front above PREALPS_ND_SPLIT rows (512), and every front with at least
+ * PREALPS_ND_TRI_COLS pivot columns (64) -- a workgroup that owns such a front alone walks a chain
+ * of 64-pivot steps, 15 us each.  Read once, before any thread asks. */
+static int g_split_rows = -1, g_split_cols = -1;
+static void nd_split_config(void) {
+  const char* se = getenv("PREALPS_ND_SPLIT");
+  const char* ce = getenv("PREALPS_ND_TRI_COLS");
+  g_split_rows = se ? atoi(se) : 512;
+  g_split_cols = ce ? atoi(ce) : 64;
+}
+static int nd_is_split(int n, int m) {
+  if (g_split_rows <= 0 || n > pa_nd_tri_cols()) return 0;
+  return n + m > g_split_rows || (g_split_cols > 0 && n >= g_split_cols);
+}
+
+/* The triangular part of a split front is applied as a product, not as a recurrence: the strictly
+ * lower entries of T = (I + Lhat_11)^-1 (unit lower triangular; Lhat_11 = the strictly lower part of
+ * L_11 diag(L_11)^-1) replace Lhat_11 in the forward copy, and the same numbers, transposed access,
+ * replace it in the backward copy: forward a = T w, backward z = T^T (D^-1 rhs) -- exactly
+ * transposed operators, so the block solve stays symmetric.  Returns max |T (I + Lhat) - I|. */
+static double nd_invert_tri(int n, int ld, int ldb, double* pf, double* pb, double* wk) {
+  double* Lc = wk;                 /* n x n copy of I + Lhat (column major, ld n) */
+  double* t = wk + (size_t)n * n;  /* one column of T */
+  for (int j = 0; j < n; ++j) {
+    for (int i = 0; i <= j; ++i) Lc[(size_t)j * n + i] = i == j ? 1.0 : 0.0;
+    for (int i = j + 1; i < n; ++i) Lc[(size_t)j * n + i] = pf[(size_t)j * ld + i];
+  }
+  double dev = 0.0;
+  for (int j = 0; j < n; ++j) {
+    for (int i = j + 1; i < n; ++i) t[i] = 0.0;
+    t[j] = 1.0;
+    for (int k = j; k < n; ++k) {
+      const double tk = t[k];
+      if (tk == 0.0) continue;
+      const double* lk = Lc + (size_t)k * n;
+      for (int i = k + 1; i < n; ++i) t[i] -= lk[i] * tk;
+    }
+    for (int i = j + 1; i < n; ++i) { pf[(size_t)j * ld + i] = t[i]; pb[(size_t)i * ldb + j] = t[i]; }
+  }
+  /* T (I + Lhat) - I: T was built as a right inverse, column by column, so the product in the other
+   * order is an independent check (the one in the building order cancels exactly) */
+  for (int j = 0; j < n; ++j)
+    for (int i = j + 1; i < n; ++i) {
+      double sm = Lc[(size_t)j * n + i];                       /* k = i: T(i,i) = 1 */
+      for (int k = j + 1; k < i; ++k) sm += pf[(size_t)k * ld + i] * Lc[(size_t)j * n + k];
+      sm += pf[(size_t)j * ld + i];                            /* k = j: Lc(j,j) = 1 */
+      if (fabs(sm) > dev) dev = fabs(sm);
+    }
+  return dev;
+}
+
 /* Multifrontal factorisation of one block into the two panel copies (host staging buffers hF, hB,
  * laid out supernode after supernode) and dinv (1 / L_jj per new index).  *fail = 1 + new index
- * of a non-positive pivot. */
-static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv, int* fail) {
+ * of a non-positive pivot.  invert: 1 = the split fronts get nd_invert_tri (what the device
+ * kernels expect), 0 = plain factor everywhere (selfcheck). */
+static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv, int* fail, int invert) {
   const int nsn = B->tree.nsn, b = B->b;
   double** upd = (double**)calloc((size_t)nsn, sizeof(double*));     /* update matrices waiting for the parent */
   int* loc = (int*)malloc((size_t)b * sizeof(int));
@@ -314,6 +368,12 @@ static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv,
       const int kmax = i < n ? i : n;
       for (int k = 0; k < kmax; ++k) pb[(size_t)i * ldb + k] = F[(size_t)k * f + i] * sc;
     }
+    if (invert && n > 1 && nd_is_split(n, m)) {
+      double* wk = (double*)malloc(((size_t)n * n + n) * sizeof(double));
+      if (!wk) { free(F); rc = 1; break; }
+      nd_invert_tri(n, ld, ldb, pf, pb, wk);
+      free(wk);
+    }
     oF += (long long)ld * n; oB += (long long)ldb * f;
     if (m > 0 && B->tree.parent[s] >= 0) {
       double* U = (double*)calloc((size_t)m * m, sizeof(double));
@@ -337,6 +397,7 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
   pa_nd_t* S = &g_nd;
   const char* le = getenv("PREALPS_ND_LEAF");
   const int leaf_rows = le ? atoi(le) : 96;
+  nd_split_config();
   nd_block_t* B = (nd_block_t*)calloc((size_t)nblk, sizeof(nd_block_t));
   if (!B) return PA_FAIL("out of host memory");
   int rc = 0;
@@ -435,7 +496,7 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
       double* hF = (double*)malloc((size_t)(B[x].nF ? B[x].nF : 1) * sizeof(double));
       double* hB = (double*)malloc((size_t)(B[x].nB ? B[x].nB : 1) * sizeof(double));
       double* di = (double*)malloc((size_t)B[x].b * sizeof(double));
-      int fail = 0, r2 = (!hF || !hB || !di) ? 1 : nd_numeric(&B[x], hF, hB, di, &fail);
+      int fail = 0, r2 = (!hF || !hB || !di) ? 1 : nd_numeric(&B[x], hF, hB, di, &fail, 1);
       if (!r2) {
         for (int i = 0; i < B[x].b; ++i) h_dinv[B[x].row0 + B[x].tree.perm[i]] = di[i];
 #pragma omp critical
@@ -463,15 +524,13 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
               pa_rt_h2d(S->d_dinv, h_dinv, (size_t)m_local * sizeof(double));
     if (bad) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
   }
-  /* launch lists: by height, then by size class.  Fronts above PREALPS_ND_SPLIT rows (512) are
-   * split: their class is that of the n pivot rows alone (the triangular part, one workgroup),
-   * and the rows below go to a second grid in chunks of pa_nd_chunk_rows() rows, so that the few
-   * large fronts at the top of the tree occupy the whole chip. */
+  /* launch lists: by height, then by size class.  Split fronts (nd_is_split) form one list per
+   * height: the triangular part goes to k_nd_tri_* (one workgroup each), the rows below to a second
+   * grid in chunks of pa_nd_chunk_rows() rows, so that the few large fronts at the top of the tree
+   * occupy the whole chip. */
   long long totp = 0;
   if (!rc) {
     const int ncls = pa_nd_num_classes(), CH = pa_nd_chunk_rows();
-    const char* se = getenv("PREALPS_ND_SPLIT");
-    const int split_from = se ? atoi(se) : 512;
     int cap = 2 * (maxh + 1) * ncls;
     S->l_height = (int*)calloc((size_t)cap, sizeof(int)); S->l_class = (int*)calloc((size_t)cap, sizeof(int));
     S->l_count = (int*)calloc((size_t)cap, sizeof(int)); S->l_list = (int**)calloc((size_t)cap, sizeof(int*));
@@ -486,8 +545,8 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
     long long* h_poff = (long long*)calloc((size_t)nsn, sizeof(long long));
     for (int g = 0; g < nsn && !rc; ++g) {
       int f = h_n[g] + h_m[g];
-      is_split[g] = split_from > 0 && f > split_from && h_m[g] > 0;
-      cls_of[g] = pa_nd_class_of(is_split[g] ? h_n[g] : f);
+      is_split[g] = (char)(h_n[g] > 1 && nd_is_split(h_n[g], h_m[g]));
+      cls_of[g] = is_split[g] ? 0 : pa_nd_class_of(f);
       if (cls_of[g] < 0) rc = PA_FAIL("block solve: a front of %d rows exceeds the kernel's limit; use more subdomains", f);
       if (is_split[g]) { h_poff[g] = totp; totp += (long long)((h_m[g] + CH - 1) / CH) * h_n[g]; }
     }
@@ -565,7 +624,9 @@ int pa_nd_apply(int ts, const double* in, double* out) {
  * like pa_nd_create does and reports: stats[0] supernodes, [1] doubles of one panel copy,
  * [2] rows of the largest front, [3] height of the tree, [4] ||L L^T x - A x|| / ||A x|| for a
  * fixed pseudo-random x with L rebuilt from the forward panels, [5] the largest relative
- * difference between the backward panels and the same entries of the forward panels.
+ * difference between the backward panels and the same entries of the forward panels, [6] the
+ * largest entry of T (I + Lhat_11) - I over the triangular inverses (nd_invert_tri), [7] the
+ * number of fronts the device would handle as split fronts.
  * It multiplies with the factor, it does not solve: there is no CPU solve path in this library. */
 int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const double* val, int leaf_rows,
                              double* stats) {
@@ -586,7 +647,7 @@ int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const 
   int fail = 0;
   if (!hF || !hB || !di || !x || !u || !w || !ax) rc = PA_FAIL("out of host memory");
   if (!rc) {
-    rc = nd_numeric(&B, hF, hB, di, &fail);
+    rc = nd_numeric(&B, hF, hB, di, &fail, 0);
     if (rc == 2) rc = PA_FAIL("matrix is not SPD (row %d)", B.tree.perm[fail - 1]);
     else if (rc) rc = PA_FAIL("out of host memory");
   }
@@ -643,6 +704,25 @@ int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const 
                   B.tree.first[s2 + 1] - B.tree.first[s2], B.m[s2]);
     stats[0] = B.tree.nsn; stats[1] = (double)B.nF; stats[2] = maxf; stats[3] = maxh;
     stats[4] = sqrt(num / (den > 0.0 ? den : 1.0)); stats[5] = dmax;
+    /* the explicit inverses the device uses for the triangular part of split fronts: here of EVERY
+     * supernode the triangular kernels could take, so that small test matrices exercise it too */
+    double dev = 0.0;
+    int nsplit = 0;
+    nd_split_config();
+    oF = 0; oB = 0;
+    for (int s = 0; s < B.tree.nsn && !rc; ++s) {
+      int ns = B.tree.first[s + 1] - B.tree.first[s], m = B.m[s], f = ns + m, ld = (f + 1) & ~1, ldb = (ns + 1) & ~1;
+      if (ns > 1 && ns <= pa_nd_tri_cols()) {
+        double* wk = (double*)malloc(((size_t)ns * ns + ns) * sizeof(double));
+        if (!wk) { rc = PA_FAIL("out of host memory"); break; }
+        double d = nd_invert_tri(ns, ld, ldb, hF + oF, hB + oB, wk);
+        if (d > dev) dev = d;
+        free(wk);
+      }
+      nsplit += ns > 1 && nd_is_split(ns, m);
+      oF += (long long)ld * ns; oB += (long long)ldb * f;
+    }
+    stats[6] = dev; stats[7] = nsplit;
   }
   free(hF); free(hB); free(di); free(x); free(u); free(w); free(ax);
   nd_block_free(&B);

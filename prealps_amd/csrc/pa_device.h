@@ -223,6 +223,7 @@ typedef struct {
   const long long* poff; double* partial;
 } pa_nd_plan_t;
 int pa_nd_chunk_rows(void);
+int pa_nd_tri_cols(void);             /* most pivot columns of a split front (k_nd_tri_*) */
 int pa_nd_num_classes(void);
 int pa_nd_class_of(int front_rows);   /* -1: front too large for the kernels */
 int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out);
