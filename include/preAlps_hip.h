@@ -82,8 +82,8 @@ int preAlps_hip_partition_kway(int N, const int* rowPtr, const int* colInd, int 
  * dissection + multifrontal Cholesky, nd.c), on one SPD matrix taken as a single block; no GPU
  * needed.  stats[0..7] = supernodes, doubles of one panel copy, rows of the largest front, tree
  * height, ||L L^T x - A x|| / ||A x||, largest relative mismatch between the two panel copies,
- * largest entry of T (I + Lhat) - I over the explicit inverses of the pivot triangles, number of
- * fronts handled as split fronts (triangle and rows below on separate grids). */
+ * largest deviation of the selective-inversion panels [T ; -G] from T (I + Lhat_11) = I and
+ * G (I + Lhat_11) = Lhat_21, pivot columns of the widest supernode. */
 int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const double* val, int leaf_rows,
                              double* stats);
 /* Cut the SpMM plan (slices, LDS staging lists) for this enlarging factor now rather than
@@ -134,7 +134,9 @@ int preAlps_hip_panel_trsm_update(CPLM_Mat_Dense_t* P, CPLM_Mat_Dense_t* AP, CPL
                                   double* host_res2);
 /* Numeric facts about the built operator / preconditioner, by name:
  * "nnz_local", "rows_local", "halo_rows", "spmm_blocks", "bj_factor_bytes",
- * "bj_max_bandwidth", "bj_parts_local".  Returns non-zero for unknown keys. */
+ * "bj_max_bandwidth", "bj_parts_local", "bj_nd_blocks" (blocks with the sparse factor),
+ * "bj_nd_inverse_dev" (largest deviation of its inverted pivot triangles), ...  Returns non-zero
+ * for unknown keys. */
 int preAlps_hip_get_stat(const char* key, double* value);
 /* A stopwatch made of two hipEvents on the library stream: start records the
  * first, stop records the second, waits for it and returns the device time

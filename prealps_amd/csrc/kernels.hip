@@ -2077,343 +2077,42 @@ __global__ __launch_bounds__(NT) void k_bj_wide(
 }
 
 // ------------------------------------------------ sparse block solve (large blocks) ----
-// Supernodal triangular solves for the nested-dissection factor of nd.c.  One workgroup per
-// supernode, the supernodes of one tree level per launch.  A front has n pivot columns and
-// f = n + m rows; thread `tid` keeps rows tid, tid + NT, ... of the front in registers (TS
-// right-hand sides each).  Both sweeps have one shape: a block of <= 64 finished rows is
-// published in LDS, then every thread applies it to its own rows with coalesced loads of the
-// panel (column major forward, row major backward) and LDS broadcasts of the published values.
-// The 64 pivot rows of a block settle among themselves inside the wavefront that owns them
-// (v_readlane).  Forward columns are stored divided by their pivot and the running values stay
-// unscaled (as in the band kernels above), so no division sits on the critical path.
-template <int TS, int NT, int RPT>
-__device__ __forceinline__ void nd_apply_block(double (&acc)[RPT][TS], const double* __restrict__ base, int ldm,
-                                               int nb, int lo, int hi, const double (*yb)[TS], int tid) {
-  bool on[RPT];
-  const double* p[RPT];
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    const int r = tid + k * NT;
-    on[k] = r >= lo && r < hi;
-    p[k] = base + (on[k] ? r : lo);
-  }
-  bool any = false;
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) any |= on[k];
-  if (!any) return;
-  // Software pipeline: the UN * RPT panel loads of the next batch are issued before the current
-  // batch is used -- a workgroup runs alone on its CU at the upper levels of the tree, so the
-  // memory latency has to be covered from inside the thread.
-  constexpr int UN = NT >= 1024 ? (RPT >= 8 ? 1 : 8 / RPT) : (RPT >= 16 ? 1 : 16 / RPT);   // (128 VGPRs per thread at 1024 threads)
-  double cur[UN][RPT], nxt[UN][RPT];
-#pragma unroll
-  for (int u = 0; u < UN; ++u)
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) cur[u][k] = (on[k] && u < nb) ? p[k][(size_t)u * ldm] : 0.0;
-#pragma unroll 1
-  for (int j0 = 0; j0 < nb; j0 += UN) {
-    const int j1 = j0 + UN;
-#pragma unroll
-    for (int u = 0; u < UN; ++u)
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) nxt[u][k] = (on[k] && j1 + u < nb) ? p[k][(size_t)(j1 + u) * ldm] : 0.0;
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      double y[TS];
-      const int j = min(j0 + u, 63);
-#pragma unroll
-      for (int c = 0; c < TS / 2; ++c) { const double2 v = reinterpret_cast<const double2*>(yb[j])[c]; y[2 * c] = v.x; y[2 * c + 1] = v.y; }
-#pragma unroll
-      for (int k = 0; k < RPT; ++k)
-#pragma unroll
-        for (int c = 0; c < TS; ++c) acc[k][c] = fma(-cur[u][k], y[c], acc[k][c]);
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u)
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) cur[u][k] = nxt[u][k];
-  }
-}
-
-// The 64 x 64 block the pivots of a step settle in was copied to LDS by the whole workgroup
-// (dblk[j][i] = coefficient of pivot j for the row in lane i, zero where it does not apply), so
-// the serial chain below meets LDS latency, not HBM latency, at each of its 64 links.
-template <int TS, int RPT, int K, bool FWD>
-__device__ __forceinline__ void nd_diag(double (&acc)[RPT][TS], const double (*dblk)[65], int nb, int lane) {
-  // four coefficients read ahead of the chain (rows of dblk past nb are zero: harmless steps)
-  const int q1 = (nb + 3) & ~3;
-#pragma unroll 1
-  for (int q0 = 0; q0 < q1; q0 += 4) {
-    double cf[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) cf[u] = dblk[FWD ? q0 + u : q1 - 1 - (q0 + u)][lane];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = FWD ? q0 + u : q1 - 1 - (q0 + u);
-#pragma unroll
-      for (int c = 0; c < TS; ++c) {
-        const double y = readlane_f64(acc[K][c], j);
-        acc[K][c] = fma(-cf[u], y, acc[K][c]);
-      }
-    }
-  }
-}
-
-template <int TS, int RPT, int K, bool FWD>
-__device__ __forceinline__ void nd_diag_pick(double (&acc)[RPT][TS], int ok, const double (*dblk)[65], int nb,
-                                             int lane, double (*yb)[TS]) {
-  if constexpr (K < RPT) {
-    if (ok == K) {
-      nd_diag<TS, RPT, K, FWD>(acc, dblk, nb, lane);
-      double2* q = reinterpret_cast<double2*>(yb[lane]);
-#pragma unroll
-      for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(acc[K][2 * c], acc[K][2 * c + 1]);
-    } else {
-      nd_diag_pick<TS, RPT, K + 1, FWD>(acc, ok, dblk, nb, lane, yb);
-    }
-  }
-}
-
-// dblk <- the pivot block of a step.  FWD: column jb + j of the column-major panel, rows jb + i
-// (i > j, row inside the front); backward: row jb + j of the row-major panel, columns jb + i (i < j).
-template <int NT, bool FWD>
-__device__ __forceinline__ void nd_load_diag(double (*dblk)[65], const double* __restrict__ base, int ldm, int nb,
-                                             int nvalid, int tid) {
-  for (int e = tid; e < 64 * 64; e += NT) {
-    const int j = e >> 6, i = e & 63;
-    const bool act = j < nb && (FWD ? (i > j && i < nvalid) : (i < j));
-    dblk[j][i] = act ? base[(size_t)j * ldm + i] : 0.0;
-  }
-}
-
-struct nd_args {
-  const int* n; const int* m; const int* ld; const long long* offF; const long long* offB; const int* rows_off;
-  const int* coff; const int* ccoff; const int* rows; const int* src; const double* dinv; const double* F;
-  const double* B; double* contrib;
-  const long long* poff; double* partial;     /* split fronts: partial sums of the backward sweep, [chunk][column] */
-};
-constexpr int ND_CHUNK = 256;                 /* rows below of a split front handled by one workgroup */
-
-// Forward: w = [x(columns) ; 0] + the children's contributions; L y = w on the n columns; the m rows
-// below leave as this supernode's contribution to its parent.  XS = panel stride, TS = columns
-// handled by this workgroup (blockIdx.y picks the column group).
-template <int TS, int XS, int NT, int RPT>
-__global__ __launch_bounds__(NT) void k_nd_forward(nd_args a, const int* __restrict__ list, int split,
-                                                   const double* __restrict__ in, double* __restrict__ out) {
-  __shared__ double ybuf[2][64][TS];
-  __shared__ double dblk[64][65];
-  const int s = list[blockIdx.x], coff = blockIdx.y * TS;
-  // split: only the triangular part (the n pivot rows); the rows below belong to k_nd_rect_fwd
-  const int n = a.n[s], f = split ? n : n + a.m[s], ld = a.ld[s];
-  const double* __restrict__ L = a.F + a.offF[s];
-  const int* __restrict__ rows = a.rows + a.rows_off[s];
-  const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
-  const int cc0 = a.ccoff[2 * s], cc1 = a.ccoff[2 * s + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double acc[RPT][TS];
-  int grow[RPT];
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    const int r = tid + k * NT;
-    grow[k] = -1;
-#pragma unroll
-    for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
-    if (r < f) {
-      grow[k] = rows[r];
-      if (r < n) load_row_s<TS, XS>(in + coff, (size_t)grow[k], acc[k]);
-      const int s0 = src[2 * r], s1 = src[2 * r + 1];
-      double t[TS];
-      if (s0 >= 0) {
-        load_row_s<TS, XS>(a.contrib + coff, (size_t)(cc0 + s0), t);
-#pragma unroll
-        for (int c = 0; c < TS; ++c) acc[k][c] += t[c];
-      }
-      if (s1 >= 0) {
-        load_row_s<TS, XS>(a.contrib + coff, (size_t)(cc1 + s1), t);
-#pragma unroll
-        for (int c = 0; c < TS; ++c) acc[k][c] += t[c];
-      }
-    }
-  }
-  int par = 0;
-  for (int jb = 0; jb < n; jb += 64, par ^= 1) {
-    const int nb = min(64, n - jb);
-    nd_load_diag<NT, true>(dblk, L + (size_t)jb * ld + jb, ld, nb, min(64, f - jb), tid);
-    __syncthreads();
-    if (wave == ((jb % NT) >> 6)) nd_diag_pick<TS, RPT, 0, true>(acc, jb / NT, dblk, nb, lane, ybuf[par]);
-    __syncthreads();
-    nd_apply_block<TS, NT, RPT>(acc, L + (size_t)jb * ld, ld, nb, jb + 64, f, ybuf[par], tid);
-  }
-  const int c0 = a.coff[s];
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    const int r = tid + k * NT;
-    if (r < n) {
-      const double id = a.dinv[grow[k]];
-      double y[TS];
-#pragma unroll
-      for (int c = 0; c < TS; ++c) y[c] = acc[k][c] * id;
-      store_row_s<TS, XS>(out + coff, (size_t)grow[k], y);
-    } else if (r < f) {
-      store_row_s<TS, XS>(a.contrib + coff, (size_t)(c0 + r - n), acc[k]);
-    }
-  }
-}
-
-// Backward: L^T z = y on the n columns, the m rows below are ancestors whose z is final.
-// b_k = L_kk z_k is carried unscaled; the row-major copy holds L(i,k) for the rows below and
-// L(i,k) / L(i,i) for the pivot rows.
-template <int TS, int XS, int NT, int RPT>
-__global__ __launch_bounds__(NT) void k_nd_backward(nd_args a, const int* __restrict__ list, int split,
-                                                    double* __restrict__ out) {
-  __shared__ double ybuf[2][64][TS];
-  __shared__ double dblk[64][65];
-  __shared__ double zbuf[2048];
-  const int s = list[blockIdx.x], coff = blockIdx.y * TS;
-  const int n = a.n[s], mrows = a.m[s], f = split ? n : n + mrows, ldb = (n + 1) & ~1;
-  const double* __restrict__ U = a.B + a.offB[s];
-  const int* __restrict__ rows = a.rows + a.rows_off[s];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double acc[RPT][TS];
-  int grow[RPT];
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    const int r = tid + k * NT;
-    grow[k] = -1;
-#pragma unroll
-    for (int c = 0; c < TS; ++c) acc[k][c] = 0.0;
-    if (r < n) { grow[k] = rows[r]; load_row_s<TS, XS>(out + coff, (size_t)grow[k], acc[k]); }
-  }
-  if (split) {
-    // the rows below were multiplied in by k_nd_rect_bwd, ND_CHUNK of them per workgroup: add the
-    // partial sums (fixed order)
-    const int nch = (mrows + ND_CHUNK - 1) / ND_CHUNK;
-    const long long p0 = a.poff[s];
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      const int r = tid + k * NT;
-      if (r < n)
-        for (int ch = 0; ch < nch; ++ch) {
-          double t[TS];
-          load_row_s<TS, XS>(a.partial + coff, (size_t)(p0 + (long long)ch * n + r), t);
-#pragma unroll
-          for (int c = 0; c < TS; ++c) acc[k][c] -= t[c];
-        }
-    }
-  }
-  int par = 0;
-  // The rows below (ancestors, final).  A supernode low in the tree has few columns and many rows
-  // below: with one thread per column most of the workgroup would idle while the panel streams by.
-  // When the columns fill at most half the workgroup, G groups of threads share the source rows
-  // (z staged in LDS ZR rows at a time) and their partial sums are added up through LDS.
-  const int npad = (n + 63) & ~63;
-  const int G = (n > 0 && 2 * npad <= NT) ? NT / npad : 1;
-  if (G > 1) {
-    constexpr int ZR = 2048 / TS;
-    const int g = tid / npad, k = tid - g * npad;
-    const bool on = g < G && k < n;
-    double part[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) part[c] = 0.0;
-    for (int i0 = n; i0 < f; i0 += ZR) {
-      const int nb = min(ZR, f - i0);
-      for (int r = tid; r < nb; r += NT) {
-        double z[TS];
-        load_row_s<TS, XS>(out + coff, (size_t)rows[i0 + r], z);
-        double2* q = reinterpret_cast<double2*>(zbuf + (size_t)r * TS);
-#pragma unroll
-        for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(z[2 * c], z[2 * c + 1]);
-      }
-      __syncthreads();
-      if (on) {
-        const double* __restrict__ p = U + (size_t)i0 * ldb + k;
-#pragma unroll 4
-        for (int r = g; r < nb; r += G) {
-          const double cf = p[(size_t)r * ldb];
-          const double2* zq = reinterpret_cast<const double2*>(zbuf + (size_t)r * TS);
-#pragma unroll
-          for (int c = 0; c < TS / 2; ++c) {
-            const double2 zv = zq[c];
-            part[2 * c] = fma(-cf, zv.x, part[2 * c]);
-            part[2 * c + 1] = fma(-cf, zv.y, part[2 * c + 1]);
-          }
-        }
-      }
-      __syncthreads();
-    }
-    double* red = &dblk[0][0];            /* NT <= 64 * 65 doubles */
-#pragma unroll
-    for (int c = 0; c < TS; ++c) {
-      red[tid] = part[c];
-      __syncthreads();
-      if (tid < n) {
-        double sm = 0.0;
-        for (int g2 = 0; g2 < G; ++g2) sm += red[g2 * npad + tid];
-        acc[0][c] += sm;
-      }
-      __syncthreads();
-    }
-  }
-  // (otherwise) 64 at a time: z from the solution panel into LDS, then everyone applies them
-  for (int i0 = n; G == 1 && i0 < f; i0 += 64, par ^= 1) {
-    const int nb = min(64, f - i0);
-    if (tid < 64) {
-      double z[TS];
-#pragma unroll
-      for (int c = 0; c < TS; ++c) z[c] = 0.0;
-      if (tid < nb) load_row_s<TS, XS>(out + coff, (size_t)rows[i0 + tid], z);
-      double2* q = reinterpret_cast<double2*>(ybuf[par][tid]);
-#pragma unroll
-      for (int c = 0; c < TS / 2; ++c) q[c] = make_double2(z[2 * c], z[2 * c + 1]);
-    }
-    __syncthreads();
-    nd_apply_block<TS, NT, RPT>(acc, U + (size_t)i0 * ldb, ldb, nb, 0, n, ybuf[par], tid);
-  }
-  // the pivot blocks, last first
-  for (int jb = ((n - 1) >> 6) << 6; jb >= 0; jb -= 64, par ^= 1) {
-    const int nb = min(64, n - jb);
-    nd_load_diag<NT, false>(dblk, U + (size_t)jb * ldb + jb, ldb, nb, nb, tid);
-    __syncthreads();
-    if (wave == ((jb % NT) >> 6)) nd_diag_pick<TS, RPT, 0, false>(acc, jb / NT, dblk, nb, lane, ybuf[par]);
-    __syncthreads();
-    nd_apply_block<TS, NT, RPT>(acc, U + (size_t)jb * ldb, ldb, nb, 0, jb, ybuf[par], tid);
-  }
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    if (grow[k] >= 0) {
-      const double id = a.dinv[grow[k]];
-      double z[TS];
-#pragma unroll
-      for (int c = 0; c < TS; ++c) z[c] = acc[k][c] * id;
-      store_row_s<TS, XS>(out + coff, (size_t)grow[k], z);
-    }
-  }
-}
-
-// Dot products of the split-front kernels.  A thread adds coefficient(j) * ys[j] over the 16-wide
-// groups g = g0 + q, g0 + q + Q, ... < g1 of an index range (j = 16 g + u, kept to lo <= j < hi);
-// consecutive j are `stride` doubles apart at p.  Q threads share one output and are added up
-// through LDS afterwards.  The first group is requested by nd_dot_first (before the barrier that
-// publishes ys), every other group one round ahead of its use.
-__device__ __forceinline__ void nd_dot_load(double (&cf)[16], const double* __restrict__ p, size_t stride, int g, int g1,
+// Sparse block solve with the nested-dissection factor of nd.c.  Every front (n pivot columns,
+// m rows below) is stored as the panel P = [T ; -G], T = strictly lower part of (L_11 D^-1)^-1,
+// G = (L_21 D^-1) (L_11 D^-1)^-1, D = diag(L_11) -- the "selective inversion" form of a supernodal
+// factor: both sweeps become products of dense panels with short vectors, there is no recurrence
+// inside a front and one launch takes a whole level of the tree.
+//   forward   w = x(pivot rows) + children's contributions;  a = w + T w;  y = D^-1 a  -> Y
+//             contribution to the parent = children's contributions(rows below) + (-G) w
+//   backward  v = [D^-1 y ; z(rows below, final)];  z_k = v_k + sum_{i > k} P(i, k) v_i
+// Two copies of P: column major (forward: a thread owns a front row, lanes = consecutive rows) and
+// row major (backward: a thread owns a pivot column, lanes = consecutive columns).
+//
+// A thread adds coefficient(j) * ys[j] over 16-wide groups of an index range (j = 16 g + u, kept
+// to lo <= j < hi); consecutive j are `stride` doubles apart at p.  Q threads (wavefronts) share
+// one output, groups dealt round robin, and meet in LDS afterwards.  The vector is staged in LDS
+// in rounds; the coefficients of a group are requested one group ahead, across the rounds'
+// barriers, so a workgroup that is alone on its CU still keeps 16 loads per thread in flight.
+__device__ __forceinline__ void nd_dot_load(double (&cf)[16], const double* __restrict__ p, size_t stride, int g, int gtot,
                                             int lo, int hi, bool on) {
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int j = 16 * g + u;
-    cf[u] = (on && g < g1 && j >= lo && j < hi) ? p[(size_t)j * stride] : 0.0;
+    cf[u] = (on && g < gtot && j >= lo && j < hi) ? p[(size_t)j * stride] : 0.0;
   }
 }
 
 template <int TS, int Q, int YN>
 __device__ __forceinline__ void nd_dot(double (&acc)[TS], double (&cf)[16], const double* __restrict__ p, size_t stride,
-                                       int g, int g1, int lo, int hi, bool on, const double (*ys)[TS]) {
+                                       int& g, int gend, int gtot, int lo, int hi, bool on, const double (*ys)[TS],
+                                       int y0) {
   double nx[16];
 #pragma unroll 1
-  for (; g < g1; g += Q) {
-    nd_dot_load(nx, p, stride, g + Q, g1, lo, hi, on);
+  for (; g < gend; g += Q) {
+    nd_dot_load(nx, p, stride, g + Q, gtot, lo, hi, on);
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const double2* yq = reinterpret_cast<const double2*>(ys[min(16 * g + u, YN - 1)]);
+      const double2* yq = reinterpret_cast<const double2*>(ys[min(16 * g + u - y0, YN - 1)]);
 #pragma unroll
       for (int c = 0; c < TS / 2; ++c) {
         const double2 yv = yq[c];
@@ -2426,271 +2125,173 @@ __device__ __forceinline__ void nd_dot(double (&acc)[TS], double (&cf)[16], cons
   }
 }
 
-// The triangular part of a split front as a product with the explicit inverse (nd.c, nd_invert_tri):
-// no recurrence, no step-by-step barriers -- the n <= R pivot rows are staged in LDS once, Q threads
-// share a row (16-column groups dealt round robin) and their sums meet in LDS.  R * Q threads keep
-// 16 coefficients in flight each, requested before the staging barrier, so one CU pulls the
-// triangle in a few microseconds (the recurrence this replaces took 15 us per 64 pivots).
-constexpr int ND_TRI = 256;
+struct nd_args {
+  const int* n; const int* m; const int* ld; const long long* offF; const long long* offB; const int* rows_off;
+  const int* coff; const int* ccoff; const int* rows; const int* src; const double* dinv; const double* F;
+  const double* B; double* contrib; double* Y;
+};
+constexpr int ND_CHUNK = 256;                 /* front rows per forward workgroup */
+constexpr int ND_COLS = 64;                   /* pivot columns per backward workgroup */
+constexpr int ND_STAGE = 512;                 /* entries of w staged per round (forward) */
 
-// Forward: w = x(columns) + the children's contributions; a = T w; y = a / L_jj leaves in `out`
-// (k_nd_rect_fwd of the same level reads it there).
-template <int TS, int XS, int R, int Q>
-__global__ __launch_bounds__(R * Q) void k_nd_tri_fwd(nd_args a, const int* __restrict__ list,
-                                                      const double* __restrict__ in, double* __restrict__ out) {
-  __shared__ double ws[R][TS];
-  __shared__ double red[Q - 1][R][TS];
-  const int s = list[blockIdx.x], coff = blockIdx.y * TS;
-  const int n = a.n[s], ld = a.ld[s];
-  const double* __restrict__ T = a.F + a.offF[s];
-  const int tid = threadIdx.x, r = tid % R, q = tid / R;
-  const bool on = r < n;
-  const int g1 = (r + 15) >> 4;                              // columns 0 .. r - 1
-  const double* __restrict__ p = T + r;
-  double cf[16];
-  nd_dot_load(cf, p, (size_t)ld, q, g1, 0, r, on);
-  double w[TS];
-  int grow = -1;
-  double id = 0.0;
+template <int TS, int XS>
+__device__ __forceinline__ void nd_gather_w(const nd_args& a, const int* __restrict__ rows, const int* __restrict__ src,
+                                            int cc0, int cc1, int j, int n, const double* __restrict__ in, int coff,
+                                            double (&w)[TS]) {
+  const int s0 = src[2 * j], s1 = src[2 * j + 1];
+  if (j < n) load_row_s<TS, XS>(in + coff, (size_t)rows[j], w);
+  double t[TS];
+  if (s0 >= 0) {
+    load_row_s<TS, XS>(a.contrib + coff, (size_t)(cc0 + s0), t);
 #pragma unroll
-  for (int c = 0; c < TS; ++c) w[c] = 0.0;
-  if (q == 0) {
-    if (on) {
-      const int* __restrict__ rows = a.rows + a.rows_off[s];
-      const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
-      grow = rows[r];
-      const int s0 = src[2 * r], s1 = src[2 * r + 1];
-      load_row_s<TS, XS>(in + coff, (size_t)grow, w);
-      id = a.dinv[grow];
-      double t[TS];
-      if (s0 >= 0) {
-        load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s] + s0), t);
-#pragma unroll
-        for (int c = 0; c < TS; ++c) w[c] += t[c];
-      }
-      if (s1 >= 0) {
-        load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s + 1] + s1), t);
-#pragma unroll
-        for (int c = 0; c < TS; ++c) w[c] += t[c];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < TS; ++c) ws[r][c] = w[c];           // (rows >= n: zeros, met by zero coefficients only)
+    for (int c = 0; c < TS; ++c) w[c] += t[c];
   }
-  __syncthreads();
-  double acc[TS];
+  if (s1 >= 0) {
+    load_row_s<TS, XS>(a.contrib + coff, (size_t)(cc1 + s1), t);
 #pragma unroll
-  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-  nd_dot<TS, Q, R>(acc, cf, p, (size_t)ld, q, g1, 0, r, on, ws);
-  if (q > 0) {
-#pragma unroll
-    for (int c = 0; c < TS; ++c) red[q - 1][r][c] = acc[c];
-  }
-  __syncthreads();
-  if (q == 0 && on) {
-    double y[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) {
-      double sm = w[c] + acc[c];
-#pragma unroll
-      for (int k = 0; k < Q - 1; ++k) sm += red[k][r][c];
-      y[c] = sm * id;
-    }
-    store_row_s<TS, XS>(out + coff, (size_t)grow, y);
+    for (int c = 0; c < TS; ++c) w[c] += t[c];
   }
 }
 
-// Backward: rhs = y(columns) - the partial sums k_nd_rect_bwd left for the rows below (fixed order);
-// u = rhs / L_kk; z = T^T u.
-template <int TS, int XS, int R, int Q>
-__global__ __launch_bounds__(R * Q) void k_nd_tri_bwd(nd_args a, const int* __restrict__ list, double* __restrict__ out) {
-  __shared__ double us[R][TS];
-  __shared__ double red[Q - 1][R][TS];
-  const int s = list[blockIdx.x], coff = blockIdx.y * TS;
-  const int n = a.n[s], mrows = a.m[s], ldb = (n + 1) & ~1;
-  const double* __restrict__ U = a.B + a.offB[s];
-  const int tid = threadIdx.x, k = tid % R, q = tid / R;
-  const bool on = k < n;
-  const int g0 = (k + 1) >> 4, g1 = (n + 15) >> 4;           // rows k + 1 .. n - 1
-  const double* __restrict__ p = U + k;
-  double cf[16];
-  nd_dot_load(cf, p, (size_t)ldb, g0 + q, g1, k + 1, n, on);
-  double uk[TS];
-  int grow = -1;
-#pragma unroll
-  for (int c = 0; c < TS; ++c) uk[c] = 0.0;
-  if (q == 0) {
-    if (on) {
-      grow = (a.rows + a.rows_off[s])[k];
-      load_row_s<TS, XS>(out + coff, (size_t)grow, uk);
-      const double id = a.dinv[grow];
-      const int nch = (mrows + ND_CHUNK - 1) / ND_CHUNK;
-      const long long p0 = a.poff[s];
-#pragma unroll 4
-      for (int ch = 0; ch < nch; ++ch) {
-        double t[TS];
-        load_row_s<TS, XS>(a.partial + coff, (size_t)(p0 + (long long)ch * n + k), t);
-#pragma unroll
-        for (int c = 0; c < TS; ++c) uk[c] -= t[c];
-      }
-#pragma unroll
-      for (int c = 0; c < TS; ++c) uk[c] *= id;
-    }
-#pragma unroll
-    for (int c = 0; c < TS; ++c) us[k][c] = uk[c];
-  }
-  __syncthreads();
-  double acc[TS];
-#pragma unroll
-  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-  nd_dot<TS, Q, R>(acc, cf, p, (size_t)ldb, g0 + q, g1, k + 1, n, on, us);
-  if (q > 0) {
-#pragma unroll
-    for (int c = 0; c < TS; ++c) red[q - 1][k][c] = acc[c];
-  }
-  __syncthreads();
-  if (q == 0 && on) {
-    double z[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) {
-      double sm = uk[c] + acc[c];
-#pragma unroll
-      for (int j = 0; j < Q - 1; ++j) sm += red[j][k][c];
-      z[c] = sm;
-    }
-    store_row_s<TS, XS>(out + coff, (size_t)grow, z);
-  }
-}
-
-// The rectangular part of a split front on its own grid: ND_CHUNK rows below per workgroup, so
-// that the upper levels of the tree -- 64..256 fronts of 1000..2000 rows -- fill the chip instead
-// of one CU each; Q threads share a row (launches of few chunks: a workgroup is then alone on its
-// CU and needs the loads of 1024 threads in flight).  Forward: contribution(r) = children's
-// contributions - sum_j Lhat(r, j) a_j with a_j = y_j L_jj (the unscaled pivot values; y was
-// written by the triangular kernel of the level).
+// Forward, one workgroup per (front, chunk of ND_CHUNK front rows); Q threads per row.
 template <int TS, int XS, int Q>
-__global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_rect_fwd(nd_args a, const int* __restrict__ cfront,
-                                                              const int* __restrict__ crow0,
-                                                              const double* __restrict__ out) {
-  __shared__ double ys[ND_TRI][TS];
+__global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_forward(nd_args a, const int* __restrict__ cfront,
+                                                             const int* __restrict__ crow0,
+                                                             const double* __restrict__ in) {
+  __shared__ double ws[ND_STAGE][TS];
   __shared__ double red[Q > 1 ? Q - 1 : 1][ND_CHUNK][TS];
   const int s = cfront[blockIdx.x], r0 = crow0[blockIdx.x], coff = blockIdx.y * TS;
-  const int n = a.n[s], m = a.m[s], ld = a.ld[s];
-  const double* __restrict__ L = a.F + a.offF[s];
+  const int n = a.n[s], f = n + a.m[s], ld = a.ld[s];
+  const double* __restrict__ P = a.F + a.offF[s];
   const int* __restrict__ rows = a.rows + a.rows_off[s];
+  const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
+  const int cc0 = a.ccoff[2 * s], cc1 = a.ccoff[2 * s + 1];
   const int tid = threadIdx.x, rl = tid % ND_CHUNK, q = tid / ND_CHUNK;
-  const int rr = r0 + rl;                     // row below, 0-based
-  const bool on = rr < m;
-  const int r = n + (on ? rr : 0);            // front row
-  const int g1 = (n + 15) >> 4;
-  const double* __restrict__ p = L + r;
+  const int r = r0 + rl;
+  const bool on = r < f;
+  const int hi = min(r, n);                   // columns 0 .. hi - 1 of front row r
+  const int gtot = (hi + 15) >> 4;
+  const int jwg = min(n, r0 + ND_CHUNK);      // columns this workgroup meets
+  const double* __restrict__ p = P + (on ? r : 0);
   double cf[16];
-  nd_dot_load(cf, p, (size_t)ld, q, g1, 0, n, on);
-  if (tid < ND_TRI) {
-    double y[TS];
+  int g = q;
+  nd_dot_load(cf, p, (size_t)ld, g, gtot, 0, hi, on);
+  double acc[TS], own[TS];
 #pragma unroll
-    for (int c = 0; c < TS; ++c) y[c] = 0.0;
-    if (tid < n) {
-      const int g = rows[tid];
-      load_row_s<TS, XS>(out + coff, (size_t)g, y);
-      const double ljj = 1.0 / a.dinv[g];
+  for (int c = 0; c < TS; ++c) { acc[c] = 0.0; own[c] = 0.0; }
+  if (q == 0 && on && r >= n) nd_gather_w<TS, XS>(a, rows, src, cc0, cc1, r, n, in, coff, own);
+  for (int c0 = 0; c0 < jwg; c0 += ND_STAGE) {
+    if (c0 > 0) __syncthreads();
+    for (int jj = tid; jj < ND_STAGE; jj += ND_CHUNK * Q) {
+      double w[TS];
 #pragma unroll
-      for (int c = 0; c < TS; ++c) y[c] *= ljj;
+      for (int c = 0; c < TS; ++c) w[c] = 0.0;
+      if (c0 + jj < jwg) nd_gather_w<TS, XS>(a, rows, src, cc0, cc1, c0 + jj, n, in, coff, w);
+      double2* wq = reinterpret_cast<double2*>(ws[jj]);
+#pragma unroll
+      for (int c = 0; c < TS / 2; ++c) wq[c] = make_double2(w[2 * c], w[2 * c + 1]);
     }
-    double2* yq = reinterpret_cast<double2*>(ys[tid]);
+    __syncthreads();
+    if (q == 0 && on && r < n && r >= c0 && r < c0 + ND_STAGE) {
 #pragma unroll
-    for (int c = 0; c < TS / 2; ++c) yq[c] = make_double2(y[2 * c], y[2 * c + 1]);
+      for (int c = 0; c < TS; ++c) own[c] = ws[r - c0][c];
+    }
+    nd_dot<TS, Q, ND_STAGE>(acc, cf, p, (size_t)ld, g, min(gtot, (c0 + ND_STAGE) >> 4), gtot, 0, hi, on, ws, c0);
   }
-  double acc[TS], part[TS];
-#pragma unroll
-  for (int c = 0; c < TS; ++c) { acc[c] = 0.0; part[c] = 0.0; }
-  if (on && q == 0) {
-    const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
-    const int s0 = src[2 * r], s1 = src[2 * r + 1];
-    double t[TS];
-    if (s0 >= 0) {
-      load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s] + s0), t);
-#pragma unroll
-      for (int c = 0; c < TS; ++c) acc[c] += t[c];
-    }
-    if (s1 >= 0) {
-      load_row_s<TS, XS>(a.contrib + coff, (size_t)(a.ccoff[2 * s + 1] + s1), t);
-#pragma unroll
-      for (int c = 0; c < TS; ++c) acc[c] += t[c];
-    }
-  }
-  __syncthreads();
-  nd_dot<TS, Q, ND_TRI>(part, cf, p, (size_t)ld, q, g1, 0, n, on, ys);
   if constexpr (Q > 1) {
     if (q > 0) {
 #pragma unroll
-      for (int c = 0; c < TS; ++c) red[q - 1][rl][c] = part[c];
+      for (int c = 0; c < TS; ++c) red[q - 1][rl][c] = acc[c];
     }
     __syncthreads();
   }
-  if (on && q == 0) {
+  if (q == 0 && on) {
 #pragma unroll
     for (int c = 0; c < TS; ++c) {
-      double sm = part[c];
+      double sm = acc[c];
       if constexpr (Q > 1) {
 #pragma unroll
         for (int k = 0; k < Q - 1; ++k) sm += red[k][rl][c];
       }
-      acc[c] -= sm;
+      own[c] += sm;
     }
-    store_row_s<TS, XS>(a.contrib + coff, (size_t)(a.coff[s] + rr), acc);
+    if (r < n) {
+      const int gr = rows[r];
+      const double id = a.dinv[gr];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) own[c] *= id;
+      store_row_s<TS, XS>(a.Y + coff, (size_t)gr, own);
+    } else {
+      store_row_s<TS, XS>(a.contrib + coff, (size_t)(a.coff[s] + r - n), own);
+    }
   }
 }
 
-// Backward: partial(chunk, k) = sum over the chunk's rows i of L(i, k) z_i for the n <= 256 columns k;
-// the triangular kernel of the level subtracts the chunks in order.
-template <int TS, int XS, int Q>
-__global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_rect_bwd(nd_args a, const int* __restrict__ cfront,
-                                                              const int* __restrict__ crow0,
-                                                              const double* __restrict__ out) {
-  __shared__ double zs[ND_CHUNK][TS];
-  __shared__ double red[Q > 1 ? Q - 1 : 1][ND_CHUNK][TS];
-  const int s = cfront[blockIdx.x], r0 = crow0[blockIdx.x], coff = blockIdx.y * TS;
-  const int n = a.n[s], m = a.m[s], ldb = (n + 1) & ~1;
+// Backward, one workgroup per (front, block of ND_COLS pivot columns); W wavefronts share the rows.
+template <int TS, int XS, int W>
+__global__ __launch_bounds__(64 * W) void k_nd_backward(nd_args a, const int* __restrict__ cfront,
+                                                        const int* __restrict__ ccol0, double* __restrict__ out) {
+  constexpr int NSTG = TS >= 8 ? 512 : 1024;  // rows of v staged per round
+  __shared__ double vs[NSTG][TS];
+  __shared__ double red[W - 1][ND_COLS][TS];
+  const int s = cfront[blockIdx.x], k0 = ccol0[blockIdx.x], coff = blockIdx.y * TS;
+  const int n = a.n[s], f = n + a.m[s], ldb = (n + 1) & ~1;
   const double* __restrict__ U = a.B + a.offB[s];
   const int* __restrict__ rows = a.rows + a.rows_off[s];
-  const int tid = threadIdx.x, k = tid % ND_CHUNK, q = tid / ND_CHUNK;
-  const int nr = min(ND_CHUNK, m - r0);
+  const int tid = threadIdx.x, kk = tid & 63, q = tid >> 6;
+  const int k = k0 + kk;
   const bool on = k < n;
-  const int g1 = (nr + 15) >> 4;
-  const double* __restrict__ p = U + (size_t)(n + r0) * ldb + k;
+  const int gtot = (f + 15) >> 4;
+  const double* __restrict__ p = U + (on ? k : 0);
   double cf[16];
-  nd_dot_load(cf, p, (size_t)ldb, q, g1, 0, nr, on);
-  if (tid < ND_CHUNK) {
-    double z[TS];
+  int g = (k0 >> 4) + q;
+  nd_dot_load(cf, p, (size_t)ldb, g, gtot, k + 1, f, on);
+  double acc[TS], own[TS];
 #pragma unroll
-    for (int c = 0; c < TS; ++c) z[c] = 0.0;
-    if (tid < nr) load_row_s<TS, XS>(out + coff, (size_t)rows[n + r0 + tid], z);
-    double2* zq = reinterpret_cast<double2*>(zs[tid]);
+  for (int c = 0; c < TS; ++c) { acc[c] = 0.0; own[c] = 0.0; }
+  for (int c0 = k0; c0 < f; c0 += NSTG) {
+    if (c0 > k0) __syncthreads();
+    for (int ii = tid; ii < NSTG; ii += 64 * W) {
+      const int i = c0 + ii;
+      double v[TS];
 #pragma unroll
-    for (int c = 0; c < TS / 2; ++c) zq[c] = make_double2(z[2 * c], z[2 * c + 1]);
-  }
-  __syncthreads();
-  double acc[TS];
+      for (int c = 0; c < TS; ++c) v[c] = 0.0;
+      if (i < f) {
+        const int gr = rows[i];
+        if (i < n) {
+          load_row_s<TS, XS>(a.Y + coff, (size_t)gr, v);
+          const double id = a.dinv[gr];
 #pragma unroll
-  for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-  nd_dot<TS, Q, ND_CHUNK>(acc, cf, p, (size_t)ldb, q, g1, 0, nr, on, zs);
-  if constexpr (Q > 1) {
-    if (q > 0) {
+          for (int c = 0; c < TS; ++c) v[c] *= id;
+        } else {
+          load_row_s<TS, XS>(out + coff, (size_t)gr, v);
+        }
+      }
+      double2* vq = reinterpret_cast<double2*>(vs[ii]);
 #pragma unroll
-      for (int c = 0; c < TS; ++c) red[q - 1][k][c] = acc[c];
+      for (int c = 0; c < TS / 2; ++c) vq[c] = make_double2(v[2 * c], v[2 * c + 1]);
     }
     __syncthreads();
-  }
-  if (on && q == 0) {
-    if constexpr (Q > 1) {
+    if (q == 0 && on && k >= c0 && k < c0 + NSTG) {
 #pragma unroll
-      for (int c = 0; c < TS; ++c) {
-#pragma unroll
-        for (int j = 0; j < Q - 1; ++j) acc[c] += red[j][k][c];
-      }
+      for (int c = 0; c < TS; ++c) own[c] = vs[k - c0][c];
     }
-    store_row_s<TS, XS>(a.partial + coff, (size_t)(a.poff[s] + (long long)(r0 / ND_CHUNK) * n + k), acc);
+    nd_dot<TS, W, NSTG>(acc, cf, p, (size_t)ldb, g, min(gtot, (c0 + NSTG) >> 4), gtot, k + 1, f, on, vs, c0);
+  }
+  if (q > 0) {
+#pragma unroll
+    for (int c = 0; c < TS; ++c) red[q - 1][kk][c] = acc[c];
+  }
+  __syncthreads();
+  if (q == 0 && on) {
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      double sm = acc[c];
+#pragma unroll
+      for (int j = 0; j < W - 1; ++j) sm += red[j][kk][c];
+      own[c] += sm;
+    }
+    store_row_s<TS, XS>(out + coff, (size_t)rows[k], own);
   }
 }
 
@@ -2927,73 +2528,31 @@ static int bj_factor_big_launch(const int* list, int count, int wmax, const int*
   return kfail("k_bj_factor_big");
 }
 
-// size classes of the fronts: NT threads keep up to RPT rows each
-constexpr int ND_NCLASS = 6;
-constexpr int ND_NT[ND_NCLASS] = {256, 256, 512, 1024, 1024, 1024};
-constexpr int ND_RPT[ND_NCLASS] = {1, 2, 2, 2, 4, 8};
-
-template <int TS, int XS, int NT, int RPT>
-static int nd_launch_one(const nd_args& a, const int* list, int count, int split, bool fwd, const double* in, double* out) {
-  const dim3 grid(count, XS / TS);
-  if (fwd) hipLaunchKernelGGL((k_nd_forward<TS, XS, NT, RPT>), grid, dim3(NT), 0, cur_stream(), a, list, split, in, out);
-  else hipLaunchKernelGGL((k_nd_backward<TS, XS, NT, RPT>), grid, dim3(NT), 0, cur_stream(), a, list, split, out);
-  return kfail(fwd ? "k_nd_forward" : "k_nd_backward");
-}
-
-// a thread keeps RPT * TS doubles: at most 32 (64 VGPRs); wider panels go in column groups
-template <int XS, int NT, int RPT>
-static int nd_launch_cls(const nd_args& a, const int* list, int count, int split, bool fwd, const double* in, double* out) {
-  constexpr int TSMAX = 32 / RPT;
-  constexpr int TS = XS <= TSMAX ? XS : (TSMAX < 2 ? 2 : TSMAX);
-  return nd_launch_one<TS, XS, NT, RPT>(a, list, count, split, fwd, in, out);
+// one level of the tree; launches of few workgroups put more threads on each output
+template <int XS>
+static int nd_launch_fwd(const nd_args& a, const int* cfront, const int* crow0, int nwg, const double* in) {
+  if (nwg <= 0) return 0;
+  static int few = -1;
+  if (few < 0) { const char* e = getenv("PREALPS_ND_FEW"); few = e ? atoi(e) : 1024; }
+  constexpr int TS = XS <= 8 ? XS : 8;        // 16-column panels in two column groups (LDS, registers)
+  constexpr int QB = TS >= 8 ? 2 : 4;
+  const dim3 grid(nwg, XS / TS);
+  if (nwg < few) hipLaunchKernelGGL((k_nd_forward<TS, XS, QB>), grid, dim3(ND_CHUNK * QB), 0, cur_stream(), a, cfront, crow0, in);
+  else hipLaunchKernelGGL((k_nd_forward<TS, XS, 1>), grid, dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, in);
+  return kfail("k_nd_forward");
 }
 
 template <int XS>
-static int nd_launch(const nd_args& a, int cls, const int* list, int count, int split, bool fwd, const double* in, double* out) {
-  switch (cls) {
-    case 0: return nd_launch_cls<XS, 256, 1>(a, list, count, split, fwd, in, out);
-    case 1: return nd_launch_cls<XS, 256, 2>(a, list, count, split, fwd, in, out);
-    case 2: return nd_launch_cls<XS, 512, 2>(a, list, count, split, fwd, in, out);
-    case 3: return nd_launch_cls<XS, 1024, 2>(a, list, count, split, fwd, in, out);
-    case 4: return nd_launch_cls<XS, 1024, 4>(a, list, count, split, fwd, in, out);
-    case 5: return nd_launch_cls<XS, 1024, 8>(a, list, count, split, fwd, in, out);
-  }
-  return 1;
-}
-
-// the triangular parts of the split fronts of one level
-template <int XS>
-static int nd_launch_tri(const nd_args& a, const int* list, int count, int nmax, bool fwd, const double* in, double* out) {
-  constexpr int TS = XS <= 4 ? XS : 4;
-  const dim3 grid(count, XS / TS);
-  if (nmax <= 128) {      // (the many small fronts just above the leaves)
-    if (fwd) hipLaunchKernelGGL((k_nd_tri_fwd<TS, XS, 128, 4>), grid, dim3(512), 0, cur_stream(), a, list, in, out);
-    else hipLaunchKernelGGL((k_nd_tri_bwd<TS, XS, 128, 4>), grid, dim3(512), 0, cur_stream(), a, list, out);
-  } else {
-    if (fwd) hipLaunchKernelGGL((k_nd_tri_fwd<TS, XS, ND_TRI, 4>), grid, dim3(1024), 0, cur_stream(), a, list, in, out);
-    else hipLaunchKernelGGL((k_nd_tri_bwd<TS, XS, ND_TRI, 4>), grid, dim3(1024), 0, cur_stream(), a, list, out);
-  }
-  return kfail(fwd ? "k_nd_tri_fwd" : "k_nd_tri_bwd");
-}
-
-// the rows below of the split fronts of one launch: `nchunk` (front, first row) pairs
-template <int XS>
-static int nd_launch_rect(const nd_args& a, const int* cfront, const int* crow0, int nchunk, bool fwd, const double* out) {
-  if (nchunk <= 0) return 0;
-  static int few = -1;          // launches of fewer chunks than this put four threads on a row
-  if (few < 0) { const char* e = getenv("PREALPS_ND_RECT_FEW"); few = e ? atoi(e) : 1024; }
-  if (nchunk < few) {
-    constexpr int TS = XS <= 4 ? XS : 4;
-    const dim3 grid(nchunk, XS / TS);
-    if (fwd) hipLaunchKernelGGL((k_nd_rect_fwd<TS, XS, 4>), grid, dim3(ND_CHUNK * 4), 0, cur_stream(), a, cfront, crow0, out);
-    else hipLaunchKernelGGL((k_nd_rect_bwd<TS, XS, 4>), grid, dim3(ND_CHUNK * 4), 0, cur_stream(), a, cfront, crow0, out);
-  } else {
-    constexpr int TS = XS <= 8 ? XS : 8;        // 16-column panels in two column groups (LDS, registers)
-    const dim3 grid(nchunk, XS / TS);
-    if (fwd) hipLaunchKernelGGL((k_nd_rect_fwd<TS, XS, 1>), grid, dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, out);
-    else hipLaunchKernelGGL((k_nd_rect_bwd<TS, XS, 1>), grid, dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, out);
-  }
-  return kfail(fwd ? "k_nd_rect_fwd" : "k_nd_rect_bwd");
+static int nd_launch_bwd(const nd_args& a, const int* cfront, const int* ccol0, int nwg, double* out) {
+  if (nwg <= 0) return 0;
+  static int few = -1;
+  if (few < 0) { const char* e = getenv("PREALPS_ND_FEW_BWD"); few = e ? atoi(e) : 2048; }
+  constexpr int TS = XS <= 8 ? XS : 8;
+  constexpr int WB = TS >= 8 ? 8 : 16;
+  const dim3 grid(nwg, XS / TS);
+  if (nwg < few) hipLaunchKernelGGL((k_nd_backward<TS, XS, WB>), grid, dim3(64 * WB), 0, cur_stream(), a, cfront, ccol0, out);
+  else hipLaunchKernelGGL((k_nd_backward<TS, XS, 4>), grid, dim3(256), 0, cur_stream(), a, cfront, ccol0, out);
+  return kfail("k_nd_backward");
 }
 
 extern "C" {
@@ -3249,34 +2808,23 @@ int pa_k_bj_factor_big(const int* list, int count, int wmax, int wide_from, cons
   return kfail("k_bj_layout_big");
 }
 
-int pa_nd_num_classes(void) { return ND_NCLASS; }
-int pa_nd_class_of(int front_rows) {
-  for (int c = 0; c < ND_NCLASS; ++c) if (front_rows <= ND_NT[c] * ND_RPT[c]) return c;
-  return -1;
-}
-
-// launches are listed bottom-up (height, then class): forward in that order, backward reversed
 int pa_nd_chunk_rows(void) { return ND_CHUNK; }
-int pa_nd_tri_cols(void) { return ND_TRI; }
+int pa_nd_block_cols(void) { return ND_COLS; }
 
+// levels are listed bottom-up: forward in that order, backward reversed
 int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out) {
   nd_args a{pl->n, pl->m, pl->ld, pl->offF, pl->offB, pl->rows_off, pl->coff, pl->ccoff, pl->rows, pl->src,
-            pl->dinv, pl->F, pl->B, pl->contrib, pl->poff, pl->partial};
-  for (int pass = 0; pass < 2; ++pass)
-    for (int q = 0; q < pl->nlaunch; ++q) {
-      const int i = pass == 0 ? q : pl->nlaunch - 1 - q;
-      const bool fwd = pass == 0;
-      const int split = pl->l_split[i];
-      int rc = 0;
-      // forward: pivots first, then the rows below; backward: rows below first, then the pivots
-      if (split && !fwd) { TS_DISPATCH(ts, rc = nd_launch_rect<TS_>(a, pl->l_cfront[i], pl->l_crow0[i], pl->l_nchunk[i], false, out)); }
-      if (rc) return rc;
-      if (split) { TS_DISPATCH(ts, rc = nd_launch_tri<TS_>(a, pl->l_list[i], pl->l_count[i], pl->l_nmax[i], fwd, in, out)); }
-      else { TS_DISPATCH(ts, rc = nd_launch<TS_>(a, pl->l_class[i], pl->l_list[i], pl->l_count[i], 0, fwd, in, out)); }
-      if (rc) return rc;
-      if (split && fwd) { TS_DISPATCH(ts, rc = nd_launch_rect<TS_>(a, pl->l_cfront[i], pl->l_crow0[i], pl->l_nchunk[i], true, out)); }
-      if (rc) return rc;
-    }
+            pl->dinv, pl->F, pl->B, pl->contrib, pl->Y};
+  for (int i = 0; i < pl->nlevel; ++i) {
+    int rc = 0;
+    TS_DISPATCH(ts, rc = nd_launch_fwd<TS_>(a, pl->f_front[i], pl->f_row0[i], pl->f_count[i], in));
+    if (rc) return rc;
+  }
+  for (int i = pl->nlevel - 1; i >= 0; --i) {
+    int rc = 0;
+    TS_DISPATCH(ts, rc = nd_launch_bwd<TS_>(a, pl->b_front[i], pl->b_col0[i], pl->b_count[i], out));
+    if (rc) return rc;
+  }
   return 0;
 }
 

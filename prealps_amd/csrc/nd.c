@@ -9,11 +9,13 @@
  *              that its subtree touches (merged up the tree);
  *   numeric    multifrontal Cholesky on the host threads (one block per thread, dense fronts,
  *              the update matrices handed from child to parent);
- *   storage    per supernode a dense trapezoid (n columns, n + m rows) in HBM, twice: column
- *              major with every column divided by its pivot for the forward sweep, row major for
- *              the backward sweep -- each sweep streams its copy once with coalesced loads;
- *   solve      level by level up the tree and down again (kernels.hip: k_nd_forward /
- *              k_nd_backward), one workgroup per supernode, t right-hand sides at once.
+ *   storage    per supernode a dense trapezoid (n columns, n + m rows) in HBM in "selective
+ *              inversion" form: the triangle holds T = (L_11 D^-1)^-1, the rows below
+ *              -G = -(L_21 D^-1) T (D = diag L_11), so that the solves are products, not
+ *              recurrences; twice -- column major for the forward sweep, row major for the
+ *              backward sweep -- each sweep streams its copy once with coalesced loads;
+ *   solve      level by level up the forest and down again (kernels.hip: k_nd_forward /
+ *              k_nd_backward), one launch per level, t right-hand sides at once.
  *
  * Against the band factor of a 18^3-node elasticity block (17.5 k rows, band 1031: 281 MB in two
  * copies) this needs ~130 MB, and a level of the tree is thousands of independent workgroups
@@ -34,10 +36,8 @@ typedef struct {
   int* d_n; int* d_m; int* d_ld; long long* d_offF; long long* d_offB; int* d_rows_off;
   int* d_coff; int* d_ccoff; int* d_rows; int* d_src; double* d_dinv; double* d_F; double* d_B;
   double* d_contrib; size_t contrib_rows; int contrib_ts;
-  int nlaunch; int* l_height; int* l_class; int* l_count; int** l_list; const int** l_list_c;
-  /* split fronts */
-  int* l_split; int* l_nchunk; int* l_nmax; int** l_cfront; int** l_crow0; const int** l_cfront_c; const int** l_crow0_c;
-  long long* d_poff; double* d_partial; size_t partial_rows;
+  double* d_Y; int m_local; double inv_dev;
+  int nlevel; int* f_count; int** f_front; int** f_row0; int* b_count; int** b_front; int** b_col0;
   double bytes;
 } pa_nd_t;
 
@@ -51,10 +51,14 @@ void pa_nd_free(void) {
   pa_rt_free(s->d_n); pa_rt_free(s->d_m); pa_rt_free(s->d_ld); pa_rt_free(s->d_offF); pa_rt_free(s->d_offB);
   pa_rt_free(s->d_rows_off); pa_rt_free(s->d_coff); pa_rt_free(s->d_ccoff); pa_rt_free(s->d_rows); pa_rt_free(s->d_src);
   pa_rt_free(s->d_dinv); pa_rt_free(s->d_F); pa_rt_free(s->d_B); pa_rt_free(s->d_contrib);
-  for (int i = 0; i < s->nlaunch; ++i) { pa_rt_free(s->l_list[i]); if (s->l_cfront) pa_rt_free(s->l_cfront[i]); if (s->l_crow0) pa_rt_free(s->l_crow0[i]); }
-  free(s->l_height); free(s->l_class); free(s->l_count); free(s->l_list); free(s->l_list_c);
-  free(s->l_split); free(s->l_nchunk); free(s->l_nmax); free(s->l_cfront); free(s->l_crow0); free(s->l_cfront_c); free(s->l_crow0_c);
-  pa_rt_free(s->d_poff); pa_rt_free(s->d_partial);
+  for (int i = 0; i < s->nlevel; ++i) {
+    if (s->f_front) pa_rt_free(s->f_front[i]);
+    if (s->f_row0) pa_rt_free(s->f_row0[i]);
+    if (s->b_front) pa_rt_free(s->b_front[i]);
+    if (s->b_col0) pa_rt_free(s->b_col0[i]);
+  }
+  free(s->f_count); free(s->f_front); free(s->f_row0); free(s->b_count); free(s->b_front); free(s->b_col0);
+  pa_rt_free(s->d_Y);
   memset(s, 0, sizeof(*s));
 }
 
@@ -115,8 +119,7 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
    * the whole sweep.  Same entries, same arithmetic. */
   {
     const char* we = getenv("PREALPS_ND_WIDTH");
-    int width = we ? atoi(we) : 256;
-    if (width > pa_nd_tri_cols()) width = pa_nd_tri_cols();      /* (what k_nd_tri_* takes) */
+    const int width = we ? atoi(we) : 512;
     const int n0 = B->tree.nsn;
     int extra_tot = 0;
     int* base = (int*)malloc(((size_t)n0 + 1) * sizeof(int));
@@ -266,35 +269,20 @@ static int front_factor(int f, int n, double* F) {
   return 0;
 }
 
-/* Which fronts the device handles in two grids (k_nd_tri_* for the n pivot rows, k_nd_rect_* for the
- * m rows below): every front above PREALPS_ND_SPLIT rows (512), and every front with at least
- * PREALPS_ND_TRI_COLS pivot columns (64) -- a workgroup that owns such a front alone walks a chain
- * of 64-pivot steps, 15 us each.  Read once, before any thread asks. */
-static int g_split_rows = -1, g_split_cols = -1;
-static void nd_split_config(void) {
-  const char* se = getenv("PREALPS_ND_SPLIT");
-  const char* ce = getenv("PREALPS_ND_TRI_COLS");
-  g_split_rows = se ? atoi(se) : 512;
-  g_split_cols = ce ? atoi(ce) : 64;
-}
-static int nd_is_split(int n, int m) {
-  if (g_split_rows <= 0 || n > pa_nd_tri_cols()) return 0;
-  return n + m > g_split_rows || (g_split_cols > 0 && n >= g_split_cols);
-}
-
-/* The triangular part of a split front is applied as a product, not as a recurrence: the strictly
- * lower entries of T = (I + Lhat_11)^-1 (unit lower triangular; Lhat_11 = the strictly lower part of
- * L_11 diag(L_11)^-1) replace Lhat_11 in the forward copy, and the same numbers, transposed access,
- * replace it in the backward copy: forward a = T w, backward z = T^T (D^-1 rhs) -- exactly
- * transposed operators, so the block solve stays symmetric.  Returns max |T (I + Lhat) - I|. */
-static double nd_invert_tri(int n, int ld, int ldb, double* pf, double* pb, double* wk) {
-  double* Lc = wk;                 /* n x n copy of I + Lhat (column major, ld n) */
+/* Selective inversion of a factored front, in place in the forward copy (column major, leading
+ * dimension ld, columns already divided by their pivots: I + Lhat_11 on top, Lhat_21 below):
+ *   triangle   <- strictly lower part of T = (I + Lhat_11)^-1 (unit lower triangular),
+ *   rows below <- -G, G = Lhat_21 T.
+ * With these the solves are products (kernels.hip): forward a = T w and contribution -= G w,
+ * backward z_1 = T^T D^-1 y_1 - G^T z_2 -- exactly transposed operators, so the block solve stays
+ * symmetric.  wk: n * n + n doubles.  Returns the largest entry of T (I + Lhat_11) - I. */
+static double nd_selinv(int n, int m, int ld, double* pf, double* wk) {
+  double* Lc = wk;                 /* n x n copy of I + Lhat_11 (column major, ld n) */
   double* t = wk + (size_t)n * n;  /* one column of T */
   for (int j = 0; j < n; ++j) {
     for (int i = 0; i <= j; ++i) Lc[(size_t)j * n + i] = i == j ? 1.0 : 0.0;
     for (int i = j + 1; i < n; ++i) Lc[(size_t)j * n + i] = pf[(size_t)j * ld + i];
   }
-  double dev = 0.0;
   for (int j = 0; j < n; ++j) {
     for (int i = j + 1; i < n; ++i) t[i] = 0.0;
     t[j] = 1.0;
@@ -304,10 +292,11 @@ static double nd_invert_tri(int n, int ld, int ldb, double* pf, double* pb, doub
       const double* lk = Lc + (size_t)k * n;
       for (int i = k + 1; i < n; ++i) t[i] -= lk[i] * tk;
     }
-    for (int i = j + 1; i < n; ++i) { pf[(size_t)j * ld + i] = t[i]; pb[(size_t)i * ldb + j] = t[i]; }
+    for (int i = j + 1; i < n; ++i) pf[(size_t)j * ld + i] = t[i];
   }
   /* T (I + Lhat) - I: T was built as a right inverse, column by column, so the product in the other
    * order is an independent check (the one in the building order cancels exactly) */
+  double dev = 0.0;
   for (int j = 0; j < n; ++j)
     for (int i = j + 1; i < n; ++i) {
       double sm = Lc[(size_t)j * n + i];                       /* k = i: T(i,i) = 1 */
@@ -315,14 +304,56 @@ static double nd_invert_tri(int n, int ld, int ldb, double* pf, double* pb, doub
       sm += pf[(size_t)j * ld + i];                            /* k = j: Lc(j,j) = 1 */
       if (fabs(sm) > dev) dev = fabs(sm);
     }
+  /* G(:, j) = Lhat_21(:, j) + sum_{k > j} T(k, j) Lhat_21(:, k): ascending j overwrites column j when no
+   * later column needs it any more; four columns j at a time share the loads of column k */
+  if (m > 0) {
+    double* R = pf + n;            /* rows below: R[j * ld + i], i < m */
+    for (int j0 = 0; j0 < n; j0 += 4) {
+      const int nb = n - j0 < 4 ? n - j0 : 4;
+      for (int c = 0; c < nb; ++c) {          /* the corner inside the group */
+        double* gj = R + (size_t)(j0 + c) * ld;
+        for (int k = j0 + c + 1; k < j0 + nb; ++k) {
+          const double tk = pf[(size_t)(j0 + c) * ld + k];
+          const double* rk = R + (size_t)k * ld;
+          for (int i = 0; i < m; ++i) gj[i] += tk * rk[i];
+        }
+      }
+      if (nb == 4) {
+        double* restrict g0 = R + (size_t)j0 * ld; double* restrict g1 = g0 + ld;
+        double* restrict g2 = g1 + ld; double* restrict g3 = g2 + ld;
+        for (int i0 = 0; i0 < m; i0 += 512) {   /* row tiles: the four output tiles stay in L1 */
+          const int i1 = i0 + 512 < m ? i0 + 512 : m;
+          for (int k = j0 + 4; k < n; ++k) {
+            const double t0 = pf[(size_t)j0 * ld + k], t1 = pf[(size_t)(j0 + 1) * ld + k];
+            const double t2 = pf[(size_t)(j0 + 2) * ld + k], t3 = pf[(size_t)(j0 + 3) * ld + k];
+            const double* restrict rk = R + (size_t)k * ld;
+            for (int i = i0; i < i1; ++i) {
+              const double v = rk[i];
+              g0[i] += t0 * v; g1[i] += t1 * v; g2[i] += t2 * v; g3[i] += t3 * v;
+            }
+          }
+        }
+      } else {
+        for (int c = 0; c < nb; ++c) {
+          double* gj = R + (size_t)(j0 + c) * ld;
+          for (int k = j0 + nb; k < n; ++k) {
+            const double tk = pf[(size_t)(j0 + c) * ld + k];
+            const double* rk = R + (size_t)k * ld;
+            for (int i = 0; i < m; ++i) gj[i] += tk * rk[i];
+          }
+        }
+      }
+    }
+    for (int j = 0; j < n; ++j) { double* gj = R + (size_t)j * ld; for (int i = 0; i < m; ++i) gj[i] = -gj[i]; }
+  }
   return dev;
 }
 
 /* Multifrontal factorisation of one block into the two panel copies (host staging buffers hF, hB,
  * laid out supernode after supernode) and dinv (1 / L_jj per new index).  *fail = 1 + new index
- * of a non-positive pivot.  invert: 1 = the split fronts get nd_invert_tri (what the device
- * kernels expect), 0 = plain factor everywhere (selfcheck). */
-static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv, int* fail, int invert) {
+ * of a non-positive pivot.  invert: 1 = panels in selective-inversion form (nd_selinv; what the
+ * device kernels expect; *dev = largest deviation of an inverse), 0 = the plain factor (selfcheck). */
+static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv, int* fail, int invert, double* dev) {
   const int nsn = B->tree.nsn, b = B->b;
   double** upd = (double**)calloc((size_t)nsn, sizeof(double*));     /* update matrices waiting for the parent */
   int* loc = (int*)malloc((size_t)b * sizeof(int));
@@ -368,11 +399,16 @@ static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv,
       const int kmax = i < n ? i : n;
       for (int k = 0; k < kmax; ++k) pb[(size_t)i * ldb + k] = F[(size_t)k * f + i] * sc;
     }
-    if (invert && n > 1 && nd_is_split(n, m)) {
+    if (invert) {
       double* wk = (double*)malloc(((size_t)n * n + n) * sizeof(double));
       if (!wk) { free(F); rc = 1; break; }
-      nd_invert_tri(n, ld, ldb, pf, pb, wk);
+      const double d = nd_selinv(n, m, ld, pf, wk);
+      if (dev && d > *dev) *dev = d;
       free(wk);
+      for (int i = 0; i < f; ++i) {            /* the row-major copy: the same numbers */
+        const int kmax = i < n ? i : n;
+        for (int k = 0; k < kmax; ++k) pb[(size_t)i * ldb + k] = pf[(size_t)k * ld + i];
+      }
     }
     oF += (long long)ld * n; oB += (long long)ldb * f;
     if (m > 0 && B->tree.parent[s] >= 0) {
@@ -397,7 +433,6 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
   pa_nd_t* S = &g_nd;
   const char* le = getenv("PREALPS_ND_LEAF");
   const int leaf_rows = le ? atoi(le) : 96;
-  nd_split_config();
   nd_block_t* B = (nd_block_t*)calloc((size_t)nblk, sizeof(nd_block_t));
   if (!B) return PA_FAIL("out of host memory");
   int rc = 0;
@@ -490,17 +525,20 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
   /* numeric factorisation, block after block on the host threads, each block uploaded when done */
   if (!rc) {
     int fail_new = 0, fail_blk = -1;
+    double inv_dev = 0.0;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int x = 0; x < nblk; ++x) {
       if (rc) continue;
       double* hF = (double*)malloc((size_t)(B[x].nF ? B[x].nF : 1) * sizeof(double));
       double* hB = (double*)malloc((size_t)(B[x].nB ? B[x].nB : 1) * sizeof(double));
       double* di = (double*)malloc((size_t)B[x].b * sizeof(double));
-      int fail = 0, r2 = (!hF || !hB || !di) ? 1 : nd_numeric(&B[x], hF, hB, di, &fail, 1);
+      double dv = 0.0;
+      int fail = 0, r2 = (!hF || !hB || !di) ? 1 : nd_numeric(&B[x], hF, hB, di, &fail, 1, &dv);
       if (!r2) {
         for (int i = 0; i < B[x].b; ++i) h_dinv[B[x].row0 + B[x].tree.perm[i]] = di[i];
 #pragma omp critical
         {
+          if (dv > inv_dev) inv_dev = dv;
           if (pa_rt_h2d(S->d_F + bF[x], hF, (size_t)B[x].nF * sizeof(double)) ||
               pa_rt_h2d(S->d_B + bB[x], hB, (size_t)B[x].nB * sizeof(double))) r2 = 3;
         }
@@ -513,6 +551,10 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
     }
     if (rc == 2) { *fail_row = B[fail_blk].row0 + B[fail_blk].tree.perm[fail_new - 1]; }
     else if (rc) rc = PA_FAIL("factorising the large diagonal blocks failed (%s)", rc == 3 ? pa_rt_error() : "out of host memory");
+    S->inv_dev = inv_dev;
+    if (!rc && inv_dev > 1e-6)
+      fprintf(stderr, "[prealps_hip] warning: the pivot triangles of the sparse block factor are ill conditioned "
+                      "(inverse off by %.1e); the block solve loses that much accuracy\n", inv_dev);
   }
   if (!rc) {
     int bad = pa_rt_h2d(S->d_n, h_n, (size_t)nsn * sizeof(int)) || pa_rt_h2d(S->d_m, h_m, (size_t)nsn * sizeof(int)) ||
@@ -524,82 +566,56 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
               pa_rt_h2d(S->d_dinv, h_dinv, (size_t)m_local * sizeof(double));
     if (bad) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
   }
-  /* launch lists: by height, then by size class.  Split fronts (nd_is_split) form one list per
-   * height: the triangular part goes to k_nd_tri_* (one workgroup each), the rows below to a second
-   * grid in chunks of pa_nd_chunk_rows() rows, so that the few large fronts at the top of the tree
-   * occupy the whole chip. */
-  long long totp = 0;
+  /* launch lists, one level of the forest per launch: forward workgroups = (front, chunk of
+   * pa_nd_chunk_rows() front rows), backward workgroups = (front, block of pa_nd_block_cols()
+   * pivot columns) */
   if (!rc) {
-    const int ncls = pa_nd_num_classes(), CH = pa_nd_chunk_rows();
-    int cap = 2 * (maxh + 1) * ncls;
-    S->l_height = (int*)calloc((size_t)cap, sizeof(int)); S->l_class = (int*)calloc((size_t)cap, sizeof(int));
-    S->l_count = (int*)calloc((size_t)cap, sizeof(int)); S->l_list = (int**)calloc((size_t)cap, sizeof(int*));
-    S->l_list_c = (const int**)calloc((size_t)cap, sizeof(int*));
-    S->l_split = (int*)calloc((size_t)cap, sizeof(int)); S->l_nchunk = (int*)calloc((size_t)cap, sizeof(int));
-    S->l_nmax = (int*)calloc((size_t)cap, sizeof(int));
-    S->l_cfront = (int**)calloc((size_t)cap, sizeof(int*)); S->l_crow0 = (int**)calloc((size_t)cap, sizeof(int*));
-    S->l_cfront_c = (const int**)calloc((size_t)cap, sizeof(int*)); S->l_crow0_c = (const int**)calloc((size_t)cap, sizeof(int*));
-    int* tmp = (int*)malloc((size_t)nsn * sizeof(int));
-    int* cls_of = (int*)malloc((size_t)nsn * sizeof(int));
-    char* is_split = (char*)calloc((size_t)nsn, 1);
-    long long* h_poff = (long long*)calloc((size_t)nsn, sizeof(long long));
-    for (int g = 0; g < nsn && !rc; ++g) {
-      int f = h_n[g] + h_m[g];
-      is_split[g] = (char)(h_n[g] > 1 && nd_is_split(h_n[g], h_m[g]));
-      cls_of[g] = is_split[g] ? 0 : pa_nd_class_of(f);
-      if (cls_of[g] < 0) rc = PA_FAIL("block solve: a front of %d rows exceeds the kernel's limit; use more subdomains", f);
-      if (is_split[g]) { h_poff[g] = totp; totp += (long long)((h_m[g] + CH - 1) / CH) * h_n[g]; }
+    const int CH = pa_nd_chunk_rows(), CB = pa_nd_block_cols();
+    S->nlevel = maxh + 1;
+    S->f_count = (int*)calloc((size_t)S->nlevel, sizeof(int)); S->b_count = (int*)calloc((size_t)S->nlevel, sizeof(int));
+    S->f_front = (int**)calloc((size_t)S->nlevel, sizeof(int*)); S->f_row0 = (int**)calloc((size_t)S->nlevel, sizeof(int*));
+    S->b_front = (int**)calloc((size_t)S->nlevel, sizeof(int*)); S->b_col0 = (int**)calloc((size_t)S->nlevel, sizeof(int*));
+    if (!S->f_count || !S->b_count || !S->f_front || !S->f_row0 || !S->b_front || !S->b_col0) rc = PA_FAIL("out of host memory for the block-solve plan");
+    for (int h = 0; h <= maxh && !rc; ++h) {
+      long long nf = 0, nb = 0;
+      for (int g = 0; g < nsn; ++g) if (h_height[g] == h) { nf += (h_n[g] + h_m[g] + CH - 1) / CH; nb += (h_n[g] + CB - 1) / CB; }
+      if (nf > 2147483000LL || nb > 2147483000LL) { rc = PA_FAIL("block solve: too many workgroups in one level"); break; }
+      int* ff = (int*)malloc((size_t)(nf ? nf : 1) * sizeof(int)); int* fr = (int*)malloc((size_t)(nf ? nf : 1) * sizeof(int));
+      int* bf = (int*)malloc((size_t)(nb ? nb : 1) * sizeof(int)); int* bc = (int*)malloc((size_t)(nb ? nb : 1) * sizeof(int));
+      if (!ff || !fr || !bf || !bc) { free(ff); free(fr); free(bf); free(bc); rc = PA_FAIL("out of host memory for the block-solve plan"); break; }
+      long long x = 0, y = 0;
+      for (int g = 0; g < nsn; ++g) if (h_height[g] == h) {
+        for (int r0 = 0; r0 < h_n[g] + h_m[g]; r0 += CH) { ff[x] = g; fr[x++] = r0; }
+        for (int k0 = 0; k0 < h_n[g]; k0 += CB) { bf[y] = g; bc[y++] = k0; }
+      }
+      S->f_count[h] = (int)nf; S->b_count[h] = (int)nb;
+      S->f_front[h] = (int*)pa_rt_malloc((size_t)(nf ? nf : 1) * sizeof(int)); S->f_row0[h] = (int*)pa_rt_malloc((size_t)(nf ? nf : 1) * sizeof(int));
+      S->b_front[h] = (int*)pa_rt_malloc((size_t)(nb ? nb : 1) * sizeof(int)); S->b_col0[h] = (int*)pa_rt_malloc((size_t)(nb ? nb : 1) * sizeof(int));
+      if (!S->f_front[h] || !S->f_row0[h] || !S->b_front[h] || !S->b_col0[h] ||
+          pa_rt_h2d(S->f_front[h], ff, (size_t)nf * sizeof(int)) || pa_rt_h2d(S->f_row0[h], fr, (size_t)nf * sizeof(int)) ||
+          pa_rt_h2d(S->b_front[h], bf, (size_t)nb * sizeof(int)) || pa_rt_h2d(S->b_col0[h], bc, (size_t)nb * sizeof(int)))
+        rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
+      free(ff); free(fr); free(bf); free(bc);
     }
-    for (int h = 0; h <= maxh && !rc; ++h)
-      for (int sp = 0; sp < 2 && !rc; ++sp)
-        for (int c = 0; c < ncls && !rc; ++c) {
-          int cntl = 0, nchunk = 0, nmax = 0;
-          for (int g = 0; g < nsn; ++g) if (h_height[g] == h && cls_of[g] == c && is_split[g] == sp) {
-            tmp[cntl++] = g;
-            if (sp) { nchunk += (h_m[g] + CH - 1) / CH; if (h_n[g] > nmax) nmax = h_n[g]; }
-          }
-          if (!cntl) continue;
-          int i = S->nlaunch++;
-          S->l_height[i] = h; S->l_class[i] = c; S->l_count[i] = cntl; S->l_split[i] = sp; S->l_nchunk[i] = nchunk; S->l_nmax[i] = nmax;
-          S->l_list[i] = (int*)pa_rt_malloc((size_t)cntl * sizeof(int));
-          if (!S->l_list[i] || pa_rt_h2d(S->l_list[i], tmp, (size_t)cntl * sizeof(int))) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
-          S->l_list_c[i] = S->l_list[i];
-          if (sp && nchunk > 0 && !rc) {
-            int* cf = (int*)malloc((size_t)nchunk * sizeof(int));
-            int* cr = (int*)malloc((size_t)nchunk * sizeof(int));
-            int x = 0;
-            for (int q = 0; q < cntl; ++q) for (int r0 = 0; r0 < h_m[tmp[q]]; r0 += CH) { cf[x] = tmp[q]; cr[x++] = r0; }
-            S->l_cfront[i] = (int*)pa_rt_malloc((size_t)nchunk * sizeof(int));
-            S->l_crow0[i] = (int*)pa_rt_malloc((size_t)nchunk * sizeof(int));
-            if (!S->l_cfront[i] || !S->l_crow0[i] || pa_rt_h2d(S->l_cfront[i], cf, (size_t)nchunk * sizeof(int)) ||
-                pa_rt_h2d(S->l_crow0[i], cr, (size_t)nchunk * sizeof(int)))
-              rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
-            S->l_cfront_c[i] = S->l_cfront[i]; S->l_crow0_c[i] = S->l_crow0[i];
-            free(cf); free(cr);
-          }
-        }
-    if (!rc) {
-      S->d_poff = (long long*)pa_rt_malloc((size_t)nsn * sizeof(long long));
-      if (!S->d_poff || pa_rt_h2d(S->d_poff, h_poff, (size_t)nsn * sizeof(long long))) rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
-    }
-    free(tmp); free(cls_of); free(is_split); free(h_poff);
   }
   free(h_n); free(h_m); free(h_ld); free(h_offF); free(h_offB); free(h_rows_off); free(h_coff); free(h_ccoff);
   free(h_rows); free(h_src); free(h_height); free(h_dinv); free(sn0); free(bF); free(bB);
   for (int x = 0; x < nblk; ++x) nd_block_free(&B[x]);
   free(B);
   if (rc) { pa_nd_free(); return rc == 2 ? 2 : 1; }
-  S->nsn = nsn; S->contrib_rows = (size_t)totc; S->partial_rows = (size_t)totp; S->bytes = 8.0 * (double)(totF + totB);
+  S->nsn = nsn; S->contrib_rows = (size_t)totc; S->m_local = m_local; S->bytes = 8.0 * (double)(totF + totB);
   pa_nd_plan_t* pl = &S->plan;
   pl->n = S->d_n; pl->m = S->d_m; pl->ld = S->d_ld; pl->offF = S->d_offF; pl->offB = S->d_offB; pl->rows_off = S->d_rows_off;
   pl->coff = S->d_coff; pl->ccoff = S->d_ccoff; pl->rows = S->d_rows; pl->src = S->d_src; pl->dinv = S->d_dinv;
   pl->F = S->d_F; pl->B = S->d_B;
-  pl->nlaunch = S->nlaunch; pl->l_class = S->l_class; pl->l_count = S->l_count; pl->l_list = S->l_list_c;
-  pl->l_split = S->l_split; pl->l_nchunk = S->l_nchunk; pl->l_nmax = S->l_nmax;
-  pl->l_cfront = S->l_cfront_c; pl->l_crow0 = S->l_crow0_c; pl->poff = S->d_poff;
+  pl->nlevel = S->nlevel; pl->f_count = S->f_count; pl->b_count = S->b_count;
+  pl->f_front = (const int* const*)S->f_front; pl->f_row0 = (const int* const*)S->f_row0;
+  pl->b_front = (const int* const*)S->b_front; pl->b_col0 = (const int* const*)S->b_col0;
   S->created = 1;
   return 0;
 }
+
+double pa_nd_inverse_deviation(void) { return g_nd.created ? g_nd.inv_dev : 0.0; }
 
 /* out(rows of the ND blocks) = blockdiag^-1 in(...) for the ts-strided panels */
 int pa_nd_apply(int ts, const double* in, double* out) {
@@ -607,14 +623,14 @@ int pa_nd_apply(int ts, const double* in, double* out) {
   if (!S->created) return 0;
   if (S->contrib_ts < ts) {
     pa_rt_free(S->d_contrib);
-    pa_rt_free(S->d_partial);
+    pa_rt_free(S->d_Y);
     S->d_contrib = (double*)pa_rt_malloc((S->contrib_rows ? S->contrib_rows : 1) * (size_t)ts * sizeof(double));
-    S->d_partial = (double*)pa_rt_malloc((S->partial_rows ? S->partial_rows : 1) * (size_t)ts * sizeof(double));
-    if (!S->d_contrib || !S->d_partial) return PA_FAIL("block solve: scratch of %zu + %zu rows: %s", S->contrib_rows, S->partial_rows, pa_rt_error());
+    S->d_Y = (double*)pa_rt_malloc((size_t)(S->m_local ? S->m_local : 1) * (size_t)ts * sizeof(double));
+    if (!S->d_contrib || !S->d_Y) return PA_FAIL("block solve: scratch of %zu + %d rows: %s", S->contrib_rows, S->m_local, pa_rt_error());
     S->contrib_ts = ts;
   }
   S->plan.contrib = S->d_contrib;
-  S->plan.partial = S->d_partial;
+  S->plan.Y = S->d_Y;
   if (pa_k_nd_apply(&S->plan, ts, in, out)) return PA_FAIL("block-solve kernel launch failed");
   return 0;
 }
@@ -625,8 +641,8 @@ int pa_nd_apply(int ts, const double* in, double* out) {
  * [2] rows of the largest front, [3] height of the tree, [4] ||L L^T x - A x|| / ||A x|| for a
  * fixed pseudo-random x with L rebuilt from the forward panels, [5] the largest relative
  * difference between the backward panels and the same entries of the forward panels, [6] the
- * largest entry of T (I + Lhat_11) - I over the triangular inverses (nd_invert_tri), [7] the
- * number of fronts the device would handle as split fronts.
+ * largest entry of T (I + Lhat_11) - I and of G (I + Lhat_11) - Lhat_21 over all fronts (the
+ * selective-inversion form the device kernels use, nd_selinv), [7] the widest supernode.
  * It multiplies with the factor, it does not solve: there is no CPU solve path in this library. */
 int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const double* val, int leaf_rows,
                              double* stats) {
@@ -647,7 +663,7 @@ int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const 
   int fail = 0;
   if (!hF || !hB || !di || !x || !u || !w || !ax) rc = PA_FAIL("out of host memory");
   if (!rc) {
-    rc = nd_numeric(&B, hF, hB, di, &fail, 0);
+    rc = nd_numeric(&B, hF, hB, di, &fail, 0, NULL);
     if (rc == 2) rc = PA_FAIL("matrix is not SPD (row %d)", B.tree.perm[fail - 1]);
     else if (rc) rc = PA_FAIL("out of host memory");
   }
@@ -704,25 +720,33 @@ int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const 
                   B.tree.first[s2 + 1] - B.tree.first[s2], B.m[s2]);
     stats[0] = B.tree.nsn; stats[1] = (double)B.nF; stats[2] = maxf; stats[3] = maxh;
     stats[4] = sqrt(num / (den > 0.0 ? den : 1.0)); stats[5] = dmax;
-    /* the explicit inverses the device uses for the triangular part of split fronts: here of EVERY
-     * supernode the triangular kernels could take, so that small test matrices exercise it too */
+    /* the selective-inversion form the device works with: T must invert the pivot triangle, and
+     * G (I + Lhat_11) must give Lhat_21 back */
     double dev = 0.0;
-    int nsplit = 0;
-    nd_split_config();
-    oF = 0; oB = 0;
+    int widest = 0;
+    oF = 0;
     for (int s = 0; s < B.tree.nsn && !rc; ++s) {
-      int ns = B.tree.first[s + 1] - B.tree.first[s], m = B.m[s], f = ns + m, ld = (f + 1) & ~1, ldb = (ns + 1) & ~1;
-      if (ns > 1 && ns <= pa_nd_tri_cols()) {
-        double* wk = (double*)malloc(((size_t)ns * ns + ns) * sizeof(double));
-        if (!wk) { rc = PA_FAIL("out of host memory"); break; }
-        double d = nd_invert_tri(ns, ld, ldb, hF + oF, hB + oB, wk);
-        if (d > dev) dev = d;
-        free(wk);
-      }
-      nsplit += ns > 1 && nd_is_split(ns, m);
-      oF += (long long)ld * ns; oB += (long long)ldb * f;
+      int ns = B.tree.first[s + 1] - B.tree.first[s], m = B.m[s], f = ns + m, ld = (f + 1) & ~1;
+      double* pf = hF + oF;
+      double* wk = (double*)malloc(((size_t)ns * ns + ns + (size_t)ns * (m ? m : 1)) * sizeof(double));
+      if (!wk) { rc = PA_FAIL("out of host memory"); break; }
+      double* L21 = wk + (size_t)ns * ns + ns;           /* Lhat_21 before it is overwritten */
+      for (int j = 0; j < ns; ++j) memcpy(L21 + (size_t)j * m, pf + (size_t)j * ld + ns, (size_t)m * sizeof(double));
+      double d = nd_selinv(ns, m, ld, pf, wk);
+      if (d > dev) dev = d;
+      /* wk[0 .. ns*ns) still holds I + Lhat_11 (column major, ld ns) */
+      for (int j = 0; j < ns; ++j)
+        for (int i = 0; i < m; ++i) {
+          double sm = 0.0;                                /* (G (I + Lhat_11))(i, j) = sum_{k >= j} G(i,k) Lc(k,j) */
+          for (int k = j; k < ns; ++k) sm += -pf[(size_t)k * ld + ns + i] * wk[(size_t)j * ns + k];
+          sm -= L21[(size_t)j * m + i];
+          if (fabs(sm) > dev) dev = fabs(sm);
+        }
+      free(wk);
+      if (ns > widest) widest = ns;
+      oF += (long long)ld * ns;
     }
-    stats[6] = dev; stats[7] = nsplit;
+    stats[6] = dev; stats[7] = widest;
   }
   free(hF); free(hB); free(di); free(x); free(u); free(w); free(ax);
   nd_block_free(&B);

@@ -199,33 +199,23 @@ int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out)
 
 /* ---- sparse block solve for large diagonal blocks (nd.c) --------------------------------- */
 /* Supernodes of a nested-dissection Cholesky factor, all blocks of the process in one numbering.
- * Supernode s: n[s] pivot columns, m[s] rows below; forward panel F + offF[s], column major,
- * leading dimension ld[s] >= n + m, column j divided by its pivot; backward panel B + offB[s],
- * row major with row length (n + 1) & ~1: L(i, k) for the rows below, L(i, k) / L(i, i) for the
- * pivot rows.  rows[rows_off[s] + r] = local panel row of front row r; src[2 (rows_off[s] + r) + c]
- * = where front row r finds the contribution of child c (row of its vector, -1: none), that
- * vector starting at row ccoff[2 s + c] of `contrib`; this supernode's own contribution starts
- * at row coff[s].  dinv[local row] = 1 / L(row, row). */
+ * Supernode s: n[s] pivot columns, m[s] rows below, panel P = [T ; -G] (see kernels.hip) twice:
+ * F + offF[s] column major with leading dimension ld[s] >= n + m, B + offB[s] row major with row
+ * length (n + 1) & ~1; only the entries below the diagonal are read.  rows[rows_off[s] + r] =
+ * local panel row of front row r; src[2 (rows_off[s] + r) + c] = where front row r finds the
+ * contribution of child c (row of its vector, -1: none), that vector starting at row
+ * ccoff[2 s + c] of `contrib`; this supernode's own contribution starts at row coff[s].
+ * dinv[local row] = 1 / L(row, row).  Y: scratch panel for the forward result (local rows). */
 typedef struct {
   const int* n; const int* m; const int* ld; const long long* offF; const long long* offB; const int* rows_off;
   const int* coff; const int* ccoff; const int* rows; const int* src; const double* dinv;
-  const double* F; const double* B; double* contrib;
-  int nlaunch;                 /* launches in bottom-up order: (tree height, size class) */
-  const int* l_class;          /* host arrays */
-  const int* l_count;
-  const int* const* l_list;    /* host array of device pointers to supernode ids */
-  /* Large fronts are split: the launch above handles their n pivot rows only, the rows below go to
-   * a second grid in chunks of pa_nd_chunk_rows() rows: l_nchunk[i] (front, first row) pairs.  The
-   * backward sweep leaves per chunk and column a partial sum at row poff[s] + chunk * n + column of
-   * `partial`. */
-  const int* l_split; const int* l_nchunk; const int* l_nmax;
-  const int* const* l_cfront; const int* const* l_crow0;
-  const long long* poff; double* partial;
+  const double* F; const double* B; double* contrib; double* Y;
+  int nlevel;                  /* levels of the forest, bottom-up; host arrays of device pointers: */
+  const int* f_count; const int* const* f_front; const int* const* f_row0;   /* forward: (front, first front row) per workgroup */
+  const int* b_count; const int* const* b_front; const int* const* b_col0;   /* backward: (front, first pivot column) per workgroup */
 } pa_nd_plan_t;
-int pa_nd_chunk_rows(void);
-int pa_nd_tri_cols(void);             /* most pivot columns of a split front (k_nd_tri_*) */
-int pa_nd_num_classes(void);
-int pa_nd_class_of(int front_rows);   /* -1: front too large for the kernels */
+int pa_nd_chunk_rows(void);           /* front rows per forward workgroup */
+int pa_nd_block_cols(void);           /* pivot columns per backward workgroup */
 int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out);
 
 #ifdef __cplusplus

@@ -74,6 +74,7 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
 int pa_nd_apply(int ts, const double* in, double* out);
 void pa_nd_free(void);
 double pa_nd_factor_bytes(void);
+double pa_nd_inverse_deviation(void);   /* largest |T (I + Lhat) - I| over the fronts of the last pa_nd_create */
 int pa_nd_active(void);
 
 double pa_bj_factor_bytes(void);
