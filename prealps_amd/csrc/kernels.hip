@@ -2235,7 +2235,7 @@ __global__ __launch_bounds__(64 * W) void k_nd_backward(nd_args a, const int* __
   __shared__ double vs[NSTG][TS];
   __shared__ double red[W - 1][ND_COLS][TS];
   const int s = cfront[blockIdx.x], k0 = ccol0[blockIdx.x], coff = blockIdx.y * TS;
-  const int n = a.n[s], f = n + a.m[s], ldb = (n + 1) & ~1;
+  const int n = a.n[s], f = n + a.m[s], ldb = PA_ND_LD(n);
   const double* __restrict__ U = a.B + a.offB[s];
   const int* __restrict__ rows = a.rows + a.rows_off[s];
   const int tid = threadIdx.x, kk = tid & 63, q = tid >> 6;

@@ -226,7 +226,7 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
     if (!B->below[s]) { free(ip); free(sn_of); free(mark); free(tmp); return 1; }
     memcpy(B->below[s], tmp, (size_t)l * sizeof(int));
     int n = last - B->tree.first[s];
-    int ld = (n + l + 1) & ~1, ldb = (n + 1) & ~1;
+    int ld = PA_ND_LD(n + l), ldb = PA_ND_LD(n);
     B->nF += (long long)ld * n;
     B->nB += (long long)ldb * (n + l);
     B->rows_total += n + l;
@@ -353,8 +353,10 @@ static double nd_selinv(int n, int m, int ld, double* pf, double* wk) {
  * laid out supernode after supernode) and dinv (1 / L_jj per new index).  *fail = 1 + new index
  * of a non-positive pivot.  invert: 1 = panels in selective-inversion form (nd_selinv; what the
  * device kernels expect; *dev = largest deviation of an inverse), 0 = the plain factor (selfcheck). */
+static double g_cpu_factor, g_cpu_selinv;   /* PREALPS_ND_TRACE: CPU seconds over all threads */
 static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv, int* fail, int invert, double* dev) {
   const int nsn = B->tree.nsn, b = B->b;
+  double t_fac = 0.0, t_inv = 0.0;
   double** upd = (double**)calloc((size_t)nsn, sizeof(double*));     /* update matrices waiting for the parent */
   int* loc = (int*)malloc((size_t)b * sizeof(int));
   if (!upd || !loc) { free(upd); free(loc); return 1; }
@@ -380,11 +382,13 @@ static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv,
       }
       free(upd[ch]); upd[ch] = NULL;
     }
+    double tt = pa_wtime();
     int bad = front_factor(f, n, F);
+    t_fac += pa_wtime() - tt;
     if (bad) { *fail = c0 + bad; free(F); rc = 2; break; }
     /* panel copies: forward = columns divided by their pivot (unit diagonal implied), backward =
      * row major, the n pivot rows divided by THEIR pivot, the m rows below as they are */
-    const int ld = (f + 1) & ~1, ldb = (n + 1) & ~1;
+    const int ld = PA_ND_LD(f), ldb = PA_ND_LD(n);
     double* pf = hF + oF; double* pb = hB + oB;
     memset(pf, 0, (size_t)ld * n * sizeof(double));
     memset(pb, 0, (size_t)ldb * f * sizeof(double));
@@ -402,7 +406,9 @@ static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv,
     if (invert) {
       double* wk = (double*)malloc(((size_t)n * n + n) * sizeof(double));
       if (!wk) { free(F); rc = 1; break; }
+      tt = pa_wtime();
       const double d = nd_selinv(n, m, ld, pf, wk);
+      t_inv += pa_wtime() - tt;
       if (dev && d > *dev) *dev = d;
       free(wk);
       for (int i = 0; i < f; ++i) {            /* the row-major copy: the same numbers */
@@ -421,6 +427,173 @@ static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv,
   }
   for (int s = 0; s < nsn; ++s) free(upd[s]);
   free(upd); free(loc);
+  if (getenv("PREALPS_ND_TRACE")) {
+#pragma omp critical
+    { g_cpu_factor += t_fac; g_cpu_selinv += t_inv; }
+  }
+  return rc;
+}
+
+/* ---- numeric phase on the device (nd_factor.hip) ---------------------------------------------------------- */
+typedef struct { int* f; int* ti; int* tj; int n; } nd_tiles_t;
+
+static void nd_tiles_free(nd_tiles_t* t) { pa_rt_free(t->f); pa_rt_free(t->ti); pa_rt_free(t->tj); memset(t, 0, sizeof(*t)); }
+
+/* upload the (front, tile row, tile column) list of one level; lower = tiles of the f x f lower
+ * triangle, otherwise the f x n panel */
+static int nd_tiles_build(nd_tiles_t* t, const int* ids, int cnt, const int* h_n, const int* h_m, int lower) {
+  long long tot = 0;
+  for (int q = 0; q < cnt; ++q) {
+    long long ft = (h_n[ids[q]] + h_m[ids[q]] + 63) / 64, nt = (h_n[ids[q]] + 63) / 64;
+    tot += lower ? ft * (ft + 1) / 2 : ft * nt;
+  }
+  memset(t, 0, sizeof(*t));
+  if (tot > 2147483000LL) return 1;
+  int* hf = (int*)malloc((size_t)(tot ? tot : 1) * sizeof(int)); int* hi = (int*)malloc((size_t)(tot ? tot : 1) * sizeof(int));
+  int* hj = (int*)malloc((size_t)(tot ? tot : 1) * sizeof(int));
+  if (!hf || !hi || !hj) { free(hf); free(hi); free(hj); return 1; }
+  long long x = 0;
+  for (int q = 0; q < cnt; ++q) {
+    int g = ids[q], ft = (h_n[g] + h_m[g] + 63) / 64, nt = (h_n[g] + 63) / 64;
+    for (int ti = 0; ti < ft; ++ti)
+      for (int tj = 0; tj < (lower ? ti + 1 : nt); ++tj) { hf[x] = g; hi[x] = ti; hj[x++] = tj; }
+  }
+  t->n = (int)tot;
+  t->f = (int*)pa_rt_malloc((size_t)(tot ? tot : 1) * sizeof(int)); t->ti = (int*)pa_rt_malloc((size_t)(tot ? tot : 1) * sizeof(int));
+  t->tj = (int*)pa_rt_malloc((size_t)(tot ? tot : 1) * sizeof(int));
+  int bad = !t->f || !t->ti || !t->tj || pa_rt_h2d(t->f, hf, (size_t)tot * sizeof(int)) ||
+            pa_rt_h2d(t->ti, hi, (size_t)tot * sizeof(int)) || pa_rt_h2d(t->tj, hj, (size_t)tot * sizeof(int));
+  free(hf); free(hi); free(hj);
+  if (bad) nd_tiles_free(t);
+  return bad;
+}
+
+/* Factor all blocks level by level.  S holds the uploaded plan (n, m, ld, offsets, rows, src, the
+ * forward chunk lists); B the symbolic structure of the blocks, sn0 their first supernode ids.
+ * Returns 0, 1 (resources; PA_FAIL raised) or 2 (*fail_g / *fail_col: first non-positive pivot). */
+static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const int* sn0, int nsn, const int* h_n,
+                             const int* h_m, const int* h_ld, const int* h_rows_off, const int* h_height, int maxh,
+                             long long totrows, int* fail_g, int* fail_col) {
+  int rc = 0;
+  const int trace = getenv("PREALPS_ND_TRACE") != NULL;
+  double t0 = pa_wtime();
+  if (pa_nd_chunk_rows() != 256) return PA_FAIL("block solve: chunk size and factor kernels disagree");
+  int* h_child = (int*)malloc((size_t)2 * nsn * sizeof(int));
+  int* h_parent_h = (int*)malloc((size_t)nsn * sizeof(int));        /* height of the parent, -1 for roots */
+  int* h_newrow = (int*)malloc((size_t)(totrows ? totrows : 1) * sizeof(int));
+  long long* h_acol0 = (long long*)malloc((size_t)nsn * sizeof(long long));
+  unsigned long long* h_front = (unsigned long long*)calloc((size_t)nsn, sizeof(unsigned long long));
+  long long ncp = 0, nnzA = 0;
+  for (int x = 0; x < nblk; ++x) { ncp += B[x].b + 1; nnzA += B[x].cp[B[x].b]; }
+  long long* h_acp = (long long*)malloc((size_t)ncp * sizeof(long long));
+  if (!h_child || !h_parent_h || !h_newrow || !h_acol0 || !h_front || !h_acp) rc = PA_FAIL("out of host memory for the block factorisation");
+  int *d_child = NULL, *d_newrow = NULL, *d_ari = NULL;
+  long long *d_acol0 = NULL, *d_acp = NULL;
+  double* d_acv = NULL;
+  unsigned long long *d_front = NULL, *d_fail = NULL;
+  void** lvl_buf = (void**)calloc((size_t)maxh + 1, sizeof(void*));
+  int* lvl_maxpar = (int*)malloc(((size_t)maxh + 1) * sizeof(int));
+  if (!lvl_buf || !lvl_maxpar) rc = PA_FAIL("out of host memory for the block factorisation");
+  if (!rc) {
+    d_child = (int*)pa_rt_malloc((size_t)2 * nsn * sizeof(int)); d_newrow = (int*)pa_rt_malloc((size_t)(totrows ? totrows : 1) * sizeof(int));
+    d_acol0 = (long long*)pa_rt_malloc((size_t)nsn * sizeof(long long)); d_acp = (long long*)pa_rt_malloc((size_t)ncp * sizeof(long long));
+    d_ari = (int*)pa_rt_malloc((size_t)(nnzA ? nnzA : 1) * sizeof(int)); d_acv = (double*)pa_rt_malloc((size_t)(nnzA ? nnzA : 1) * sizeof(double));
+    d_front = (unsigned long long*)pa_rt_malloc((size_t)nsn * sizeof(unsigned long long));
+    d_fail = (unsigned long long*)pa_rt_malloc(sizeof(unsigned long long));
+    if (!d_child || !d_newrow || !d_acol0 || !d_acp || !d_ari || !d_acv || !d_front || !d_fail)
+      rc = PA_FAIL("allocating the inputs of the block factorisation on the device failed: %s", pa_rt_error());
+  }
+  if (!rc) {
+    long long cpo = 0, eo = 0;
+    for (int h = 0; h <= maxh; ++h) lvl_maxpar[h] = -1;
+    for (int x = 0; x < nblk && !rc; ++x) {
+      const nd_block_t* Bx = &B[x];
+      for (int j = 0; j <= Bx->b; ++j) h_acp[cpo + j] = eo + Bx->cp[j];
+      for (int s = 0; s < Bx->tree.nsn; ++s) {
+        int g = sn0[x] + s, c0 = Bx->tree.first[s], n = h_n[g], m = h_m[g];
+        h_acol0[g] = cpo + c0;
+        for (int c = 0; c < 2; ++c) h_child[2 * g + c] = Bx->child[2 * s + c] < 0 ? -1 : sn0[x] + Bx->child[2 * s + c];
+        int par = Bx->tree.parent[s];
+        h_parent_h[g] = par < 0 ? -1 : h_height[sn0[x] + par];
+        if (h_parent_h[g] > lvl_maxpar[h_height[g]]) lvl_maxpar[h_height[g]] = h_parent_h[g];
+        for (int j = 0; j < n; ++j) h_newrow[h_rows_off[g] + j] = c0 + j;
+        for (int k = 0; k < m; ++k) h_newrow[h_rows_off[g] + n + k] = Bx->below[s][k];
+      }
+      long long ne = Bx->cp[Bx->b];
+      if (ne > 0 && (pa_rt_h2d(d_ari + eo, Bx->ri, (size_t)ne * sizeof(int)) || pa_rt_h2d(d_acv + eo, Bx->cv, (size_t)ne * sizeof(double))))
+        rc = PA_FAIL("uploading the blocks failed: %s", pa_rt_error());
+      cpo += Bx->b + 1; eo += ne;
+    }
+    unsigned long long none = ~0ULL;
+    if (!rc && (pa_rt_h2d(d_child, h_child, (size_t)2 * nsn * sizeof(int)) || pa_rt_h2d(d_newrow, h_newrow, (size_t)totrows * sizeof(int)) ||
+                pa_rt_h2d(d_acol0, h_acol0, (size_t)nsn * sizeof(long long)) || pa_rt_h2d(d_acp, h_acp, (size_t)ncp * sizeof(long long)) ||
+                pa_rt_h2d(d_fail, &none, sizeof(none))))
+      rc = PA_FAIL("uploading the blocks failed: %s", pa_rt_error());
+  }
+  pa_ndf_args_t a;
+  memset(&a, 0, sizeof(a));
+  a.n = S->d_n; a.m = S->d_m; a.ld = S->d_ld; a.offF = S->d_offF; a.offB = S->d_offB; a.rows_off = S->d_rows_off;
+  a.rows = S->d_rows; a.src = S->d_src; a.child = d_child; a.newrow = d_newrow; a.acol0 = d_acol0; a.acp = d_acp;
+  a.ari = d_ari; a.acv = d_acv; a.front = d_front; a.ldf = S->d_ld; a.F = S->d_F; a.B = S->d_B; a.dinv = S->d_dinv; a.fail = d_fail;
+  int* ids = (int*)malloc((size_t)(nsn ? nsn : 1) * sizeof(int));
+  if (!ids && !rc) rc = PA_FAIL("out of host memory for the block factorisation");
+  double front_gb_peak = 0.0, front_gb_now = 0.0;
+  for (int h = 0; h <= maxh && !rc; ++h) {
+    int cnt = 0, nmax = 0;
+    size_t doubles = 0;
+    for (int g = 0; g < nsn; ++g) if (h_height[g] == h) {
+      ids[cnt++] = g;
+      if (h_n[g] > nmax) nmax = h_n[g];
+      doubles += (size_t)h_ld[g] * (size_t)(h_n[g] + h_m[g]);
+    }
+    if (!cnt) continue;
+    lvl_buf[h] = pa_rt_malloc((doubles ? doubles : 1) * sizeof(double));
+    if (!lvl_buf[h]) { rc = PA_FAIL("block factorisation: %.2f GB for the fronts of level %d: %s", 8e-9 * (double)doubles, h, pa_rt_error()); break; }
+    front_gb_now += 8e-9 * (double)doubles;
+    if (front_gb_now > front_gb_peak) front_gb_peak = front_gb_now;
+    size_t off = 0;
+    for (int q = 0; q < cnt; ++q) {
+      h_front[ids[q]] = (unsigned long long)(size_t)((double*)lvl_buf[h] + off);
+      off += (size_t)h_ld[ids[q]] * (size_t)(h_n[ids[q]] + h_m[ids[q]]);
+    }
+    int* d_ids = (int*)pa_rt_malloc((size_t)cnt * sizeof(int));
+    nd_tiles_t ll, rc_t;
+    memset(&ll, 0, sizeof(ll)); memset(&rc_t, 0, sizeof(rc_t));
+    if (!d_ids || pa_rt_h2d(d_ids, ids, (size_t)cnt * sizeof(int)) || pa_rt_h2d(d_front, h_front, (size_t)nsn * sizeof(unsigned long long)) ||
+        nd_tiles_build(&ll, ids, cnt, h_n, h_m, 1) || nd_tiles_build(&rc_t, ids, cnt, h_n, h_m, 0))
+      rc = PA_FAIL("block factorisation: work lists of level %d: %s", h, pa_rt_error());
+    const int* cf = S->f_front[h]; const int* cr = S->f_row0[h]; const int nch = S->f_count[h];
+    if (!rc && pa_k_ndf_assemble(&a, ll.f, ll.ti, ll.tj, ll.n, d_ids, cnt)) rc = PA_FAIL("block factorisation: kernel launch failed");
+    for (int jb = 0; jb < nmax && !rc; jb += 64)
+      if (pa_k_ndf_potrf(&a, d_ids, cnt, jb) || pa_k_ndf_trsm(&a, cf, cr, nch, jb, 0) || pa_k_ndf_update(&a, ll.f, ll.ti, ll.tj, ll.n, jb, 0))
+        rc = PA_FAIL("block factorisation: kernel launch failed");
+    if (!rc && pa_k_ndf_pinit(&a, cf, cr, nch)) rc = PA_FAIL("block factorisation: kernel launch failed");
+    for (int jb = ((nmax - 1) / 64) * 64; jb >= 0 && !rc; jb -= 64)
+      if (pa_k_ndf_trsm(&a, cf, cr, nch, jb, 1) || pa_k_ndf_update(&a, rc_t.f, rc_t.ti, rc_t.tj, rc_t.n, jb, 1))
+        rc = PA_FAIL("block factorisation: kernel launch failed");
+    if (!rc && pa_k_ndf_finalize(&a, rc_t.f, rc_t.ti, rc_t.tj, rc_t.n)) rc = PA_FAIL("block factorisation: kernel launch failed");
+    if (!rc && pa_rt_sync()) rc = PA_FAIL("block factorisation of level %d failed: %s", h, pa_rt_error());
+    pa_rt_free(d_ids); nd_tiles_free(&ll); nd_tiles_free(&rc_t);
+    /* fronts nobody above this level reads any more */
+    for (int l = 0; l <= h; ++l)
+      if (lvl_buf[l] && lvl_maxpar[l] <= h) {
+        size_t dl = 0;
+        for (int g = 0; g < nsn; ++g) if (h_height[g] == l) dl += (size_t)h_ld[g] * (size_t)(h_n[g] + h_m[g]);
+        front_gb_now -= 8e-9 * (double)dl;
+        pa_rt_free(lvl_buf[l]); lvl_buf[l] = NULL;
+      }
+  }
+  if (!rc) {
+    unsigned long long key = ~0ULL;
+    if (pa_rt_d2h(&key, d_fail, sizeof(key))) rc = PA_FAIL("block factorisation: %s", pa_rt_error());
+    else if (key != ~0ULL) { *fail_g = (int)(key >> 32); *fail_col = (int)(key & 0xffffffffULL); rc = 2; }
+  }
+  if (trace) fprintf(stderr, "[nd] numeric phase on the device: %.2f s, at most %.2f GB of fronts at a time\n", pa_wtime() - t0, front_gb_peak);
+  for (int h = 0; lvl_buf && h <= maxh; ++h) pa_rt_free(lvl_buf[h]);
+  free(lvl_buf); free(lvl_maxpar); free(ids);
+  pa_rt_free(d_child); pa_rt_free(d_newrow); pa_rt_free(d_acol0); pa_rt_free(d_acp); pa_rt_free(d_ari); pa_rt_free(d_acv);
+  pa_rt_free(d_front); pa_rt_free(d_fail);
+  free(h_child); free(h_parent_h); free(h_newrow); free(h_acol0); free(h_front); free(h_acp);
   return rc;
 }
 
@@ -437,6 +610,8 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
   if (!B) return PA_FAIL("out of host memory");
   int rc = 0;
   *fail_row = -1;
+  const int trace = getenv("PREALPS_ND_TRACE") != NULL;
+  double t_phase = pa_wtime();
 #pragma omp parallel for schedule(dynamic, 1)
   for (int x = 0; x < nblk; ++x) {
     int q = blocks[x];
@@ -446,6 +621,7 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
     }
   }
   if (rc) { for (int x = 0; x < nblk; ++x) nd_block_free(&B[x]); free(B); return PA_FAIL("nested dissection of the diagonal blocks failed (out of memory)"); }
+  if (trace) { fprintf(stderr, "[nd] ordering + symbolic phase of %d blocks: %.2f s\n", nblk, pa_wtime() - t_phase); t_phase = pa_wtime(); }
   /* global numbering of the supernodes and offsets */
   int nsn = 0, maxh = 0;
   long long totF = 0, totB = 0, totrows = 0, totc = 0;
@@ -478,9 +654,9 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
       long long oF = bF[x], oB = bB[x];
       for (int s = 0; s < Bx->tree.nsn; ++s) {
         int g = sn0[x] + s, c0 = Bx->tree.first[s], n = Bx->tree.first[s + 1] - c0, m = Bx->m[s];
-        h_n[g] = n; h_m[g] = m; h_ld[g] = (n + m + 1) & ~1; h_offF[g] = oF; h_offB[g] = oB;
+        h_n[g] = n; h_m[g] = m; h_ld[g] = PA_ND_LD(n + m); h_offF[g] = oF; h_offB[g] = oB;
         h_rows_off[g] = (int)ro; h_coff[g] = (int)co; h_height[g] = Bx->height[s];
-        oF += (long long)h_ld[g] * n; oB += (long long)((n + 1) & ~1) * (n + m);
+        oF += (long long)h_ld[g] * n; oB += (long long)PA_ND_LD(n) * (n + m);
         for (int j = 0; j < n; ++j) h_rows[ro + j] = Bx->row0 + Bx->tree.perm[c0 + j];
         for (int k = 0; k < m; ++k) h_rows[ro + n + k] = Bx->row0 + Bx->tree.perm[Bx->below[s][k]];
         for (int r = 0; r < 2 * (n + m); ++r) h_src[2 * ro + r] = -1;
@@ -522,8 +698,11 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
         !S->d_rows || !S->d_src || !S->d_dinv || !S->d_F || !S->d_B)
       rc = PA_FAIL("allocating %.2f GB of block factors on the device failed: %s", 8e-9 * (double)(totF + totB), pa_rt_error());
   }
-  /* numeric factorisation, block after block on the host threads, each block uploaded when done */
-  if (!rc) {
+  /* numeric factorisation: on the device (nd_factor.hip, after the plan is uploaded, below) or, with
+   * PREALPS_ND_NUMERIC=host, block after block on the host threads, each block uploaded when done */
+  const char* nume = getenv("PREALPS_ND_NUMERIC");
+  const int numeric_on_host = nume && !strcmp(nume, "host");
+  if (!rc && numeric_on_host) {
     int fail_new = 0, fail_blk = -1;
     double inv_dev = 0.0;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -552,6 +731,12 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
     if (rc == 2) { *fail_row = B[fail_blk].row0 + B[fail_blk].tree.perm[fail_new - 1]; }
     else if (rc) rc = PA_FAIL("factorising the large diagonal blocks failed (%s)", rc == 3 ? pa_rt_error() : "out of host memory");
     S->inv_dev = inv_dev;
+    if (trace) {
+      fprintf(stderr, "[nd] numeric phase (factor, selective inversion, upload): %.2f s; CPU seconds over the threads: %.2f in the dense partial factorisations, %.2f in the inversions\n",
+              pa_wtime() - t_phase, g_cpu_factor, g_cpu_selinv);
+      g_cpu_factor = g_cpu_selinv = 0.0;
+      t_phase = pa_wtime();
+    }
     if (!rc && inv_dev > 1e-6)
       fprintf(stderr, "[prealps_hip] warning: the pivot triangles of the sparse block factor are ill conditioned "
                       "(inverse off by %.1e); the block solve loses that much accuracy\n", inv_dev);
@@ -589,6 +774,16 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
         for (int k0 = 0; k0 < h_n[g]; k0 += CB) { bf[y] = g; bc[y++] = k0; }
       }
       S->f_count[h] = (int)nf; S->b_count[h] = (int)nb;
+      if (getenv("PREALPS_ND_TRACE")) {
+        long long by = 0; int cnt = 0, nmx = 0, fmx = 0;
+        for (int g = 0; g < nsn; ++g) if (h_height[g] == h) {
+          ++cnt; by += (long long)h_ld[g] * h_n[g];
+          if (h_n[g] > nmx) nmx = h_n[g];
+          if (h_n[g] + h_m[g] > fmx) fmx = h_n[g] + h_m[g];
+        }
+        fprintf(stderr, "[nd] level %d: %d fronts (widest %d columns, tallest %d rows), %.1f MB per copy, %lld forward / %lld backward workgroups\n",
+                h, cnt, nmx, fmx, 8e-6 * (double)by, nf, nb);
+      }
       S->f_front[h] = (int*)pa_rt_malloc((size_t)(nf ? nf : 1) * sizeof(int)); S->f_row0[h] = (int*)pa_rt_malloc((size_t)(nf ? nf : 1) * sizeof(int));
       S->b_front[h] = (int*)pa_rt_malloc((size_t)(nb ? nb : 1) * sizeof(int)); S->b_col0[h] = (int*)pa_rt_malloc((size_t)(nb ? nb : 1) * sizeof(int));
       if (!S->f_front[h] || !S->f_row0[h] || !S->b_front[h] || !S->b_col0[h] ||
@@ -596,6 +791,15 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
           pa_rt_h2d(S->b_front[h], bf, (size_t)nb * sizeof(int)) || pa_rt_h2d(S->b_col0[h], bc, (size_t)nb * sizeof(int)))
         rc = PA_FAIL("uploading the block-solve plan failed: %s", pa_rt_error());
       free(ff); free(fr); free(bf); free(bc);
+    }
+  }
+  if (!rc && !numeric_on_host) {
+    int fg = -1, fc = 0;
+    rc = nd_numeric_device(S, B, nblk, sn0, nsn, h_n, h_m, h_ld, h_rows_off, h_height, maxh, totrows, &fg, &fc);
+    if (rc == 2) {
+      int x = 0;
+      while (x + 1 < nblk && sn0[x + 1] <= fg) ++x;
+      *fail_row = B[x].row0 + B[x].tree.perm[B[x].tree.first[fg - sn0[x]] + fc];
     }
   }
   free(h_n); free(h_m); free(h_ld); free(h_offF); free(h_offB); free(h_rows_off); free(h_coff); free(h_ccoff);
@@ -674,7 +878,7 @@ int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const 
     long long oF = 0, oB = 0;
     double dmax = 0.0;
     for (int s = 0; s < B.tree.nsn; ++s) {       /* u = L^T x */
-      int c0 = B.tree.first[s], ns = B.tree.first[s + 1] - c0, m = B.m[s], f = ns + m, ld = (f + 1) & ~1, ldb = (ns + 1) & ~1;
+      int c0 = B.tree.first[s], ns = B.tree.first[s + 1] - c0, m = B.m[s], f = ns + m, ld = PA_ND_LD(f), ldb = PA_ND_LD(ns);
       if (f > maxf) maxf = f;
       if (B.height[s] > maxh) maxh = B.height[s];
       for (int j = 0; j < ns; ++j) {
@@ -694,7 +898,7 @@ int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const 
     }
     oF = 0;
     for (int s = 0; s < B.tree.nsn; ++s) {       /* w = L u */
-      int c0 = B.tree.first[s], ns = B.tree.first[s + 1] - c0, m = B.m[s], f = ns + m, ld = (f + 1) & ~1;
+      int c0 = B.tree.first[s], ns = B.tree.first[s + 1] - c0, m = B.m[s], f = ns + m, ld = PA_ND_LD(f);
       for (int j = 0; j < ns; ++j) {
         double ljj = 1.0 / di[c0 + j];
         w[c0 + j] += ljj * u[c0 + j];
@@ -726,7 +930,7 @@ int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const 
     int widest = 0;
     oF = 0;
     for (int s = 0; s < B.tree.nsn && !rc; ++s) {
-      int ns = B.tree.first[s + 1] - B.tree.first[s], m = B.m[s], f = ns + m, ld = (f + 1) & ~1;
+      int ns = B.tree.first[s + 1] - B.tree.first[s], m = B.m[s], f = ns + m, ld = PA_ND_LD(f);
       double* pf = hF + oF;
       double* wk = (double*)malloc(((size_t)ns * ns + ns + (size_t)ns * (m ? m : 1)) * sizeof(double));
       if (!wk) { rc = PA_FAIL("out of host memory"); break; }

@@ -1,0 +1,330 @@
+// nd_factor.hip -- numeric phase of the sparse factor of large diagonal blocks (nd.c) on the
+// device: multifrontal Cholesky, level by level up the forest, every front of a level in the same
+// launches.  It stands where the reference calls PARDISO's numeric factorisation (phase 22 of
+// src/preconditioners/block_jacobi.c:48-58 via cplm_kernels.c:741-784), once per block.
+//
+// A front is a dense f x f lower triangle (column major, leading dimension ldf), f = n pivot
+// columns + m rows below.  Per level:
+//   assemble   F = sum of the children's Schur complements (gathered through the row maps the solve
+//              uses for the contribution vectors) + the block's own entries of the pivot columns;
+//   factor     right-looking in blocks of 64 pivots: k_ndf_potrf (the 64 x 64 pivot block, one
+//              workgroup per front), k_ndf_trsm (the rows below it, a thread per row),
+//              k_ndf_update (64 x 64 tiles of everything to the right, LDS-tiled products);
+//   invert     P = [I ; L_21] L_11^-1 by the same two kernels run from the last pivot block to the
+//              first (column block J: P(:, J) <- P(:, J) L_JJ^-1, then P(:, J') -= P(:, J) L(J, J')
+//              for J' < J) -- the "selective inversion" form the solve kernels multiply with;
+//   finalise   T = D L_11^-1 (rows scaled by their pivots), -G = -L_21 L_11^-1, written to the
+//              column-major and (through an LDS transpose) the row-major copy.
+// All of it is fp64 VALU work on 64 x 64 tiles (about 12 GFLOP per 17.5 k-row elasticity block):
+// the host threads need seconds for what these kernels do in tens of milliseconds.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "pa_device.h"
+
+namespace {
+
+constexpr int TB = 64;            // pivots per step = tile edge
+constexpr int NT = 256;
+
+inline hipStream_t cur_stream() { return (hipStream_t)pa_rt_stream(); }
+
+int kfail(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  fprintf(stderr, "[prealps_hip] kernel launch failed: %s: %s\n", what, hipGetErrorString(e));
+  return 1;
+}
+
+__device__ __forceinline__ double* front_of(const pa_ndf_args_t& a, int g) {
+  return reinterpret_cast<double*>(a.front[g]);
+}
+
+// F(i, j) for the tile (ti, tj), i >= j: what the children hand up.  A front row finds its place in
+// child c through src (the map the solve's contribution vectors use); both maps are monotone, so
+// a lower-triangle entry of the parent comes from a lower-triangle entry of the child.
+__global__ __launch_bounds__(NT) void k_ndf_assemble(pa_ndf_args_t a, const int* __restrict__ tf,
+                                                     const int* __restrict__ tti, const int* __restrict__ ttj) {
+  const int g = tf[blockIdx.x], ti = tti[blockIdx.x], tj = ttj[blockIdx.x];
+  const int n = a.n[g], f = n + a.m[g], ldf = a.ldf[g];
+  double* __restrict__ F = front_of(a, g);
+  const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[g];
+  const int c0 = a.child[2 * g], c1 = a.child[2 * g + 1];
+  const double* F0 = nullptr; const double* F1 = nullptr;
+  int n0 = 0, n1 = 0, ld0 = 0, ld1 = 0;
+  if (c0 >= 0) { F0 = front_of(a, c0); n0 = a.n[c0]; ld0 = a.ldf[c0]; }
+  if (c1 >= 0) { F1 = front_of(a, c1); n1 = a.n[c1]; ld1 = a.ldf[c1]; }
+  const int tid = threadIdx.x;
+  const int i = ti * TB + (tid & 63);
+  if (i >= f) return;
+  const int si0 = c0 >= 0 ? src[2 * i] : -1, si1 = c1 >= 0 ? src[2 * i + 1] : -1;
+  for (int k = 0; k < 16; ++k) {
+    const int j = tj * TB + (tid >> 6) + 4 * k;
+    if (j > i) continue;
+    double v = 0.0;
+    if (si0 >= 0) { const int sj = src[2 * j]; if (sj >= 0) v += F0[(size_t)(n0 + sj) * ld0 + n0 + si0]; }
+    if (si1 >= 0) { const int sj = src[2 * j + 1]; if (sj >= 0) v += F1[(size_t)(n1 + sj) * ld1 + n1 + si1]; }
+    F[(size_t)j * ldf + i] = v;
+  }
+}
+
+// + the block's own entries of the pivot columns (lower triangle of the permuted block, by
+// column); a thread per column, the row of an entry below the pivots found by bisection.
+__global__ __launch_bounds__(NT) void k_ndf_scatter(pa_ndf_args_t a, const int* __restrict__ fronts) {
+  const int g = fronts[blockIdx.x];
+  const int n = a.n[g], m = a.m[g], ldf = a.ldf[g];
+  double* __restrict__ F = front_of(a, g);
+  const int* __restrict__ newrow = a.newrow + a.rows_off[g];
+  const int c0 = newrow[0];
+  const long long* __restrict__ cp = a.acp + a.acol0[g];
+  for (int j = threadIdx.x; j < n; j += NT) {
+    for (long long e = cp[j]; e < cp[j + 1]; ++e) {
+      const int ri = a.ari[e];
+      int r;
+      if (ri < c0 + n) r = ri - c0;
+      else {
+        int lo = 0, hi = m;                   // first below-row >= ri (it is there: symbolic phase)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (newrow[n + mid] < ri) lo = mid + 1; else hi = mid; }
+        r = n + lo;
+      }
+      F[(size_t)j * ldf + r] += a.acv[e];
+    }
+  }
+}
+
+// Cholesky of the pivot block at (jb, jb) in LDS; also 1 / L_kk for the solve kernels.
+__global__ __launch_bounds__(NT) void k_ndf_potrf(pa_ndf_args_t a, const int* __restrict__ fronts, int jb) {
+  __shared__ double D[TB][TB + 1];            // D[column][row]
+  const int g = fronts[blockIdx.x];
+  const int n = a.n[g];
+  if (jb >= n) return;
+  const int nb = min(TB, n - jb), ldf = a.ldf[g];
+  double* __restrict__ F = front_of(a, g);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < TB * TB; e += NT) {
+    const int j = e >> 6, i = e & 63;
+    D[j][i] = (i < nb && j < nb && i >= j) ? F[(size_t)(jb + j) * ldf + jb + i] : 0.0;
+  }
+  __syncthreads();
+  for (int k = 0; k < nb; ++k) {
+    double d = D[k][k];
+    if (!(d > 0.0)) {                         // not positive definite: remember the first such column
+      if (tid == 0) atomicMin(a.fail, ((unsigned long long)(unsigned)g << 32) | (unsigned)(jb + k));
+      d = 1.0;
+    }
+    const double sd = sqrt(d), id = 1.0 / sd;
+    __syncthreads();
+    for (int i = k + tid; i < nb; i += NT) D[k][i] = i == k ? sd : D[k][i] * id;
+    __syncthreads();
+    const int w = nb - k - 1;
+    for (int e = tid; e < w * w; e += NT) {
+      const int j = k + 1 + e / w, i = k + 1 + e % w;
+      if (i >= j) D[j][i] -= D[k][i] * D[k][j];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < TB * TB; e += NT) {
+    const int j = e >> 6, i = e & 63;
+    if (i < nb && j < nb && i >= j) F[(size_t)(jb + j) * ldf + jb + i] = D[j][i];
+  }
+  if (tid < nb) a.dinv[a.rows[a.rows_off[g] + jb + tid]] = 1.0 / D[tid][tid];
+}
+
+// A thread per row, the 64 values of its row in registers.
+//   INV = false: F(i, J) <- F(i, J) L_JJ^-T for the rows below the pivot block (x L^T = f)
+//   INV = true:  P(i, J) <- P(i, J) L_JJ^-1 for the rows from the pivot block down (x L = p)
+template <bool INV>
+__global__ __launch_bounds__(NT) void k_ndf_trsm(pa_ndf_args_t a, const int* __restrict__ cfront,
+                                                 const int* __restrict__ crow0, int jb) {
+  __shared__ double Ls[TB][TB + 1];           // Ls[row j][column k] of the pivot block, identity past nb
+  __shared__ double idg[TB];
+  const int g = cfront[blockIdx.x], r0 = crow0[blockIdx.x];
+  const int n = a.n[g];
+  if (jb >= n) return;
+  const int nb = min(TB, n - jb), f = n + a.m[g], ldf = a.ldf[g];
+  const int first = INV ? jb : jb + nb;
+  if (r0 + NT - 1 < first) return;
+  const double* __restrict__ F = front_of(a, g);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < TB * TB; e += NT) {
+    const int k = e >> 6, j = e & 63;         // lanes along the rows of a column: coalesced
+    Ls[j][k] = (j < nb && k < nb && k <= j) ? F[(size_t)(jb + k) * ldf + jb + j] : (j == k ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  if (tid < TB) idg[tid] = 1.0 / Ls[tid][tid];
+  __syncthreads();
+  const int i = r0 + tid;
+  if (i < first || i >= f) return;
+  double* __restrict__ X = INV ? a.F + a.offF[g] : front_of(a, g);
+  const size_t ldx = INV ? (size_t)a.ld[g] : (size_t)ldf;
+  double x[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) x[j] = j < nb ? X[(size_t)(jb + j) * ldx + i] : 0.0;
+  if constexpr (!INV) {
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      double s = x[j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s = fma(-x[k], Ls[j][k], s);
+      x[j] = s * idg[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = TB - 1; j >= 0; --j) {
+      double s = x[j];
+#pragma unroll
+      for (int k = j + 1; k < TB; ++k) s = fma(-x[k], Ls[k][j], s);
+      x[j] = s * idg[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TB; ++j)
+    if (j < nb) X[(size_t)(jb + j) * ldx + i] = x[j];
+}
+
+// One 64 x 64 tile, K = the pivot block of this step; a thread owns 4 x 4 entries.
+//   INV = false: F(i, j) -= sum_k F(i, jb + k) F(j, jb + k)   for j >= jb + nb, i >= j
+//   INV = true:  P(i, j) -= sum_k P(i, jb + k) L(jb + k, j)   for j < jb, i >= jb
+template <bool INV>
+__global__ __launch_bounds__(NT) void k_ndf_update(pa_ndf_args_t a, const int* __restrict__ tf,
+                                                   const int* __restrict__ tti, const int* __restrict__ ttj, int jb) {
+  __shared__ double As[TB][TB + 4];           // As[k][i]
+  __shared__ double Bs[TB][TB + 4];           // Bs[k][j]
+  const int g = tf[blockIdx.x], ti = tti[blockIdx.x], tj = ttj[blockIdx.x];
+  const int n = a.n[g];
+  if (jb >= n) return;
+  const int nb = min(TB, n - jb), f = n + a.m[g], ldf = a.ldf[g];
+  if constexpr (!INV) { if (tj * TB + TB - 1 < jb + nb) return; }
+  else { if (tj * TB >= jb || ti * TB + TB - 1 < jb) return; }
+  const double* __restrict__ F = front_of(a, g);
+  double* __restrict__ C = INV ? a.F + a.offF[g] : front_of(a, g);
+  const size_t ldc = INV ? (size_t)a.ld[g] : (size_t)ldf;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < TB * TB; e += NT) {
+    const int k = e >> 6, l = e & 63;
+    const int i = ti * TB + l;
+    As[k][l] = (k < nb && i < f) ? C[(size_t)(jb + k) * ldc + i] : 0.0;
+    if constexpr (!INV) {
+      const int j = tj * TB + l;
+      Bs[k][l] = (k < nb && j < f) ? F[(size_t)(jb + k) * ldf + j] : 0.0;
+    }
+  }
+  if constexpr (INV) {
+    for (int e = tid; e < TB * TB; e += NT) {
+      const int l = e >> 6, k = e & 63;       // lanes along k: rows of the factor, coalesced
+      const int j = tj * TB + l;
+      Bs[k][l] = (k < nb && j < jb) ? F[(size_t)j * ldf + jb + k] : 0.0;
+    }
+  }
+  __syncthreads();
+  const int i0 = (tid & 15) * 4, j0 = (tid >> 4) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[p][q] = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < TB; ++k) {
+    const double2 a01 = *reinterpret_cast<const double2*>(&As[k][i0]), a23 = *reinterpret_cast<const double2*>(&As[k][i0 + 2]);
+    const double2 b01 = *reinterpret_cast<const double2*>(&Bs[k][j0]), b23 = *reinterpret_cast<const double2*>(&Bs[k][j0 + 2]);
+    const double av[4] = {a01.x, a01.y, a23.x, a23.y}, bv[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[p][q] = fma(av[p], bv[q], acc[p][q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = tj * TB + j0 + q;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int i = ti * TB + i0 + p;
+      const bool ok = INV ? (j < jb && i >= jb && i < f) : (j >= jb + nb && j < f && i >= j && i < f);
+      if (ok) C[(size_t)j * ldc + i] -= acc[p][q];
+    }
+  }
+}
+
+// P = [I ; L_21] in the place of the forward copy, before the inversion sweep.
+__global__ __launch_bounds__(NT) void k_ndf_pinit(pa_ndf_args_t a, const int* __restrict__ cfront,
+                                                  const int* __restrict__ crow0) {
+  const int g = cfront[blockIdx.x], r0 = crow0[blockIdx.x];
+  const int n = a.n[g], f = n + a.m[g], ldf = a.ldf[g], ld = a.ld[g];
+  const double* __restrict__ F = front_of(a, g);
+  double* __restrict__ P = a.F + a.offF[g];
+  const int i = r0 + threadIdx.x;
+  if (i >= f) return;
+  for (int j = 0; j < n; ++j) P[(size_t)j * ld + i] = i < n ? (i == j ? 1.0 : 0.0) : F[(size_t)j * ldf + i];
+}
+
+// T = D L_11^-1 (pivot rows times their pivots), -G below; both copies.
+__global__ __launch_bounds__(NT) void k_ndf_finalize(pa_ndf_args_t a, const int* __restrict__ tf,
+                                                     const int* __restrict__ tti, const int* __restrict__ ttj) {
+  __shared__ double Ts[TB][TB + 1];           // Ts[j][i]
+  const int g = tf[blockIdx.x], ti = tti[blockIdx.x], tj = ttj[blockIdx.x];
+  const int n = a.n[g], f = n + a.m[g], ldf = a.ldf[g], ld = a.ld[g], ldb = PA_ND_LD(n);
+  const double* __restrict__ F = front_of(a, g);
+  double* __restrict__ P = a.F + a.offF[g];
+  double* __restrict__ Bc = a.B + a.offB[g];
+  const int tid = threadIdx.x;
+  {
+    const int i = ti * TB + (tid & 63);
+    const double sc = i < n ? F[(size_t)i * ldf + i] : -1.0;
+    for (int k = 0; k < 16; ++k) {
+      const int jl = (tid >> 6) + 4 * k, j = tj * TB + jl;
+      double v = 0.0;
+      if (i < f && j < n && j < i) { v = P[(size_t)j * ld + i] * sc; P[(size_t)j * ld + i] = v; }
+      Ts[jl][tid & 63] = v;
+    }
+  }
+  __syncthreads();
+  {
+    const int j = tj * TB + (tid & 63);
+    for (int k = 0; k < 16; ++k) {
+      const int il = (tid >> 6) + 4 * k, i = ti * TB + il;
+      if (i < f && j < n && j < i) Bc[(size_t)i * ldb + j] = Ts[tid & 63][il];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pa_k_ndf_assemble(const pa_ndf_args_t* a, const int* tf, const int* ti, const int* tj, int ntiles,
+                      const int* fronts, int nfronts) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_ndf_assemble, dim3(ntiles), dim3(NT), 0, cur_stream(), *a, tf, ti, tj);
+  if (nfronts > 0) hipLaunchKernelGGL(k_ndf_scatter, dim3(nfronts), dim3(NT), 0, cur_stream(), *a, fronts);
+  return kfail("k_ndf_assemble");
+}
+
+int pa_k_ndf_potrf(const pa_ndf_args_t* a, const int* fronts, int nfronts, int jb) {
+  if (nfronts > 0) hipLaunchKernelGGL(k_ndf_potrf, dim3(nfronts), dim3(NT), 0, cur_stream(), *a, fronts, jb);
+  return kfail("k_ndf_potrf");
+}
+
+int pa_k_ndf_trsm(const pa_ndf_args_t* a, const int* cfront, const int* crow0, int nchunks, int jb, int inverse) {
+  if (nchunks <= 0) return 0;
+  if (inverse) hipLaunchKernelGGL((k_ndf_trsm<true>), dim3(nchunks), dim3(NT), 0, cur_stream(), *a, cfront, crow0, jb);
+  else hipLaunchKernelGGL((k_ndf_trsm<false>), dim3(nchunks), dim3(NT), 0, cur_stream(), *a, cfront, crow0, jb);
+  return kfail("k_ndf_trsm");
+}
+
+int pa_k_ndf_update(const pa_ndf_args_t* a, const int* tf, const int* ti, const int* tj, int ntiles, int jb,
+                    int inverse) {
+  if (ntiles <= 0) return 0;
+  if (inverse) hipLaunchKernelGGL((k_ndf_update<true>), dim3(ntiles), dim3(NT), 0, cur_stream(), *a, tf, ti, tj, jb);
+  else hipLaunchKernelGGL((k_ndf_update<false>), dim3(ntiles), dim3(NT), 0, cur_stream(), *a, tf, ti, tj, jb);
+  return kfail("k_ndf_update");
+}
+
+int pa_k_ndf_pinit(const pa_ndf_args_t* a, const int* cfront, const int* crow0, int nchunks) {
+  if (nchunks > 0) hipLaunchKernelGGL(k_ndf_pinit, dim3(nchunks), dim3(NT), 0, cur_stream(), *a, cfront, crow0);
+  return kfail("k_ndf_pinit");
+}
+
+int pa_k_ndf_finalize(const pa_ndf_args_t* a, const int* tf, const int* ti, const int* tj, int ntiles) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_ndf_finalize, dim3(ntiles), dim3(NT), 0, cur_stream(), *a, tf, ti, tj);
+  return kfail("k_ndf_finalize");
+}
+
+}  // extern "C"

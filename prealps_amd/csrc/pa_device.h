@@ -201,11 +201,14 @@ int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out)
 /* Supernodes of a nested-dissection Cholesky factor, all blocks of the process in one numbering.
  * Supernode s: n[s] pivot columns, m[s] rows below, panel P = [T ; -G] (see kernels.hip) twice:
  * F + offF[s] column major with leading dimension ld[s] >= n + m, B + offB[s] row major with row
- * length (n + 1) & ~1; only the entries below the diagonal are read.  rows[rows_off[s] + r] =
+ * length PA_ND_LD(n); only the entries below the diagonal are read.  rows[rows_off[s] + r] =
  * local panel row of front row r; src[2 (rows_off[s] + r) + c] = where front row r finds the
  * contribution of child c (row of its vector, -1: none), that vector starting at row
  * ccoff[2 s + c] of `contrib`; this supernode's own contribution starts at row coff[s].
  * dinv[local row] = 1 / L(row, row).  Y: scratch panel for the forward result (local rows). */
+/* leading dimensions of both copies: multiples of 128 bytes, so that the 512-byte segment a
+ * wavefront loads never straddles an extra cache line */
+#define PA_ND_LD(x) (((x) + 15) & ~15)
 typedef struct {
   const int* n; const int* m; const int* ld; const long long* offF; const long long* offB; const int* rows_off;
   const int* coff; const int* ccoff; const int* rows; const int* src; const double* dinv;
@@ -214,6 +217,32 @@ typedef struct {
   const int* f_count; const int* const* f_front; const int* const* f_row0;   /* forward: (front, first front row) per workgroup */
   const int* b_count; const int* const* b_front; const int* const* b_col0;   /* backward: (front, first pivot column) per workgroup */
 } pa_nd_plan_t;
+/* ---- numeric factorisation of those blocks on the device (nd_factor.hip) ------------------- */
+/* n, m, ld, offF, offB, rows_off, rows, src, F, B, dinv as in pa_nd_plan_t.  front[s] = device
+ * address of the dense front of supernode s while its level (and its parent's) is being worked on:
+ * column major, leading dimension ld[s], lower triangle.  child[2 s + c] = supernode id of child c
+ * (-1: none); newrow[rows_off[s] + r] = index of front row r in its block's elimination order;
+ * the block's own entries of the pivot columns of s: columns acp[acol0[s] + j] .. of (ari, acv),
+ * rows in elimination order, lower triangle.  fail: smallest (supernode << 32 | pivot column) whose
+ * pivot was not positive, ~0 if none. */
+typedef struct {
+  const int* n; const int* m; const int* ld; const long long* offF; const long long* offB; const int* rows_off;
+  const int* rows; const int* src; const int* child; const int* newrow;
+  const long long* acol0; const long long* acp; const int* ari; const double* acv;
+  const unsigned long long* front; const int* ldf;
+  double* F; double* B; double* dinv; unsigned long long* fail;
+} pa_ndf_args_t;
+/* tiles = (front, tile row, tile column) of 64 x 64 entries; chunks = (front, first row) of
+ * pa_nd_chunk_rows() rows; jb = first pivot of the step (a multiple of 64) */
+int pa_k_ndf_assemble(const pa_ndf_args_t* a, const int* tf, const int* ti, const int* tj, int ntiles,
+                      const int* fronts, int nfronts);
+int pa_k_ndf_potrf(const pa_ndf_args_t* a, const int* fronts, int nfronts, int jb);
+int pa_k_ndf_trsm(const pa_ndf_args_t* a, const int* cfront, const int* crow0, int nchunks, int jb, int inverse);
+int pa_k_ndf_update(const pa_ndf_args_t* a, const int* tf, const int* ti, const int* tj, int ntiles, int jb,
+                    int inverse);
+int pa_k_ndf_pinit(const pa_ndf_args_t* a, const int* cfront, const int* crow0, int nchunks);
+int pa_k_ndf_finalize(const pa_ndf_args_t* a, const int* tf, const int* ti, const int* tj, int ntiles);
+
 int pa_nd_chunk_rows(void);           /* front rows per forward workgroup */
 int pa_nd_block_cols(void);           /* pivot columns per backward workgroup */
 int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out);
