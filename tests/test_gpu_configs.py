@@ -280,17 +280,22 @@ def test_block_solve_dispatch_by_band(n, t, lo, hi, wide_from, monkeypatch):
 
 
 # ---- large blocks: sparse (nested dissection) factor against the band factor and the oracle -----------
-@pytest.mark.parametrize("split", ["default", "0"])
+@pytest.mark.parametrize("variant", ["device", "host", "chains"])
 @pytest.mark.parametrize("t", [1, 4, 8, 16])
 @pytest.mark.parametrize("kind", ["poisson", "elasticity"])
-def test_large_blocks_sparse_factor(kind, t, split, monkeypatch):
+def test_large_blocks_sparse_factor(kind, t, variant, monkeypatch):
     """Few large subdomains (nparts = 64 on 1M rows, the reference's one block per
-    rank): blocks of >= 4096 rows with a wide band get the supernodal factor of nd.c, solved level
-    by level (k_nd_forward / k_nd_backward).  Same answer as the oracle's exact block solve and as
-    the band kernels (PREALPS_BJ_ND=0) on the same blocks."""
+    rank): blocks of >= 4096 rows with a wide band get the supernodal factor of nd.c in
+    selective-inversion form, solved level by level (k_nd_forward / k_nd_backward).  Same answer
+    as the oracle's exact block solve and as the band kernels (PREALPS_BJ_ND=0) on the same
+    blocks -- with the numeric phase on the device (nd_factor.hip, the default), on the host
+    threads, and with separators cut into chains of 64-column supernodes over small leaves."""
     from oracle import oracle as O
-    if split != "default":       # fronts above 512 rows are split into pivot rows + chunks of rows below; 0: never
-        monkeypatch.setenv("PREALPS_ND_SPLIT", split)
+    if variant == "host":
+        monkeypatch.setenv("PREALPS_ND_NUMERIC", "host")
+    if variant == "chains":
+        monkeypatch.setenv("PREALPS_ND_WIDTH", "64")
+        monkeypatch.setenv("PREALPS_ND_LEAF", "24")
     if kind == "poisson":
         A, P, part = O.poisson3d(24), 2, None          # slabs of 12 x 24 x 24 = 6912 rows, band 288
     else:
