@@ -164,12 +164,13 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   for (int q = 0; q < np; ++q) { row0[q] = rowPos[op->part0 + q] - row_off; nrows[q] = rowPos[op->part0 + q + 1] - rowPos[op->part0 + q]; }
   /* Large blocks (few subdomains of thousands of rows, the reference's own regime) get a sparse
    * nested-dissection factor instead of a band (nd.c).  PREALPS_BJ_ND: 0 never, 1 (default) for
-   * blocks of at least PREALPS_BJ_ND_ROWS (4096) rows whose band exceeds 256, 2 for every block of
-   * at least PREALPS_BJ_ND_ROWS rows.  (Measured on elasticity 70^3: blocks of 17.5 k rows 6.9 ms
-   * per apply against 15.3 ms with the band kernels; blocks of 2187 rows 1.95 ms against 1.49 ms.) */
+   * blocks of at least PREALPS_BJ_ND_ROWS (2048) rows whose band exceeds 256, 2 for every block of
+   * at least PREALPS_BJ_ND_ROWS rows.  (Measured on elasticity 70^3, per apply: blocks of 17.5 k rows
+   * 2.3 ms against 15.3 ms with the band kernels; 2187 rows 1.35 against 1.46 ms; 648 rows 0.90
+   * against 0.60 ms: small blocks stay with the band.) */
   char* is_nd = (char*)calloc(np ? np : 1, 1);
   const int nd_mode = getenv("PREALPS_BJ_ND") ? atoi(getenv("PREALPS_BJ_ND")) : 1;
-  const int nd_rows = getenv("PREALPS_BJ_ND_ROWS") ? atoi(getenv("PREALPS_BJ_ND_ROWS")) : 4096;
+  const int nd_rows = getenv("PREALPS_BJ_ND_ROWS") ? atoi(getenv("PREALPS_BJ_ND_ROWS")) : 2048;
 
   double t_setup0 = pa_wtime();
   /* PREALPS_BJ_FACTOR=host keeps every factorisation on the host threads */

@@ -262,6 +262,7 @@ def test_block_solve_dispatch_by_band(n, t, lo, hi, wide_from, monkeypatch):
     Both against the oracle's solve."""
     if wide_from != "default":
         monkeypatch.setenv("PREALPS_BJ_WIDE_FROM", wide_from)
+    monkeypatch.setenv("PREALPS_BJ_ND", "0")      # (blocks this large would otherwise get the sparse factor: tested below)
     from oracle import oracle as O
     import scipy.sparse as sp2
     T = sp2.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])
@@ -285,7 +286,7 @@ def test_block_solve_dispatch_by_band(n, t, lo, hi, wide_from, monkeypatch):
 @pytest.mark.parametrize("kind", ["poisson", "elasticity"])
 def test_large_blocks_sparse_factor(kind, t, variant, monkeypatch):
     """Few large subdomains (nparts = 64 on 1M rows, the reference's one block per
-    rank): blocks of >= 4096 rows with a wide band get the supernodal factor of nd.c in
+    rank): blocks of >= 2048 rows with a wide band get the supernodal factor of nd.c in
     selective-inversion form, solved level by level (k_nd_forward / k_nd_backward).  Same answer
     as the oracle's exact block solve and as the band kernels (PREALPS_BJ_ND=0) on the same
     blocks -- with the numeric phase on the device (nd_factor.hip, the default), on the host
