@@ -10,7 +10,7 @@ make -s
 for f in context operator partition block_jacobi nd ecg dense_ops smalldense; do
   gcc -O1 -g -fPIC -std=gnu11 -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -I. -c $f.c -o $D/$f.o
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libprealps_hip.so build/kernels.o build/runtime.o build/comm_rccl.o $D/*.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libprealps_hip.so build/kernels.o build/nd_factor.o build/runtime.o build/comm_rccl.o $D/*.o \
   -fopenmp -lgomp -lm -ldl -fsanitize=address,undefined
 cd ../..
 cp prealps_amd/libprealps_hip.so $D/orig.so
