@@ -34,6 +34,8 @@ typedef struct {
   int* d_row0; int* d_nrows; int* d_bw; long long* d_off;
   int* d_map_f; int* d_map_b;
   double* d_Lf; double* d_Lb; double* d_invd_f; double* d_invd_b;
+  double* d_Lf2; double* d_Lb2; long long* d_off2;     /* paired records of the narrow classes (optional) */
+  double pairs_bytes;
   /* classes by register sets */
   int nclass; int class_R[16]; int class_count[16]; int class_wmax[16]; int* class_list[16];
   const int* class_list_c[16];
@@ -64,12 +66,14 @@ double pa_bj_factor_bytes(void) { return g_bj.created ? g_bj.factor_bytes : 0.0;
 int pa_bj_max_bandwidth(void) { return g_bj.created ? g_bj.max_bw : 0; }
 int pa_bj_nparts(void) { return g_bj.created ? g_bj.np : 0; }
 int pa_bj_nd_blocks(void) { return g_bj.created ? g_bj.nd_blocks : 0; }
+double pa_bj_pairs_bytes(void) { return g_bj.created ? g_bj.pairs_bytes : 0.0; }
 
 void preAlps_BlockJacobiFree(void) {
   pa_bj_t* s = &g_bj;
   pa_rt_free(s->d_row0); pa_rt_free(s->d_nrows); pa_rt_free(s->d_bw); pa_rt_free(s->d_off);
   pa_rt_free(s->d_map_f); pa_rt_free(s->d_map_b);
   pa_rt_free(s->d_Lf); pa_rt_free(s->d_Lb); pa_rt_free(s->d_invd_f); pa_rt_free(s->d_invd_b);
+  pa_rt_free(s->d_Lf2); pa_rt_free(s->d_Lb2); pa_rt_free(s->d_off2);
   for (int c = 0; c < 16; ++c) pa_rt_free(s->class_list[c]);
   pa_nd_free();
   memset(s, 0, sizeof(*s));
@@ -540,6 +544,38 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     else if (r2) rc = 1;
     free(ndl); free(grow0);
   }
+  /* The sweep records of the classes R = 2, 3 (bands up to 128) a second time in pairs of steps
+   * (k_bj_pairs), read by k_bj_apply_pairs at up to 4 columns: two 16-byte LDS reads per four steps
+   * instead of four clamped 8-byte reads (elasticity 70^3, band 35: 177 -> 166 us per apply; Poisson
+   * 100^3, band 25: 172 -> 150 us).  The plain records stay for the 8- and 16-column kernels.
+   * PREALPS_BJ_PAIRS=0 turns it off. */
+  if (!rc && !(getenv("PREALPS_BJ_PAIRS") && atoi(getenv("PREALPS_BJ_PAIRS")) == 0)) {
+    long long* off2 = (long long*)calloc((size_t)np + 1, sizeof(long long));
+    long long tot2 = 0;
+    int any = 0;
+    for (int c = 0; c < s->nclass; ++c) any |= s->class_R[c] == 2 || s->class_R[c] == 3;
+    if (off2 && any) {
+      for (int q = 0; q < np; ++q) {
+        const int R = (bw[q] + 127) / 64;
+        if (is_nd[q] || bw[q] > wide_from || (R != 2 && R != 3)) continue;
+        off2[q] = tot2;
+        tot2 += 8LL * ((nrows[q] + 7) / 8) * (bw[q] + 4);
+      }
+      s->d_Lf2 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
+      s->d_Lb2 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
+      s->d_off2 = (long long*)pa_rt_malloc(((size_t)np + 1) * sizeof(long long));
+      if (!s->d_Lf2 || !s->d_Lb2 || !s->d_off2 || pa_rt_h2d(s->d_off2, off2, ((size_t)np + 1) * sizeof(long long)) ||
+          pa_rt_memset(s->d_Lf2 + tot2, 0, 512 * sizeof(double)) || pa_rt_memset(s->d_Lb2 + tot2, 0, 512 * sizeof(double)))
+        rc = PA_FAIL("allocating the paired sweep records failed: %s", pa_rt_error());
+      for (int c = 0; c < s->nclass && !rc; ++c)
+        if (s->class_R[c] == 2 || s->class_R[c] == 3)
+          if (pa_k_bj_pairs(s->class_list[c], s->class_count[c], s->d_nrows, s->d_bw, s->d_off, s->d_off2, s->d_Lf, s->d_Lf2) ||
+              pa_k_bj_pairs(s->class_list[c], s->class_count[c], s->d_nrows, s->d_bw, s->d_off, s->d_off2, s->d_Lb, s->d_Lb2))
+            rc = PA_FAIL("k_bj_pairs failed");
+    }
+    if (!rc && any) s->pairs_bytes = 2.0 * 8.0 * (double)tot2;
+    free(off2);
+  }
   for (int q = 0; q < np; ++q) { free(bands[q]); free(coo_off[q]); free(coo_val[q]); }   /* (NULL where already released) */
   free(bands); free(coo_off); free(coo_val); free(coo_n);
   free(row0); free(nrows); free(bw); free(off); free(map_f); free(map_b); free(invd_f); free(invd_b); free(is_nd);
@@ -550,6 +586,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   pl->nparts = np; pl->row0 = s->d_row0; pl->nrows = s->d_nrows; pl->bw = s->d_bw; pl->off = s->d_off;
   pl->map_f = s->d_map_f; pl->map_b = s->d_map_b; pl->Lf = s->d_Lf; pl->Lb = s->d_Lb;
   pl->invd_f = s->d_invd_f; pl->invd_b = s->d_invd_b;
+  pl->Lf2 = s->d_Lf2; pl->Lb2 = s->d_Lb2; pl->off2 = s->d_off2;
   pl->nclass = s->nclass; pl->class_R = s->class_R; pl->class_count = s->class_count;
   pl->class_wmax = s->class_wmax;
   pl->class_list = s->class_list_c;

@@ -1515,6 +1515,41 @@ __device__ __forceinline__ void bj_chunk_fast(double (&acc)[R][TS], const double
   }
 }
 
+// The same chunk from PAIRED records (k_bj_pairs): a chunk is two sub-blocks of four steps, a
+// sub-block holds, for each of its two pivot pairs, one double2 per target row rho = row - first
+// pivot of the sub-block (0 .. w + 3; row 0 is all zero and doubles as the slot of every row outside
+// the band): the band values a lane needs for four steps are two ds_read_b128 at one index instead
+// of four ds_read_b64 at four clamped indices.
+template <int TS, int R, int CH, int K, int NA>
+__device__ __forceinline__ void bj_chunk_pairs(double (&acc)[R][TS], const double* cur, int lc, int w, int lane) {
+  const int nr = w + 4;
+#pragma unroll
+  for (int sb = 0; sb < CH / 4; ++sb) {
+    const double2* blk = reinterpret_cast<const double2*>(cur + (size_t)sb * 4 * nr);
+    double2 cf[NA][2];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const unsigned rho = (unsigned)(a * 64 + lane - lc - 4 * sb);
+      const unsigned idx = rho < (unsigned)nr ? rho : 0u;
+      cf[a][0] = blk[idx];
+      cf[a][1] = blk[nr + idx];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double y[TS];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) y[c] = readlane_f64(acc[K][c], lc + 4 * sb + s);
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const int k2 = (K + a) % R;
+        const double v = (s & 1) ? cf[a][s >> 1].y : cf[a][s >> 1].x;
+#pragma unroll
+        for (int c = 0; c < TS; ++c) acc[k2][c] = fma(-v, y[c], acc[k2][c]);
+      }
+    }
+  }
+}
+
 // The chunks of a sweep go through a ring of `nbuf` LDS buffers (`lstride` doubles apart).  Two
 // buffers: chunk c+1 is in flight while chunk c is consumed, and c has landed once every
 // outstanding VMEM operation of the wave is done.  Three buffers (narrow bands): c+1 AND c+2 are in
@@ -1532,7 +1567,7 @@ __device__ __forceinline__ void bj_wait_chunk(int nld_allowed) {
   }
 }
 
-template <int TS, int R, int CH, int K>
+template <int TS, int R, int CH, int K, int LAY = 0>
 __device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chunk, int b, int w, int wr,
                                          const double* __restrict__ rec, double* lds0, int lstride, int nbuf,
                                          int nld, int lane) {
@@ -1542,6 +1577,13 @@ __device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chu
     {
       const int ahead = chunk + nbuf - 1;
       if (ahead * CH < b) bj_issue_chunk<CH>(rec, wr, ahead, lds0 + (size_t)(ahead % nbuf) * lstride, lane);
+    }
+    if constexpr (LAY == 1) {            // paired records: every chunk is whole (zero padded)
+      const int lmax = lc + CH - 1;
+      if (R >= 3 && lmax >= 128 - w) bj_chunk_pairs<TS, R, CH, K, (R >= 3 ? 3 : 1)>(acc, cur, lc, w, lane);
+      else if (R >= 2 && lmax >= 64 - w) bj_chunk_pairs<TS, R, CH, K, (R >= 2 ? 2 : 1)>(acc, cur, lc, w, lane);
+      else bj_chunk_pairs<TS, R, CH, K, 1>(acc, cur, lc, w, lane);
+      continue;
     }
     const int send = (lim - lc) < CH ? (lim - lc) : CH;
     if constexpr (R <= 3 && TS <= 4) {   // (no gain measured at 8 columns; 16 would spill)
@@ -1576,7 +1618,7 @@ __device__ __forceinline__ void bj_block(double (&acc)[R][TS], int lim, int& chu
   }
 }
 
-template <int TS, int R, int CH, int K, int XS>
+template <int TS, int R, int CH, int K, int XS, int LAY = 0>
 __device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R], int jb, int& chunk, int b,
                                           int w, int wr, const double* __restrict__ rec,
                                           const double* __restrict__ invd,
@@ -1597,7 +1639,7 @@ __device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R],
 #pragma unroll
         for (int c = 0; c < TS; ++c) nxt[c] = 0.0;
       const int lim = (b - j0) < 64 ? (b - j0) : 64;
-      bj_block<TS, R, CH, K>(acc, lim, chunk, b, w, wr, rec, lds0, lstride, nbuf, nld, lane);
+      bj_block<TS, R, CH, K, LAY>(acc, lim, chunk, b, w, wr, rec, lds0, lstride, nbuf, nld, lane);
       if (lane < lim) {
         double y[TS];
 #pragma unroll
@@ -1608,12 +1650,12 @@ __device__ __forceinline__ void bj_blocks(double (&acc)[R][TS], int (&rowid)[R],
       for (int c = 0; c < TS; ++c) acc[K][c] = nxt[c];
       rowid[K] = nrow;
     }
-    bj_blocks<TS, R, CH, K + 1, XS>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0,
+    bj_blocks<TS, R, CH, K + 1, XS, LAY>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0,
                                 lstride, nbuf, nld, lane);
   }
 }
 
-template <int TS, int R, int CH, int XS>
+template <int TS, int R, int CH, int XS, int LAY = 0>
 __device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __restrict__ rec,
                                          const double* __restrict__ invd,
                                          const int* __restrict__ iomap, size_t rowbase,
@@ -1635,7 +1677,7 @@ __device__ __forceinline__ void bj_sweep(int b, int w, int wr, const double* __r
   if (nbuf == 3 && CH < b) bj_issue_chunk<CH>(rec, wr, 1, lds0 + lstride, lane);
   int chunk = 0;
   for (int jb = 0; jb < b; jb += W)
-    bj_blocks<TS, R, CH, 0, XS>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lstride,
+    bj_blocks<TS, R, CH, 0, XS, LAY>(acc, rowid, jb, chunk, b, w, wr, rec, invd, iomap, rowbase, src, dst, lds0, lstride,
                             nbuf, nld, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1678,6 +1720,63 @@ __global__ __launch_bounds__(256, OCC) void k_bj_apply(
   bj_sweep<TS, R, CH, XS>(b, w, wr, Lf + o, invd_f + r0, map_f + r0, (size_t)r0, in + coff, out + coff, lds0, lstride, nb, nld, lane);
   __threadfence_block();
   bj_sweep<TS, R, CH, XS>(b, w, wr, Lb + o, invd_b + r0, map_b + r0, (size_t)r0, out + coff, out + coff, lds0, lstride, nb, nld, lane);
+}
+
+// k_bj_apply on paired records (bj_chunk_pairs): Lf2 / Lb2 at off2[p], 8 (w + 4) doubles per chunk.
+template <int TS, int R, int CH, int XS>
+__global__ __launch_bounds__(256) void k_bj_apply_pairs(
+    const int* __restrict__ list, int count, const int* __restrict__ row0,
+    const int* __restrict__ nrows, const int* __restrict__ bw, const long long* __restrict__ off2,
+    const int* __restrict__ map_f, const int* __restrict__ map_b, const double* __restrict__ Lf2,
+    const double* __restrict__ Lb2, const double* __restrict__ invd_f,
+    const double* __restrict__ invd_b, int lds_per_wave, int nbuf, const double* __restrict__ in,
+    double* __restrict__ out) {
+  extern __shared__ double smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  constexpr int NS = XS / TS;
+  const int unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  const int pi = unit / NS;
+  if (pi >= count) return;
+  const int coff = (unit % NS) * TS;
+  const int p = __builtin_amdgcn_readfirstlane(list[pi]);
+  const int r0 = __builtin_amdgcn_readfirstlane(row0[p]);
+  const int b = __builtin_amdgcn_readfirstlane(nrows[p]);
+  const int w = __builtin_amdgcn_readfirstlane(bw[p]);
+  const int wr2 = w + 4;
+  const int nld = (CH * wr2 * 8 + 1023) >> 10;
+  const int nb = nld <= 4 ? nbuf : 2;
+  const long long o64 = off2[p];
+  const size_t o = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(o64 >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)o64);
+  double* lds0 = smem + (size_t)wave * lds_per_wave;
+  const int lstride = lds_per_wave / nbuf;
+  bj_sweep<TS, R, CH, XS, 1>(b, w, wr2, Lf2 + o, invd_f + r0, map_f + r0, (size_t)r0, in + coff, out + coff, lds0, lstride, nb, nld, lane);
+  __threadfence_block();
+  bj_sweep<TS, R, CH, XS, 1>(b, w, wr2, Lb2 + o, invd_b + r0, map_b + r0, (size_t)r0, out + coff, out + coff, lds0, lstride, nb, nld, lane);
+}
+
+// Paired records from the plain ones: sub-block q = steps 4q .. 4q + 3; entry (pair, rho) =
+// the two pivots' coefficients for row 4q + rho (zero outside the band and past the last step).
+__global__ __launch_bounds__(WG) void k_bj_pairs(const int* __restrict__ list, const int* __restrict__ nrows,
+                                                 const int* __restrict__ bw, const long long* __restrict__ off,
+                                                 const long long* __restrict__ off2, const double* __restrict__ L,
+                                                 double* __restrict__ L2) {
+  const int p = list[blockIdx.x];
+  const int b = nrows[p], w = bw[p], wr = (w + 2) & ~1, nr = w + 4;
+  const double* __restrict__ rec = L + off[p];
+  double2* __restrict__ dst = reinterpret_cast<double2*>(L2 + off2[p]);
+  const int nsub = 2 * ((b + 7) / 8);
+  const int total = nsub * 2 * nr;
+  for (int e = threadIdx.x; e < total; e += WG) {
+    const int q = e / (2 * nr), r = e - q * 2 * nr, pr = r / nr, rho = r - pr * nr;
+    double v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int l = 4 * q + 2 * pr + h, d = rho - (2 * pr + h);      // pivot, distance row - pivot
+      v[h] = (l < b && d >= 1 && d <= w) ? rec[(size_t)l * wr + d - 1] : 0.0;
+    }
+    dst[e] = make_double2(v[0], v[1]);
+  }
 }
 
 // Wide bands (RCM bandwidth > 448: few, large subdomains).  One workgroup of up to 16
@@ -2401,6 +2500,38 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
                        cur_stream(), list, count, pl->row0, pl->nrows, pl->bw, pl->off,           \
                        pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, per_wave, nbuf, in, out); \
   } break;
+  // paired records (pa_k_bj_pairs ran at setup): classes R = 2, 3 at up to 4 columns
+  if constexpr (TS <= 4) {
+    if (pl->Lf2 && (R == 2 || R == 3)) {
+      const int wr2 = wmax + 4;
+      const int cb2 = (CH * wr2 + 127) & ~127;
+      const int nbuf2 = (ring && (CH * wr2 * 8 + 1023) / 1024 <= 4 && 3 * cb2 * 8 * 16 <= 160 * 1024) ? 3 : 2;
+      const int pw2 = nbuf2 * cb2;
+      int wv2 = (160 * 1024) / (pw2 * 8);
+      if (wv2 > 4) wv2 = 4;
+      if (wv2 >= 1) {
+        const size_t lds2 = (size_t)wv2 * pw2 * 8;
+        const int blocks2 = (units + wv2 - 1) / wv2;
+        static size_t conf2[2] = {0, 0};
+        const void* fn = R == 2 ? reinterpret_cast<const void*>(&k_bj_apply_pairs<TS, 2, CH, XS>)
+                                : reinterpret_cast<const void*>(&k_bj_apply_pairs<TS, 3, CH, XS>);
+        if (lds2 > 64 * 1024 && lds2 > conf2[R - 2]) {
+          if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+            return kfail("hipFuncSetAttribute(k_bj_apply_pairs)");
+          conf2[R - 2] = lds2;
+        }
+        if (R == 2)
+          hipLaunchKernelGGL((k_bj_apply_pairs<TS, 2, CH, XS>), dim3(blocks2), dim3(64 * wv2), lds2, cur_stream(), list, count,
+                             pl->row0, pl->nrows, pl->bw, pl->off2, pl->map_f, pl->map_b, pl->Lf2, pl->Lb2, pl->invd_f,
+                             pl->invd_b, pw2, nbuf2, in, out);
+        else
+          hipLaunchKernelGGL((k_bj_apply_pairs<TS, 3, CH, XS>), dim3(blocks2), dim3(64 * wv2), lds2, cur_stream(), list, count,
+                             pl->row0, pl->nrows, pl->bw, pl->off2, pl->map_f, pl->map_b, pl->Lf2, pl->Lb2, pl->invd_f,
+                             pl->invd_b, pw2, nbuf2, in, out);
+        return kfail("k_bj_apply_pairs");
+      }
+    }
+  }
   // narrow bands at up to 4 columns: variants that leave room for 5 / 6 wavefronts per SIMD
   if constexpr (TS <= 4 && XS == TS) {
     static int occ = -1;
@@ -2826,6 +2957,13 @@ int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out)
     if (rc) return rc;
   }
   return 0;
+}
+
+int pa_k_bj_pairs(const int* list, int count, const int* nrows, const int* bw, const long long* off,
+                  const long long* off2, const double* L, double* L2) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_bj_pairs, dim3(count), dim3(WG), 0, cur_stream(), list, nrows, bw, off, off2, L, L2);
+  return kfail("k_bj_pairs");
 }
 
 int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out) {

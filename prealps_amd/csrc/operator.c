@@ -882,6 +882,7 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "bj_max_bandwidth")) *value = pa_bj_max_bandwidth();
   else if (!strcmp(key, "bj_parts_local")) *value = pa_bj_nparts();
   else if (!strcmp(key, "bj_nd_blocks")) *value = pa_bj_nd_blocks();
+  else if (!strcmp(key, "bj_pairs_bytes")) *value = pa_bj_pairs_bytes();
   else if (!strcmp(key, "bj_nd_inverse_dev")) *value = pa_nd_inverse_deviation();
   else return 1;
   return 0;

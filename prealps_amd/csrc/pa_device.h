@@ -169,6 +169,9 @@ typedef struct {
    * Arrays are padded by 2 KiB at the end. */
   const double* Lf;
   const double* Lb;
+  /* optional (NULL: absent): the same records in pairs for the classes R = 2, 3 (k_bj_pairs), block p at
+   * off2[p]: per chunk of 8 steps two sub-blocks of [2 pivot pairs][w + 4 target rows] double2 */
+  const double* Lf2; const double* Lb2; const long long* off2;
   const double* invd_f;    /* 1 / L(j,j) in forward step order (m entries) */
   const double* invd_b;    /* ... in backward step order */
   int nclass;              /* parts grouped by register sets R = ceil((w+64)/64) of the one-wavefront kernel */
@@ -178,6 +181,8 @@ typedef struct {
   const int* const* class_list; /* host array of device pointers to part ids */
 } pa_bj_plan_t;
 int pa_bj_max_R(void);
+int pa_k_bj_pairs(const int* list, int count, const int* nrows, const int* bw, const long long* off,
+                  const long long* off2, const double* L, double* L2);
 /* Band Cholesky on the device for blocks with bandwidth <= pa_bj_factor_wmax(): `band` holds
  * each listed block's rows in factor order, (w+1) doubles per row (A(i, i-d) at d), at offset
  * boff[part]; writes the forward / backward sweep records and 1/L(j,j) straight into Lf, Lb

@@ -82,5 +82,6 @@ int pa_bj_max_bandwidth(void);
 double pa_bj_setup_seconds(int which);   /* 0: ordering + band Cholesky, 1: sweep layouts + upload */
 int pa_bj_nparts(void);
 int pa_bj_nd_blocks(void);
+double pa_bj_pairs_bytes(void);     /* bytes of the paired sweep records (both sweeps), 0 if absent */
 
 #endif

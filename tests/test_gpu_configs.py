@@ -431,18 +431,32 @@ got = prob.solve(rhs, 8)
 ref = O.ECG(B, rowpos, 8).solve(rhs)
 assert got.iters == ref["iters"]
 np.testing.assert_allclose(got.res, ref["res"], rtol=1e-8)
-print("variant ok", prob.stat("spmm_staged"), prob.stat("bj_max_bandwidth"))
+prob.close()
+# narrow bands (register-set class 2): 27 boxes of 4 x 4 x 4 points
+from prealps_amd import gen
+A2 = O.poisson3d(12)
+part2, P2 = gen.box_partition(12, (4, 4, 4))
+rp, ci, v = O.as_csr(A2)
+prob2 = prealps_amd.EcgProblem(rp, ci, v, P2, part2, scale=True, device=0)
+B2, perm2, rowpos2 = O.permute_by_part(O.symrac_scale(A2), part2, P2)
+for t in (2, 4):
+    X = np.random.default_rng(t).standard_normal((B2.shape[0], t))
+    zr = O.BlockJacobi(B2, rowpos2).apply(X)
+    np.testing.assert_allclose(prob2.block_jacobi_apply(X, t), zr, rtol=1e-9, atol=1e-10 * np.abs(zr).max())
+print("variant ok", prob.stat("spmm_staged"), prob.stat("bj_max_bandwidth"), prob2.stat("bj_max_bandwidth"))
 """
 
 
 @pytest.mark.parametrize("env", [{"PREALPS_SPMM_NT": "1", "PREALPS_SPMM_STAGED": "0"},
                                  {"PREALPS_BJ_SPLIT": "1", "PREALPS_BJ_MFMA": "0", "PREALPS_BJ_WIDE_FROM": "448"},
                                  {"PREALPS_BJ_MFMA": "2", "PREALPS_BJ_WIDE_FROM": "448", "PREALPS_TRSM_MFMA": "0"},
-                                 {"PREALPS_BJ_SPLIT4": "0", "PREALPS_ECG_FUSE": "0"}])
+                                 {"PREALPS_BJ_SPLIT4": "0", "PREALPS_ECG_FUSE": "0"},
+                                 {"PREALPS_BJ_PAIRS": "0"}])
 def test_opt_in_kernel_variants(env):
     """Non-temporal SpMM loads (k_spmm<TS,true>), the column-split block solve (PREALPS_BJ_SPLIT),
-    the matrix-core block solve at every width, the unsplit 4-column sweep and the four-pass first
-    half: same answers as the oracle (Poisson 16^3, 16 slabs, band 256 -> register-set class 5)."""
+    the matrix-core block solve at every width, the unsplit 4-column sweep, the four-pass first
+    half, and the narrow-band sweep on plain instead of paired records: same answers as the oracle
+    (Poisson 16^3, 16 slabs, band 256 -> register-set class 5; Poisson 12^3 in 27 boxes, class 2)."""
     r = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET % ROOT], capture_output=True, text=True,
                        env=dict(os.environ, **env), timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
