@@ -24,11 +24,36 @@ difference of the first residuals, GPU vs CPU oracle).
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import socket
 import subprocess
 import sys
 import time
+
+
+def host_cpu_share():
+    """CPUs this process can really use: affinity mask and cgroup CPU quota (a GPU box gives a
+    one-GPU job 16 CPUs' worth of quota on a 256-thread host; 128 OpenMP threads then only take
+    turns -- the CPU baseline measured 5.9 iterations/s with 128 threads and 24 with 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, math.ceil(q / per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+# OpenMP reads this when libgomp is loaded (the CPU oracle of the baseline leg, the library's setup loops)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(host_cpu_share(), 128)))
 
 import numpy as np
 
@@ -338,7 +363,7 @@ def main():
                   "factorisation %.1fs outside the rate" % (r["iters"], r["t_op"], r["t_prec"], r["t_total"], tfac))]
         if a.alg == "odir" and M.load_mkl() is not None:
             try:
-                e_cpu = M.MklEcg(B, rowpos, a.t, 1e-5, a.cpu_iters, threads=min(os.cpu_count() or 1, 128))
+                e_cpu = M.MklEcg(B, rowpos, a.t, 1e-5, a.cpu_iters, threads=min(host_cpu_share(), 128))
                 rm = e_cpu.solve(rhs_cpu)
                 phase_table("ODIR on the host CPU, MKL kernels (%d threads)" % int(rm["threads"]), 1, rm["iters"],
                             {"total": rm["t_total"], "operator": rm["t_op"], "precond": rm["t_prec"]},
@@ -356,7 +381,7 @@ def main():
                                "sample": "same workload (matrix, scaling, partition, rhs), %d ECG iterations each; reported = the "
                                          "faster of: [%s] = %.2f it/s; [%s] = %.2f it/s"
                                          % (a.cpu_iters, cands[0][2], cands[0][0], cands[1][2], cands[1][0]),
-                               "host_cores_online": os.cpu_count()}
+                               "host_cores_online": os.cpu_count(), "host_cpu_share": host_cpu_share()}
     prob.close()
     # ---- the same problem with the subdomain count SURVEY 8(d) names (64): large blocks, sparse
     #      nested-dissection factors (nd.c) instead of bands.  Iterations/s there and at the tuned

@@ -181,7 +181,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   const char* fenv = getenv("PREALPS_BJ_FACTOR");
   const int dev_factor = !(fenv && !strcmp(fenv, "host")), dev_wmax = pa_bj_factor_wmax();
   /* pass 1 (parallel over blocks): RCM order, bandwidth, band assembly, host band Cholesky */
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 1)
   for (int q = 0; q < np; ++q) {
     int r0 = row0[q], b = nrows[q];
     int g0 = rowPos[op->part0 + q], g1 = g0 + b;
@@ -371,7 +371,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       nitem = 0;
       for (int x = q; x < q1; ++x)
         for (int j0 = 0; j0 < nrows[x]; j0 += 256) { item_part[nitem] = x; item_j0[nitem++] = j0; }
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 4)
       for (int it = 0; it < nitem; ++it) {
         int x = item_part[it];
         int b = nrows[x], w = bw[x], r0 = row0[x];
@@ -489,7 +489,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       size_t len = (size_t)(boff[q1] - boff[q]);
       if (len > hb_cap) { hb_cap = len; hb = (double*)realloc(hb, hb_cap * sizeof(double)); }
       if (!hb) { rc = PA_FAIL("out of host memory for %zu band entries", len); break; }
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 16)
       for (int x = q; x < q1; ++x)
         memcpy(hb + (boff[x] - boff[q]), bands[x], (size_t)nrows[x] * (bw[x] + 1) * sizeof(double));
       if (pa_rt_h2d(d_band + boff[q], hb, len * sizeof(double))) rc = PA_FAIL("uploading the bands failed: %s", pa_rt_error());
@@ -506,7 +506,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       double* d_gv = (double*)pa_rt_malloc((ntot ? ntot : 1) * sizeof(double));
       if (!go || !gv || !d_go || !d_gv) rc = PA_FAIL("out of memory for %zu band entries", ntot);
       if (!rc) {
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 1)
         for (int q = 0; q < np; ++q)
           for (size_t e = 0; e < coo_n[q]; ++e) { go[cbase[q] + e] = boff[q] + coo_off[q][e]; gv[cbase[q] + e] = coo_val[q][e]; }
         if (pa_rt_h2d(d_go, go, ntot * sizeof(long long)) || pa_rt_h2d(d_gv, gv, ntot * sizeof(double)) ||

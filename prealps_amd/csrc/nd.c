@@ -612,7 +612,7 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
   *fail_row = -1;
   const int trace = getenv("PREALPS_ND_TRACE") != NULL;
   double t_phase = pa_wtime();
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 1)
   for (int x = 0; x < nblk; ++x) {
     int q = blocks[x];
     if (nd_symbolic(&B[x], A, row0[q], grow0[q], nrows[q], leaf_rows)) {
@@ -705,7 +705,7 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
   if (!rc && numeric_on_host) {
     int fail_new = 0, fail_blk = -1;
     double inv_dev = 0.0;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 1)
     for (int x = 0; x < nblk; ++x) {
       if (rc) continue;
       double* hF = (double*)malloc((size_t)(B[x].nF ? B[x].nF : 1) * sizeof(double));

@@ -449,7 +449,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     return PA_FAIL("Each process needs at least one block (nparts = %d < %d = processes)", nparts, size);
   {
     int bad_row = -1;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(static)
     for (int i = 0; i < N; ++i) {
       int seen = 0;
       for (int k = rowPtr[i]; k < rowPtr[i + 1] && !seen; ++k) seen = colInd[k] == i;
@@ -468,7 +468,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   if (scale) {
     d = (double*)malloc((size_t)N * sizeof(double));
     int zero_row = 0;
-#pragma omp parallel for schedule(static) reduction(|| : zero_row)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(static) reduction(|| : zero_row)
     for (int i = 0; i < N; ++i) {
       double mx = 0.0;
       for (int k = rowPtr[i]; k < rowPtr[i + 1]; ++k) { double a = fabs(val[k]); if (a > mx) mx = a; }
@@ -526,7 +526,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     }
     /* rows are independent: scale, renumber the columns and sort each one (threads as available) */
     int dup_row = -1;   /* (benign race: any offending row will do for the message) */
-#pragma omp parallel
+#pragma omp parallel num_threads(pa_host_threads())
     {
       cv_t* buf = (cv_t*)malloc((maxlen ? maxlen : 1) * sizeof(cv_t));
 #pragma omp for schedule(static)
@@ -583,7 +583,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   if (size > 1) {
     need = (unsigned char*)calloc((size_t)size * (m ? m : 1), 1);
     if (!need) { free(iperm); free(mark); free(recv_by_proc); return PA_FAIL("out of host memory for the halo plan"); }
-#pragma omp parallel for schedule(dynamic, 4096)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 4096)
     for (int i = 0; i < N; ++i) {
       int r = iperm[i];
       if (r >= lo && r < hi) continue;
@@ -616,7 +616,7 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   TRACE("peer lists");
   /* 5. device CSR with local column ids */
   int* lcol = (int*)big_alloc((lnnz + 8) * sizeof(int));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(static)
   for (long long k = 0; k < (long long)lnnz; ++k) { int c = A->colInd[k]; lcol[k] = (c >= lo && c < hi) ? c - lo : m + mark[c] - 1; }
   for (size_t k = lnnz; k < lnnz + 8; ++k) lcol[k] = 0;
   free(mark);

@@ -24,6 +24,7 @@ int pa_fail_at(const char* func, const char* fmt, ...);
 
 int pa_default_device(void);
 double pa_wtime(void);
+int pa_host_threads(void);            /* OpenMP threads worth starting here (cgroup quota, affinity) */
 
 /* ---- process group ------------------------------------------------------ */
 int pa_world_rank(void);

@@ -58,7 +58,7 @@ static int build_graph(int N, const int* rp, const int* ci, int merge, int* cid,
     uint64_t* h = (uint64_t*)malloc((size_t)N * sizeof(uint64_t));
     int* stamp = (int*)malloc((size_t)N * sizeof(int));
     if (!h || !stamp) { free(rep); free(h); free(stamp); return 1; }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(static)
     for (int i = 0; i < N; ++i) {
       uint64_t s = 0;
       for (int k = rp[i]; k < rp[i + 1]; ++k) s += mix64((uint64_t)ci[k] + 1);   /* order independent */
@@ -100,7 +100,7 @@ static int build_graph(int N, const int* rp, const int* ci, int merge, int* cid,
       g->adj = (int*)malloc((size_t)(g->xadj[n] ? g->xadj[n] : 1) * sizeof(int));
       if (!g->adj) { free(rows); return 1; }
     }
-#pragma omp parallel
+#pragma omp parallel num_threads(pa_host_threads())
     {
       int* buf = (int*)malloc((size_t)(maxlen ? maxlen : 1) * sizeof(int));
 #pragma omp for schedule(dynamic, 1024)
