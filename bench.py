@@ -52,8 +52,12 @@ def host_cpu_share():
     return n
 
 
-# OpenMP reads this when libgomp is loaded (the CPU oracle of the baseline leg, the library's setup loops)
-os.environ.setdefault("OMP_NUM_THREADS", str(min(host_cpu_share(), 128)))
+# OpenMP reads this when libgomp is loaded (the CPU oracle of the baseline leg, the library's setup loops).
+# torch.distributed.run gives its children OMP_NUM_THREADS=1 unless told otherwise: the ranks of one
+# node then set up their shards single-threaded; give each rank its part of the CPU share instead.
+_lws = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+if "OMP_NUM_THREADS" not in os.environ or (_lws > 1 and os.environ["OMP_NUM_THREADS"] == "1"):
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(host_cpu_share(), 128) // max(1, _lws)))
 
 import numpy as np
 

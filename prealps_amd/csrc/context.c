@@ -37,19 +37,21 @@ static void* g_ev1 = NULL;
  * the process may actually consume (cgroup quota) and by its affinity mask -- in a container with
  * 16 CPUs' worth of quota on a 256-thread host, 256 threads only take turns (measured on the MI355X
  * box: the OpenMP loops of the CPU baseline run 4x slower with 128 threads than with 16). */
-static int host_threads_of_process(void);
+static int host_cpu_share(void);
 int pa_host_threads(void) {
-  /* the ranks of a multi-GPU run share the node's CPUs (one node: preAlps_hip_set_world) */
-  int t = host_threads_of_process() / (g_size > 1 ? g_size : 1);
-  return t < 1 ? 1 : t;
-}
-static int host_threads_of_process(void) {
-  static int cached = 0;
-  if (cached) return cached;
   int t = 1;
 #ifdef _OPENMP
-  t = omp_get_max_threads();
+  t = omp_get_max_threads();          /* OMP_NUM_THREADS, if the caller set it */
 #endif
+  /* the ranks of a multi-GPU run share the node's CPUs (one node: preAlps_hip_set_world) */
+  int cap = host_cpu_share() / (g_size > 1 ? g_size : 1);
+  if (cap < 1) cap = 1;
+  return t < cap ? t : cap;
+}
+static int host_cpu_share(void) {
+  static int cached = 0;
+  if (cached) return cached;
+  int t = 1 << 20;
   long long quota = -1, period = -1;
   FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");                        /* cgroup v2 */
   if (f) {
