@@ -31,6 +31,12 @@ def _worker(rank, world, port, alg, q):
         os.environ["LOCAL_RANK"] = "0"
         if alg == "fused":
             os.environ["PREALPS_SPMM_RUNS"] = "2"   # halo slots inside the run plan of the SpMM
+        big = alg == "odir_nd"
+        if big:                                      # large blocks: every rank builds sparse (nested dissection) factors
+            os.environ["PREALPS_BJ_ND"] = "2"
+            os.environ["PREALPS_BJ_ND_ROWS"] = "512"
+            os.environ["PREALPS_ND_LEAF"] = "32"
+            alg = "odir"
         if alg == "odir_eager":                      # the residual norm reduced by itself, before the decision
             os.environ["PREALPS_ECG_LAZY_STOP"] = "0"
             alg = "odir"
@@ -40,7 +46,7 @@ def _worker(rank, world, port, alg, q):
         import prealps_amd as pa
         from prealps_amd import gen
         from oracle import oracle as O
-        n, box, t = 16, (4, 4, 8), 4
+        n, box, t = 16, ((8, 8, 16) if big else (4, 4, 8)), 4
         rp, ci, v = gen.poisson3d_csr(n)
         part, nparts = gen.box_partition(n, box)
         prob = pa.EcgProblem(rp, ci, v, nparts, part, scale=True, device=0, distributed=True)
@@ -57,6 +63,7 @@ def _worker(rank, world, port, alg, q):
         p0, p1 = rank * nparts // world, (rank + 1) * nparts // world
         lo, hi = int(rowpos[p0]), int(rowpos[p1])
         assert prob.stat("halo_rows") > 0
+        assert prob.stat("bj_nd_blocks") == (nparts // world if big else 0)
         assert got.iters == ref["iters"], (got.iters, ref["iters"])
         np.testing.assert_allclose(got.res, ref["res"], rtol=1e-8)
         np.testing.assert_allclose(got.x, ref["x"][lo:hi], rtol=1e-7, atol=1e-9 * np.abs(ref["x"]).max())
@@ -71,7 +78,7 @@ def _worker(rank, world, port, alg, q):
 
 
 @pytest.mark.parametrize("alg,world", [("odir", 2), ("odir_eager", 2), ("omin", 2), ("fused", 2), ("dodir", 2),
-                                       ("odir", 4), ("fused", 4)])
+                                       ("odir", 4), ("fused", 4), ("odir_nd", 2)])
 def test_two_ranks_one_gpu_match_oracle(alg, world):
     """(world = 4: every rank has more than one neighbour in the halo exchange)"""
     import torch.multiprocessing as mp
