@@ -8,7 +8,8 @@
 //   assemble   F = sum of the children's Schur complements (gathered through the row maps the solve
 //              uses for the contribution vectors) + the block's own entries of the pivot columns;
 //   factor     right-looking in blocks of 64 pivots: k_ndf_potrf (the 64 x 64 pivot block, one
-//              workgroup per front), k_ndf_trsm (the rows below it, a thread per row),
+//              workgroup per front; it also leaves the block's inverse above the diagonal),
+//              k_ndf_trsm (the rows below it times that inverse, 64 x 64 tiles),
 //              k_ndf_update (64 x 64 tiles of everything to the right, LDS-tiled products);
 //   invert     P = [I ; L_21] L_11^-1 by the same two kernels run from the last pivot block to the
 //              first (column block J: P(:, J) <- P(:, J) L_JJ^-1, then P(:, J') -= P(:, J) L(J, J')
@@ -127,58 +128,89 @@ __global__ __launch_bounds__(NT) void k_ndf_potrf(pa_ndf_args_t a, const int* __
     if (i < nb && j < nb && i >= j) F[(size_t)(jb + j) * ldf + jb + i] = D[j][i];
   }
   if (tid < nb) a.dinv[a.rows[a.rows_off[g] + jb + tid]] = 1.0 / D[tid][tid];
+  // X = L^-1 of the pivot block, column c by thread c (L x = e_c), kept in the unused triangle above
+  // the diagonal: F(jb + c, jb + i) = X(i, c), i > c.  k_ndf_trsm multiplies with it.
+  // (X(i, c) is parked at D[i][c], an entry above the diagonal that the factorisation does not use)
+  if (tid < nb) {
+    const int c = tid;
+    const double xc = 1.0 / D[c][c];
+    for (int i = c + 1; i < nb; ++i) {
+      double sm = D[c][i] * xc;
+      for (int k = c + 1; k < i; ++k) sm = fma(D[k][i], D[k][c], sm);
+      const double xi = -sm / D[i][i];
+      D[i][c] = xi;
+      F[(size_t)(jb + i) * ldf + jb + c] = xi;
+    }
+  }
 }
 
-// A thread per row, the 64 values of its row in registers.
-//   INV = false: F(i, J) <- F(i, J) L_JJ^-T for the rows below the pivot block (x L^T = f)
-//   INV = true:  P(i, J) <- P(i, J) L_JJ^-1 for the rows from the pivot block down (x L = p)
+// The block column of a step times the inverse of its pivot block (k_ndf_potrf left it above the
+// diagonal), 256 front rows per workgroup as four 64 x 64 tiles, 4 x 4 entries per thread:
+//   INV = false: F(i, J) <- F(i, J) L_JJ^-T for the rows below the pivot block
+//   INV = true:  P(i, J) <- P(i, J) L_JJ^-1 for the rows from the pivot block down
 template <bool INV>
 __global__ __launch_bounds__(NT) void k_ndf_trsm(pa_ndf_args_t a, const int* __restrict__ cfront,
-                                                 const int* __restrict__ crow0, int jb) {
-  __shared__ double Ls[TB][TB + 1];           // Ls[row j][column k] of the pivot block, identity past nb
-  __shared__ double idg[TB];
-  const int g = cfront[blockIdx.x], r0 = crow0[blockIdx.x];
+                                                 const int* __restrict__ crow0, int jb, int split) {
+  __shared__ double As[TB][TB + 4];           // As[k][i]: the block column before the solve
+  __shared__ double Bs[TB][TB + 4];           // Bs[k][j]: X(j, k) (INV = false) or X(k, j) (INV = true), X = L_JJ^-1
+  // split: a workgroup takes one of the four tiles of its chunk (launches of few chunks)
+  const int ch = split ? blockIdx.x >> 2 : blockIdx.x;
+  const int sub0 = split ? (int)(blockIdx.x & 3) : 0, sub1 = split ? sub0 + 1 : NT / TB;
+  const int g = cfront[ch], r0 = crow0[ch];
   const int n = a.n[g];
   if (jb >= n) return;
   const int nb = min(TB, n - jb), f = n + a.m[g], ldf = a.ldf[g];
   const int first = INV ? jb : jb + nb;
-  if (r0 + NT - 1 < first) return;
+  if (r0 + sub1 * TB - 1 < first || r0 + sub0 * TB >= f) return;
   const double* __restrict__ F = front_of(a, g);
+  double* __restrict__ C = INV ? a.F + a.offF[g] : front_of(a, g);
+  const size_t ldc = INV ? (size_t)a.ld[g] : (size_t)ldf;
   const int tid = threadIdx.x;
   for (int e = tid; e < TB * TB; e += NT) {
-    const int k = e >> 6, j = e & 63;         // lanes along the rows of a column: coalesced
-    Ls[j][k] = (j < nb && k < nb && k <= j) ? F[(size_t)(jb + k) * ldf + jb + j] : (j == k ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  if (tid < TB) idg[tid] = 1.0 / Ls[tid][tid];
-  __syncthreads();
-  const int i = r0 + tid;
-  if (i < first || i >= f) return;
-  double* __restrict__ X = INV ? a.F + a.offF[g] : front_of(a, g);
-  const size_t ldx = INV ? (size_t)a.ld[g] : (size_t)ldf;
-  double x[TB];
-#pragma unroll
-  for (int j = 0; j < TB; ++j) x[j] = j < nb ? X[(size_t)(jb + j) * ldx + i] : 0.0;
-  if constexpr (!INV) {
-#pragma unroll
-    for (int j = 0; j < TB; ++j) {
-      double s = x[j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) s = fma(-x[k], Ls[j][k], s);
-      x[j] = s * idg[j];
+    const int hi = e >> 6, lo = e & 63;       // X(hi, lo), hi > lo, sits at F(jb + lo, jb + hi): lanes along lo
+    double v = 0.0;
+    if (hi < nb && lo < nb) {
+      if (hi > lo) v = F[(size_t)(jb + hi) * ldf + jb + lo];
+      else if (hi == lo) v = 1.0 / F[(size_t)(jb + hi) * ldf + jb + hi];
     }
-  } else {
+    if (INV) Bs[hi][lo] = v; else Bs[lo][hi] = v;
+  }
+  const int i0 = (tid & 15) * 4, j0 = (tid >> 4) * 4;
+  for (int sub = sub0; sub < sub1; ++sub) {
+    const int rb = r0 + sub * TB;
+    if (rb + TB - 1 < first || rb >= f) continue;
+    __syncthreads();
+    for (int e = tid; e < TB * TB; e += NT) {
+      const int k = e >> 6, l = e & 63;
+      const int i = rb + l;
+      As[k][l] = (k < nb && i < f) ? C[(size_t)(jb + k) * ldc + i] : 0.0;
+    }
+    __syncthreads();
+    double acc[4][4];
 #pragma unroll
-    for (int j = TB - 1; j >= 0; --j) {
-      double s = x[j];
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int k = j + 1; k < TB; ++k) s = fma(-x[k], Ls[k][j], s);
-      x[j] = s * idg[j];
+      for (int q = 0; q < 4; ++q) acc[p][q] = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < TB; ++k) {
+      const double2 a01 = *reinterpret_cast<const double2*>(&As[k][i0]), a23 = *reinterpret_cast<const double2*>(&As[k][i0 + 2]);
+      const double2 b01 = *reinterpret_cast<const double2*>(&Bs[k][j0]), b23 = *reinterpret_cast<const double2*>(&Bs[k][j0 + 2]);
+      const double av[4] = {a01.x, a01.y, a23.x, a23.y}, bv[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = fma(av[p], bv[q], acc[p][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = j0 + q;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int i = rb + i0 + p;
+        if (j < nb && i >= first && i < f) C[(size_t)(jb + j) * ldc + i] = acc[p][q];
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < TB; ++j)
-    if (j < nb) X[(size_t)(jb + j) * ldx + i] = x[j];
 }
 
 // One 64 x 64 tile, K = the pivot block of this step; a thread owns 4 x 4 entries.
@@ -304,8 +336,10 @@ int pa_k_ndf_potrf(const pa_ndf_args_t* a, const int* fronts, int nfronts, int j
 
 int pa_k_ndf_trsm(const pa_ndf_args_t* a, const int* cfront, const int* crow0, int nchunks, int jb, int inverse) {
   if (nchunks <= 0) return 0;
-  if (inverse) hipLaunchKernelGGL((k_ndf_trsm<true>), dim3(nchunks), dim3(NT), 0, cur_stream(), *a, cfront, crow0, jb);
-  else hipLaunchKernelGGL((k_ndf_trsm<false>), dim3(nchunks), dim3(NT), 0, cur_stream(), *a, cfront, crow0, jb);
+  const int split = nchunks < 4096;
+  const int grid = split ? 4 * nchunks : nchunks;
+  if (inverse) hipLaunchKernelGGL((k_ndf_trsm<true>), dim3(grid), dim3(NT), 0, cur_stream(), *a, cfront, crow0, jb, split);
+  else hipLaunchKernelGGL((k_ndf_trsm<false>), dim3(grid), dim3(NT), 0, cur_stream(), *a, cfront, crow0, jb, split);
   return kfail("k_ndf_trsm");
 }
 
