@@ -499,7 +499,7 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
     d_acol0 = (long long*)pa_rt_malloc((size_t)nsn * sizeof(long long)); d_acp = (long long*)pa_rt_malloc((size_t)ncp * sizeof(long long));
     d_ari = (int*)pa_rt_malloc((size_t)(nnzA ? nnzA : 1) * sizeof(int)); d_acv = (double*)pa_rt_malloc((size_t)(nnzA ? nnzA : 1) * sizeof(double));
     d_front = (unsigned long long*)pa_rt_malloc((size_t)nsn * sizeof(unsigned long long));
-    d_fail = (unsigned long long*)pa_rt_malloc(sizeof(unsigned long long));
+    d_fail = (unsigned long long*)pa_rt_malloc(2 * sizeof(unsigned long long));
     if (!d_child || !d_newrow || !d_acol0 || !d_acp || !d_ari || !d_acv || !d_front || !d_fail)
       rc = PA_FAIL("allocating the inputs of the block factorisation on the device failed: %s", pa_rt_error());
   }
@@ -524,10 +524,10 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
         rc = PA_FAIL("uploading the blocks failed: %s", pa_rt_error());
       cpo += Bx->b + 1; eo += ne;
     }
-    unsigned long long none = ~0ULL;
+    unsigned long long none[2] = {~0ULL, 0ULL};
     if (!rc && (pa_rt_h2d(d_child, h_child, (size_t)2 * nsn * sizeof(int)) || pa_rt_h2d(d_newrow, h_newrow, (size_t)totrows * sizeof(int)) ||
                 pa_rt_h2d(d_acol0, h_acol0, (size_t)nsn * sizeof(long long)) || pa_rt_h2d(d_acp, h_acp, (size_t)ncp * sizeof(long long)) ||
-                pa_rt_h2d(d_fail, &none, sizeof(none))))
+                pa_rt_h2d(d_fail, none, sizeof(none))))
       rc = PA_FAIL("uploading the blocks failed: %s", pa_rt_error());
   }
   pa_ndf_args_t a;
@@ -571,7 +571,8 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
     for (int jb = ((nmax - 1) / 64) * 64; jb >= 0 && !rc; jb -= 64)
       if (pa_k_ndf_trsm(&a, cf, cr, nch, jb, 1) || pa_k_ndf_update(&a, rc_t.f, rc_t.ti, rc_t.tj, rc_t.n, jb, 1))
         rc = PA_FAIL("block factorisation: kernel launch failed");
-    if (!rc && pa_k_ndf_finalize(&a, rc_t.f, rc_t.ti, rc_t.tj, rc_t.n)) rc = PA_FAIL("block factorisation: kernel launch failed");
+    if (!rc && (pa_k_ndf_finalize(&a, rc_t.f, rc_t.ti, rc_t.tj, rc_t.n) || pa_k_ndf_check(&a, d_ids, cnt, nmax)))
+      rc = PA_FAIL("block factorisation: kernel launch failed");
     if (!rc && pa_rt_sync()) rc = PA_FAIL("block factorisation of level %d failed: %s", h, pa_rt_error());
     pa_rt_free(d_ids); nd_tiles_free(&ll); nd_tiles_free(&rc_t);
     /* fronts nobody above this level reads any more */
@@ -584,9 +585,17 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
       }
   }
   if (!rc) {
-    unsigned long long key = ~0ULL;
-    if (pa_rt_d2h(&key, d_fail, sizeof(key))) rc = PA_FAIL("block factorisation: %s", pa_rt_error());
-    else if (key != ~0ULL) { *fail_g = (int)(key >> 32); *fail_col = (int)(key & 0xffffffffULL); rc = 2; }
+    unsigned long long key[2] = {~0ULL, 0ULL};
+    if (pa_rt_d2h(key, d_fail, sizeof(key))) rc = PA_FAIL("block factorisation: %s", pa_rt_error());
+    else if (key[0] != ~0ULL) { *fail_g = (int)(key[0] >> 32); *fail_col = (int)(key[0] & 0xffffffffULL); rc = 2; }
+    else {
+      double dv;
+      memcpy(&dv, &key[1], sizeof(dv));
+      S->inv_dev = dv;
+      if (dv > 1e-6)
+        fprintf(stderr, "[prealps_hip] warning: the pivot triangles of the sparse block factor are ill conditioned "
+                        "(L (L^-1 1) off by %.1e); the block solve loses that much accuracy\n", dv);
+    }
   }
   if (trace) fprintf(stderr, "[nd] numeric phase on the device: %.2f s, at most %.2f GB of fronts at a time\n", pa_wtime() - t0, front_gb_peak);
   for (int h = 0; lvl_buf && h <= maxh; ++h) pa_rt_free(lvl_buf[h]);

@@ -318,9 +318,41 @@ __global__ __launch_bounds__(NT) void k_ndf_finalize(pa_ndf_args_t a, const int*
   }
 }
 
+// How good the inverted pivot triangles are: x = L_11^-1 1 from the finished panel (row sums of T over
+// the pivots), then max |L_11 x - 1| with the factor still in the front; one workgroup per front, the
+// largest value of all fronts lands in a.fail[1] (non-negative doubles order like their bit patterns).
+__global__ __launch_bounds__(NT) void k_ndf_check(pa_ndf_args_t a, const int* __restrict__ fronts) {
+  extern __shared__ double xs[];
+  const int g = fronts[blockIdx.x];
+  const int n = a.n[g], ldf = a.ldf[g], ld = a.ld[g];
+  const double* __restrict__ F = front_of(a, g);
+  const double* __restrict__ P = a.F + a.offF[g];
+  for (int r = threadIdx.x; r < n; r += NT) {
+    double sm = 1.0;                          // T(r, r) = 1
+    for (int j = 0; j < r; ++j) sm += P[(size_t)j * ld + r];
+    xs[r] = sm / F[(size_t)r * ldf + r];      // x = D^-1 T 1
+  }
+  __syncthreads();
+  double worst = 0.0;
+  for (int r = threadIdx.x; r < n; r += NT) {
+    double sm = -1.0;
+    for (int j = 0; j <= r; ++j) sm = fma(F[(size_t)j * ldf + r], xs[j], sm);
+    worst = fmax(worst, fabs(sm));
+  }
+  if (worst > 0.0) atomicMax(a.fail + 1, (unsigned long long)__double_as_longlong(worst));
+}
+
 }  // namespace
 
 extern "C" {
+
+int pa_k_ndf_check(const pa_ndf_args_t* a, const int* fronts, int nfronts, int nmax) {
+  if (nfronts <= 0) return 0;
+  const size_t lds = (size_t)nmax * sizeof(double);
+  if (lds > 64 * 1024) return 0;              // (wider supernodes than the check was written for: skipped)
+  hipLaunchKernelGGL(k_ndf_check, dim3(nfronts), dim3(NT), lds, cur_stream(), *a, fronts);
+  return kfail("k_ndf_check");
+}
 
 int pa_k_ndf_assemble(const pa_ndf_args_t* a, const int* tf, const int* ti, const int* tj, int ntiles,
                       const int* fronts, int nfronts) {

@@ -229,7 +229,7 @@ typedef struct {
  * (-1: none); newrow[rows_off[s] + r] = index of front row r in its block's elimination order;
  * the block's own entries of the pivot columns of s: columns acp[acol0[s] + j] .. of (ari, acv),
  * rows in elimination order, lower triangle.  fail: smallest (supernode << 32 | pivot column) whose
- * pivot was not positive, ~0 if none. */
+ * pivot was not positive, ~0 if none; fail[1]: see pa_k_ndf_check. */
 typedef struct {
   const int* n; const int* m; const int* ld; const long long* offF; const long long* offB; const int* rows_off;
   const int* rows; const int* src; const int* child; const int* newrow;
@@ -247,6 +247,9 @@ int pa_k_ndf_update(const pa_ndf_args_t* a, const int* tf, const int* ti, const 
                     int inverse);
 int pa_k_ndf_pinit(const pa_ndf_args_t* a, const int* cfront, const int* crow0, int nchunks);
 int pa_k_ndf_finalize(const pa_ndf_args_t* a, const int* tf, const int* ti, const int* tj, int ntiles);
+/* after finalize: fail[1] = max over the fronts of |L_11 (L_11^-1 1) - 1| with the inverse taken from the
+ * finished panels (bit pattern of a non-negative double) */
+int pa_k_ndf_check(const pa_ndf_args_t* a, const int* fronts, int nfronts, int nmax);
 
 int pa_nd_chunk_rows(void);           /* front rows per forward workgroup */
 int pa_nd_block_cols(void);           /* pivot columns per backward workgroup */

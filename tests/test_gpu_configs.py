@@ -311,6 +311,8 @@ def test_large_blocks_sparse_factor(kind, t, variant, monkeypatch):
             assert prob.stat("bj_nd_blocks") == (P if mode == "1" else 0)
             if mode == "1":
                 nd_bytes = prob.stat("bj_factor_bytes")
+                # the inverted pivot triangles, checked where they were made (device: k_ndf_check)
+                assert 0.0 < prob.stat("bj_nd_inverse_dev") < 1e-10
             else:
                 assert nd_bytes < prob.stat("bj_factor_bytes")          # the sparse factor is the smaller one
         finally:
