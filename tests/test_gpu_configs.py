@@ -323,6 +323,53 @@ def test_large_blocks_sparse_factor(kind, t, variant, monkeypatch):
         np.testing.assert_allclose(out[mode], zr, rtol=tol, atol=tol * np.abs(zr).max())
 
 
+def test_large_blocks_that_are_no_grids(monkeypatch):
+    """The sparse factor (ordering, device factorisation, selective inversion, level-scheduled
+    solve) on blocks without geometry: a random pattern (expander-like, separators of hundreds of
+    columns -> chains of supernodes), nearest-neighbour links of random points in a cube, and a block
+    made of two disconnected halves; against the oracle's exact block solve and in a full ECG solve."""
+    from oracle import oracle as O
+    from scipy.spatial import cKDTree
+    monkeypatch.setenv("PREALPS_BJ_ND", "2")
+    nb, P, t = 2600, 4, 4
+    rng = np.random.default_rng(7)
+    blocks = []
+    for p in range(P):
+        if p == 2:
+            h = nb // 2
+            M = sp.block_diag([sp.random(h, h, density=6.0 / h, random_state=rng),
+                               sp.random(nb - h, nb - h, density=14.0 / nb, random_state=rng)], format="csr")
+        elif p == 1:
+            pts = rng.random((nb, 3))
+            _, idx = cKDTree(pts).query(pts, k=9)
+            M = sp.csr_matrix((rng.random(8 * nb), (np.repeat(np.arange(nb), 8), idx[:, 1:].ravel())), shape=(nb, nb))
+        else:
+            M = sp.random(nb, nb, density=5.0 / nb, random_state=rng, format="csr")
+        blocks.append(M + M.T)
+    A = sp.lil_matrix(sp.block_diag(blocks))
+    for _ in range(100):                       # a few couplings between the blocks
+        i, j = rng.integers(0, nb * P, 2)
+        A[i, j] = A[j, i] = 0.1
+    A = sp.csr_matrix(A)
+    A = sp.csr_matrix(A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 0.5))
+    A.sort_indices()
+    part = (np.arange(nb * P) // nb).astype(np.int32)
+    prob, B, rowpos = _problem(A, P, part)
+    try:
+        X = rng.standard_normal((B.shape[0], t))
+        zr = O.BlockJacobi(B, rowpos).apply(X)
+        got = prob.block_jacobi_apply(X, t)
+        assert prob.stat("bj_nd_blocks") == P and prob.stat("bj_nd_inverse_dev") < 1e-11
+        np.testing.assert_allclose(got, zr, rtol=1e-10, atol=1e-11 * np.abs(zr).max())
+        rhs = prob.reference_rhs()
+        res = prob.solve(rhs, t)
+        ref = O.ECG(B, rowpos, t).solve(rhs)
+        assert res.iters == ref["iters"]
+        np.testing.assert_allclose(res.res, ref["res"], rtol=1e-7)
+    finally:
+        prob.close()
+
+
 def test_large_blocks_ecg_and_mixed_sizes(monkeypatch):
     """ECG on a partition that mixes one large block (sparse factor) with many small ones (band
     kernels), every leaf size of the dissection, and a non-SPD large block reported as such."""
