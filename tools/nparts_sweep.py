@@ -17,6 +17,9 @@ if shuffle:
     import scipy.sparse as sp
     N = len(rp) - 1
     pm = np.random.default_rng(3).permutation(N)
+    if "--nodes" in sys.argv and wl == "elasticity":      # renumber the nodes, keep a node's 3 dofs together (what FE codes write)
+        pn = np.random.default_rng(3).permutation(N // 3)
+        pm = (3 * pn[:, None] + np.arange(3)[None, :]).ravel()
     A = sp.csr_matrix((v, ci, rp), shape=(N, N))[pm][:, pm]
     A.sort_indices()
     rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
@@ -35,7 +38,7 @@ for name, box in cases:
     prob.create_block_jacobi()
     setup = time.time() - t0
     r = prob.solve(prob.reference_rhs(), t, max_iter=5000)
-    print(json.dumps({"workload": "%s %d^3" % (wl, n), "t": t, "nparts": int(P), "partition": ("library k-way, rows randomly renumbered" if shuffle else "library k-way") if kway else "boxes %s" % (box,),
+    print(json.dumps({"workload": "%s %d^3" % (wl, n), "t": t, "nparts": int(P), "partition": (("library k-way, nodes randomly renumbered" if "--nodes" in sys.argv else "library k-way, rows randomly renumbered") if shuffle else "library k-way") if kway else "boxes %s" % (box,),
                       "iterations": int(r.iters), "solve_seconds": r.seconds, "iterations_per_s": r.iters / r.seconds,
                       "setup_seconds": setup, "partition_seconds": tp, "factor_GB": prob.stat("bj_factor_bytes") / 1e9,
                       "sparse_factor_blocks": int(prob.stat("bj_nd_blocks")), "bj_max_bandwidth": int(prob.stat("bj_max_bandwidth")),
