@@ -587,6 +587,8 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
   if (!rc) {
     unsigned long long key[2] = {~0ULL, 0ULL};
     if (pa_rt_d2h(key, d_fail, sizeof(key))) rc = PA_FAIL("block factorisation: %s", pa_rt_error());
+    else if (key[0] != ~0ULL && (key[0] & 0xffffffffULL) == 0xffffffffULL)
+      rc = PA_FAIL("block factorisation: an entry of supernode %d has no row in its front (symbolic structure inconsistent)", (int)(key[0] >> 32));
     else if (key[0] != ~0ULL) { *fail_g = (int)(key[0] >> 32); *fail_col = (int)(key[0] & 0xffffffffULL); rc = 2; }
     else {
       double dv;

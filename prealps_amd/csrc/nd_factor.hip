@@ -85,6 +85,10 @@ __global__ __launch_bounds__(NT) void k_ndf_scatter(pa_ndf_args_t a, const int* 
       else {
         int lo = 0, hi = m;                   // first below-row >= ri (it is there: symbolic phase)
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (newrow[n + mid] < ri) lo = mid + 1; else hi = mid; }
+        if (lo >= m || newrow[n + lo] != ri) {             // cannot happen with a consistent symbolic phase: say so
+          atomicMin(a.fail, ((unsigned long long)(unsigned)g << 32) | 0xffffffffULL);
+          continue;
+        }
         r = n + lo;
       }
       F[(size_t)j * ldf + r] += a.acv[e];

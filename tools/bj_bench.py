@@ -14,6 +14,14 @@ if wl == "poisson":
     rp, ci, v = gen.poisson3d_csr(n); part, P = gen.box_partition(n, box)
 else:
     rp, ci, v = gen.elasticity3d_csr(n); part, P = gen.box_partition_nodes(n, box)
+if os.environ.get("BJ_BENCH_SHUFFLE") == "nodes" and wl != "poisson":    # renumber the nodes at random (dof triples kept)
+    import scipy.sparse as sp
+    N = len(rp) - 1
+    pn = np.random.default_rng(3).permutation(N // 3)
+    pm = (3 * pn[:, None] + np.arange(3)[None, :]).ravel()
+    A = sp.csr_matrix((v, ci, rp), shape=(N, N))[pm][:, pm]
+    A.sort_indices()
+    rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
 t0 = time.time()
 if kway:
     from prealps_amd.solver import partition_kway
@@ -42,4 +50,5 @@ both = timeit(alt)
 print("%s n=%d box=%s t=%d parts=%d%s env=%s: bj %.1f us, spmm %.1f us, alternating pair %.1f us; band %d, factor %.0f MB, bj setup %.2fs, partition %.2fs" % (
     wl, n, box, t, P, " (kway)" if kway else "", {k: os.environ[k] for k in os.environ if k.startswith("PREALPS_")}, bj, sp_, both,
     prob.stat("bj_max_bandwidth"), prob.stat("bj_factor_bytes") / 1e6, tbj, tpart), flush=True)
+print("   spmm plan: runs %d staged %d stream bytes %.0f MB, blocks %d, halo rows %d" % (prob.stat("spmm_runs"), prob.stat("spmm_staged"), prob.stat("spmm_stream_bytes") / 1e6, prob.stat("spmm_blocks"), prob.stat("halo_rows")), flush=True)
 prob.close()
