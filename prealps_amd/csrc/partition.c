@@ -141,7 +141,9 @@ typedef struct {
   keyidx_t* ki;    /* (projection, list-local index), sorted along the axis */
   char* side;      /* list-local */
   int* tmp;        /* n ints */
-  int next_tag, cur_tag;
+  int tag_store;   /* (the counter next_tag points at, in the root context) */
+  int* next_tag;   /* shared by the contexts of one recursion: every cut takes a fresh id (atomic) */
+  int cur_tag;
   int smooth;      /* sweeps of neighbour averaging applied to the projection */
   double* z;       /* 3 * n whitened principal coordinates, list-local */
 } rb_t;
@@ -171,7 +173,7 @@ static int rb_bfs(rb_t* c, const int* list, int len, int tag, int start, int* di
 static int rb_bisect(rb_t* c, const int* list, int len, long long wtot, long long want, int min0, int min1,
                      long long* w0) {
   const graph_t* g = c->g;
-  const int tag = c->next_tag++;
+  const int tag = __atomic_fetch_add(c->next_tag, 1, __ATOMIC_RELAXED);
   for (int i = 0; i < len; ++i) { c->tag[list[i]] = tag; c->loc[list[i]] = i; }
   c->cur_tag = tag;
   /* landmarks by farthest-point sampling; a vertex another component hides from all landmarks
@@ -397,14 +399,28 @@ static void rb_split(rb_t* c, int* list, int len, long long wtot, int k, int bas
   int a = 0, b = 0;
   for (int i = 0; i < len; ++i) if (!c->side[i]) list[a++] = list[i]; else c->tmp[b++] = list[i];
   memcpy(list + a, c->tmp, (size_t)b * sizeof(int));
-  rb_split(c, list, a, wl, k1, base);
-  rb_split(c, list + a, b, wtot - wl, k2, base + k1);
+  /* The two halves are independent: the right one works in the part of every list-local buffer that
+   * lies behind the left one's (the sub-lists are disjoint ranges of one array, tag / loc are indexed
+   * by vertex), so they can run as tasks.  The result does not depend on the schedule.  (A task may
+   * read tag[v] of a vertex of ANOTHER sub-list while that one's task relabels it: both the old
+   * and the new value differ from the reader's own tag, which is all the reader asks.) */
+  rb_t cr = *c;
+  cr.queue += a; cr.dist += (size_t)NLM * a; cr.ki += a; cr.side += a; cr.tmp += a; cr.z += (size_t)3 * a;
+  if (len >= 4096) {
+#pragma omp task default(shared) firstprivate(cr)
+    { rb_t c2 = cr; rb_split(&c2, list + a, b, wtot - wl, k2, base + k1); }
+    rb_split(c, list, a, wl, k1, base);
+#pragma omp taskwait
+  } else {
+    rb_split(c, list, a, wl, k1, base);
+    rb_split(&cr, list + a, b, wtot - wl, k2, base + k1);
+  }
 }
 
 static int rb_alloc(rb_t* c, const graph_t* g, int* part) {
   int n = g->n;
   memset(c, 0, sizeof(*c));
-  c->g = g; c->part = part; c->next_tag = 1;
+  c->g = g; c->part = part; c->tag_store = 1; c->next_tag = &c->tag_store;
   c->tag = (int*)calloc((size_t)n, sizeof(int)); c->loc = (int*)malloc((size_t)n * sizeof(int));
   c->queue = (int*)malloc((size_t)n * sizeof(int)); c->dist = (int*)malloc((size_t)NLM * n * sizeof(int));
   c->ki = (keyidx_t*)malloc((size_t)n * sizeof(keyidx_t));
@@ -425,6 +441,8 @@ static int bisect(const graph_t* g, int k, int* part) {
   if (!rc) {
     long long wtot = 0;
     for (int v = 0; v < n; ++v) { list[v] = v; wtot += g->vw[v]; }
+#pragma omp parallel num_threads(pa_host_threads())
+#pragma omp single
     rb_split(&c, list, n, wtot, k, 0);
   }
   rb_free(&c); free(list);
@@ -731,6 +749,8 @@ int preAlps_hip_partition_kway(int N, const int* rowPtr, const int* colInd, int 
   memset(&g, 0, sizeof(g));
   const char* me = getenv("PREALPS_PARTITION_MERGE");
   int merge = me ? atoi(me) : 1;
+  const int trace = getenv("PREALPS_PARTITION_TRACE") != NULL;
+  double t0 = pa_wtime();
   int rc = build_graph(N, rowPtr, colInd, merge, cid, &g);
   if (!rc && merge && g.n < 4 * (long long)nparts && g.n < N) {   /* too few merged vertices per part: plain rows */
     graph_free(&g);
@@ -739,8 +759,12 @@ int preAlps_hip_partition_kway(int N, const int* rowPtr, const int* colInd, int 
   if (rc) { graph_free(&g); free(cid); return PA_FAIL("out of host memory for the adjacency graph"); }
   int* cpart = (int*)malloc((size_t)g.n * sizeof(int));
   rc = !cpart;
+  double t1 = pa_wtime();
   if (!rc) rc = bisect(&g, nparts, cpart);
+  double t2 = pa_wtime();
   if (!rc) rc = join_fragments(&g, nparts, cpart, (long long)N / nparts / 8 + 1);
+  if (trace) fprintf(stderr, "[partition] graph of %d vertices %.2f s, bisection %.2f s (%d threads), fragments %.2f s\n",
+                     g.n, t1 - t0, t2 - t1, pa_host_threads(), pa_wtime() - t2);
   if (!rc)
     for (int i = 0; i < N; ++i) part[i] = cpart[cid[i]];
   graph_free(&g); free(cid); free(cpart);
