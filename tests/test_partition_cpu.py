@@ -106,3 +106,28 @@ def test_more_components_than_parts_and_tiny_graphs():
     assert sorted(part) == list(range(14))
     with pytest.raises(prealps_amd.PreAlpsError):
         partition_kway(L.indptr, L.indices, 15)
+
+
+def test_same_parts_for_every_thread_count():
+    """The halves of a cut are bisected as OpenMP tasks: the part vector must not depend on how many
+    threads there are (every rank of a multi-GPU run computes the partition on its own and they must
+    agree), nor on the schedule (repeated runs)."""
+    import hashlib
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import hashlib\n"
+        "from prealps_amd import gen\n"
+        "from prealps_amd.solver import partition_kway\n"
+        "rp, ci, v = gen.elasticity3d_csr(24)\n"
+        "print(hashlib.md5(partition_kway(rp, ci, 300).tobytes()).hexdigest())\n"
+        "rp, ci, v = gen.poisson3d_csr(36)\n"
+        "print(hashlib.md5(partition_kway(rp, ci, 77).tobytes()).hexdigest())\n") % ROOT
+    seen = set()
+    for threads in ("1", "3", "8", "8"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, OMP_NUM_THREADS=threads))
+        assert r.returncode == 0, r.stderr[-800:]
+        seen.add(r.stdout)
+    assert len(seen) == 1, seen
