@@ -111,12 +111,13 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
   int rc = pa_nd_order(b, lrp, lci, leaf_rows, &B->tree);
   free(lrp); free(lci);
   if (rc) return 1;
-  /* Wide supernodes (the separators at the top of the tree: 1000-2000 columns) are cut into chains
-   * of at most `width` columns, each piece the only child of the next.  The triangular part of a
-   * piece is a handful of pivot blocks on one workgroup and everything below it -- the later
-   * pieces included -- is rectangular work that the split kernels spread over the chip; one
-   * workgroup marching through 30 pivot blocks of a 2000-column front was the longest chain of
-   * the whole sweep.  Same entries, same arithmetic. */
+  /* Wide supernodes (the separators at the top of the tree) are cut into chains of at most `width`
+   * columns (PREALPS_ND_WIDTH, 512), each piece the only child of the next: it bounds the work of
+   * inverting a pivot triangle and forming G (n^2 (n / 3 + m) per front) and the unused square above
+   * the triangle in the panels.  Same entries, same arithmetic.  Measured on elasticity 70^3: 64
+   * blocks of 17.5 k rows do not care (2.30 / 2.36 / 2.30 ms per apply at 512 / 1024 / 2048); 8 blocks
+   * of 128 k rows solve 9 % faster at 2048 (4.88 against 5.35 ms per apply) but their numeric phase
+   * takes twice as long (2.4 s of setup against 1.2 s for a 0.45 s solve), hence 512. */
   {
     const char* we = getenv("PREALPS_ND_WIDTH");
     const int width = we ? atoi(we) : 512;
