@@ -111,16 +111,16 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
   int rc = pa_nd_order(b, lrp, lci, leaf_rows, &B->tree);
   free(lrp); free(lci);
   if (rc) return 1;
-  /* Wide supernodes (the separators at the top of the tree) are cut into chains of at most `width`
-   * columns (PREALPS_ND_WIDTH, 512), each piece the only child of the next: it bounds the work of
-   * inverting a pivot triangle and forming G (n^2 (n / 3 + m) per front) and the unused square above
-   * the triangle in the panels.  Same entries, same arithmetic.  Measured on elasticity 70^3: 64
-   * blocks of 17.5 k rows do not care (2.30 / 2.36 / 2.30 ms per apply at 512 / 1024 / 2048); 8 blocks
-   * of 128 k rows solve 9 % faster at 2048 (4.88 against 5.35 ms per apply) but their numeric phase
-   * takes twice as long (2.4 s of setup against 1.2 s for a 0.45 s solve), hence 512. */
+  /* Very wide supernodes (the top separators of blocks of 100 k rows and more) are cut into chains of
+   * at most `width` columns (PREALPS_ND_WIDTH, 2048), each piece the only child of the next: it bounds
+   * the work of inverting a pivot triangle and forming G (n^2 (n / 3 + m) per front) and the unused
+   * square above the triangle in the panels.  Same entries, same arithmetic.  Measured on elasticity
+   * 70^3, same box: 64 blocks of 17.5 k rows do not care (2.24 ms per apply at 512 and at 2048); 8
+   * blocks of 128 k rows: 5.32 / 4.89 / 4.70 ms per apply and 0.59 / 0.60 / 0.63 s of numeric phase at
+   * 512 / 1024 / 2048 (fewer levels = fewer launches), 4.5 % more memory at 2048. */
   {
     const char* we = getenv("PREALPS_ND_WIDTH");
-    const int width = we ? atoi(we) : 512;
+    const int width = we ? atoi(we) : 2048;
     const int n0 = B->tree.nsn;
     int extra_tot = 0;
     int* base = (int*)malloc(((size_t)n0 + 1) * sizeof(int));
@@ -469,6 +469,31 @@ static int nd_tiles_build(nd_tiles_t* t, const int* ids, int cnt, const int* h_n
   return bad;
 }
 
+/* hipMalloc maps memory eagerly, tens of milliseconds per gigabyte: the level buffers of the fronts
+ * are recycled through a small free list (best fit) instead of being returned and asked for again. */
+typedef struct { void* p[64]; size_t bytes[64]; int n; } nd_pool_t;
+static void* nd_pool_get(nd_pool_t* pool, size_t bytes, size_t* got) {
+  int best = -1;
+  for (int i = 0; i < pool->n; ++i)
+    if (pool->bytes[i] >= bytes && (best < 0 || pool->bytes[i] < pool->bytes[best])) best = i;
+  if (best >= 0) {
+    void* p = pool->p[best]; *got = pool->bytes[best];
+    pool->p[best] = pool->p[pool->n - 1]; pool->bytes[best] = pool->bytes[pool->n - 1]; --pool->n;
+    return p;
+  }
+  *got = bytes;
+  return pa_rt_malloc(bytes);
+}
+static void nd_pool_put(nd_pool_t* pool, void* p, size_t bytes) {
+  if (!p) return;
+  if (pool->n < 64) { pool->p[pool->n] = p; pool->bytes[pool->n++] = bytes; }
+  else pa_rt_free(p);
+}
+static void nd_pool_drain(nd_pool_t* pool) {
+  for (int i = 0; i < pool->n; ++i) pa_rt_free(pool->p[i]);
+  pool->n = 0;
+}
+
 /* Factor all blocks level by level.  S holds the uploaded plan (n, m, ld, offsets, rows, src, the
  * forward chunk lists); B the symbolic structure of the blocks, sn0 their first supernode ids.
  * Returns 0, 1 (resources; PA_FAIL raised) or 2 (*fail_g / *fail_col: first non-positive pivot). */
@@ -492,9 +517,12 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
   long long *d_acol0 = NULL, *d_acp = NULL;
   double* d_acv = NULL;
   unsigned long long *d_front = NULL, *d_fail = NULL;
+  nd_pool_t pool;
+  pool.n = 0;
+  size_t* lvl_bytes = (size_t*)calloc((size_t)maxh + 1, sizeof(size_t));
   void** lvl_buf = (void**)calloc((size_t)maxh + 1, sizeof(void*));
   int* lvl_maxpar = (int*)malloc(((size_t)maxh + 1) * sizeof(int));
-  if (!lvl_buf || !lvl_maxpar) rc = PA_FAIL("out of host memory for the block factorisation");
+  if (!lvl_buf || !lvl_maxpar || !lvl_bytes) rc = PA_FAIL("out of host memory for the block factorisation");
   if (!rc) {
     d_child = (int*)pa_rt_malloc((size_t)2 * nsn * sizeof(int)); d_newrow = (int*)pa_rt_malloc((size_t)(totrows ? totrows : 1) * sizeof(int));
     d_acol0 = (long long*)pa_rt_malloc((size_t)nsn * sizeof(long long)); d_acp = (long long*)pa_rt_malloc((size_t)ncp * sizeof(long long));
@@ -538,7 +566,8 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
   a.ari = d_ari; a.acv = d_acv; a.front = d_front; a.ldf = S->d_ld; a.F = S->d_F; a.B = S->d_B; a.dinv = S->d_dinv; a.fail = d_fail;
   int* ids = (int*)malloc((size_t)(nsn ? nsn : 1) * sizeof(int));
   if (!ids && !rc) rc = PA_FAIL("out of host memory for the block factorisation");
-  double front_gb_peak = 0.0, front_gb_now = 0.0;
+  double front_gb_peak = 0.0, front_gb_now = 0.0, t_malloc = 0.0, t_free = 0.0, t_sync = 0.0;
+  const double t_levels0 = pa_wtime();
   for (int h = 0; h <= maxh && !rc; ++h) {
     int cnt = 0, nmax = 0;
     size_t doubles = 0;
@@ -548,7 +577,9 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
       doubles += (size_t)h_ld[g] * (size_t)(h_n[g] + h_m[g]);
     }
     if (!cnt) continue;
-    lvl_buf[h] = pa_rt_malloc((doubles ? doubles : 1) * sizeof(double));
+    double tm0 = pa_wtime();
+    lvl_buf[h] = nd_pool_get(&pool, (doubles ? doubles : 1) * sizeof(double), &lvl_bytes[h]);
+    t_malloc += pa_wtime() - tm0;
     if (!lvl_buf[h]) { rc = PA_FAIL("block factorisation: %.2f GB for the fronts of level %d: %s", 8e-9 * (double)doubles, h, pa_rt_error()); break; }
     front_gb_now += 8e-9 * (double)doubles;
     if (front_gb_now > front_gb_peak) front_gb_peak = front_gb_now;
@@ -574,7 +605,9 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
         rc = PA_FAIL("block factorisation: kernel launch failed");
     if (!rc && (pa_k_ndf_finalize(&a, rc_t.f, rc_t.ti, rc_t.tj, rc_t.n) || pa_k_ndf_check(&a, d_ids, cnt, nmax)))
       rc = PA_FAIL("block factorisation: kernel launch failed");
+    tm0 = pa_wtime();
     if (!rc && pa_rt_sync()) rc = PA_FAIL("block factorisation of level %d failed: %s", h, pa_rt_error());
+    t_sync += pa_wtime() - tm0;
     pa_rt_free(d_ids); nd_tiles_free(&ll); nd_tiles_free(&rc_t);
     /* fronts nobody above this level reads any more */
     for (int l = 0; l <= h; ++l)
@@ -582,7 +615,9 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
         size_t dl = 0;
         for (int g = 0; g < nsn; ++g) if (h_height[g] == l) dl += (size_t)h_ld[g] * (size_t)(h_n[g] + h_m[g]);
         front_gb_now -= 8e-9 * (double)dl;
-        pa_rt_free(lvl_buf[l]); lvl_buf[l] = NULL;
+        tm0 = pa_wtime();
+        nd_pool_put(&pool, lvl_buf[l], lvl_bytes[l]); lvl_buf[l] = NULL;
+        t_free += pa_wtime() - tm0;
       }
   }
   if (!rc) {
@@ -600,9 +635,12 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
                         "(L (L^-1 1) off by %.1e); the block solve loses that much accuracy\n", dv);
     }
   }
-  if (trace) fprintf(stderr, "[nd] numeric phase on the device: %.2f s, at most %.2f GB of fronts at a time\n", pa_wtime() - t0, front_gb_peak);
+  if (trace) fprintf(stderr, "[nd] numeric phase on the device: %.2f s (inputs %.2f s; levels: allocating fronts %.2f s, freeing %.2f s, "
+                             "waiting for the kernels %.2f s), at most %.2f GB of fronts at a time\n",
+                     pa_wtime() - t0, t_levels0 - t0, t_malloc, t_free, t_sync, front_gb_peak);
   for (int h = 0; lvl_buf && h <= maxh; ++h) pa_rt_free(lvl_buf[h]);
-  free(lvl_buf); free(lvl_maxpar); free(ids);
+  nd_pool_drain(&pool);
+  free(lvl_buf); free(lvl_bytes); free(lvl_maxpar); free(ids);
   pa_rt_free(d_child); pa_rt_free(d_newrow); pa_rt_free(d_acol0); pa_rt_free(d_acp); pa_rt_free(d_ari); pa_rt_free(d_acv);
   pa_rt_free(d_front); pa_rt_free(d_fail);
   free(h_child); free(h_parent_h); free(h_newrow); free(h_acol0); free(h_front); free(h_acp);
