@@ -370,6 +370,32 @@ def test_large_blocks_that_are_no_grids(monkeypatch):
         prob.close()
 
 
+def test_mtx_file_with_every_default(tmp_path):
+    """The reference driver's path with nothing chosen by hand: a MatrixMarket file, the library's
+    partitioner (8 parts of 8000 rows, band ~340), which are large enough for the sparse factor, factored on the
+    device -- the same iterations and residuals as the oracle on the partition the library made."""
+    import scipy.io
+    import prealps_amd as pa
+    from oracle import oracle as O
+    n = 40
+    A = O.poisson3d(n)
+    f = str(tmp_path / "p40.mtx")
+    scipy.io.mmwrite(f, sp.tril(A), symmetry="symmetric")
+    prob = pa.EcgProblem.from_mtx(f, 8)
+    try:
+        prob.create_block_jacobi()
+        assert prob.stat("bj_nd_blocks") == 8 and prob.stat("bj_nd_inverse_dev") < 1e-11
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, 4)
+        part = prob.part_vector()
+        B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, 8)
+        ref = O.ECG(B, rowpos, 4).solve(O.reference_rhs(rowpos))
+        assert got.iters == ref["iters"]
+        np.testing.assert_allclose(got.res, ref["res"], rtol=1e-8)
+    finally:
+        prob.close()
+
+
 def test_large_blocks_ecg_and_mixed_sizes(monkeypatch):
     """ECG on a partition that mixes one large block (sparse factor) with many small ones (band
     kernels), every leaf size of the dissection, and a non-SPD large block reported as such."""
