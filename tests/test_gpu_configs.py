@@ -514,7 +514,7 @@ part2, P2 = gen.box_partition(12, (4, 4, 4))
 rp, ci, v = O.as_csr(A2)
 prob2 = prealps_amd.EcgProblem(rp, ci, v, P2, part2, scale=True, device=0)
 B2, perm2, rowpos2 = O.permute_by_part(O.symrac_scale(A2), part2, P2)
-for t in (2, 4):
+for t in (2, 4, 8, 16):      # (8 and 16: the matrix-core kernels, or -- PREALPS_BJ_SPLIT -- column groups of 4 on the paired records)
     X = np.random.default_rng(t).standard_normal((B2.shape[0], t))
     zr = O.BlockJacobi(B2, rowpos2).apply(X)
     np.testing.assert_allclose(prob2.block_jacobi_apply(X, t), zr, rtol=1e-9, atol=1e-10 * np.abs(zr).max())
