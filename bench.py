@@ -65,7 +65,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-ROUND = "r02"
+ROUND = "r03"
 
 
 def parse():
@@ -79,7 +79,16 @@ def parse():
     ap.add_argument("--box", type=str, default="", help="subdomain box in nodes; default 5,5,10 (poisson) / 2,4,8 (elasticity)")
     ap.add_argument("--nparts", type=int, default=0,
                     help="number of subdomains from the library's own graph partitioner instead of --box")
-    ap.add_argument("--alg", type=str, default="odir", choices=["odir", "omin", "fused"])
+    ap.add_argument("--alg", type=str, default="auto", choices=["auto", "odir", "omin", "fused"],
+                    help="auto: Orthodir on one GPU; with several, the one-collective fused Orthodir of "
+                         "examples/test_ecg_bench_fused.c (one all-reduce per iteration instead of two)")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="rehearse ONE rank of a G-GPU run on this one GPU (with --shard r): the rank's rows, plan, "
+                         "kernels and stream choreography; sums are local, halo rows arrive as zeros")
+    ap.add_argument("--shard", type=int, default=0)
+    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel of an iteration (no HIP graphs)")
+    ap.add_argument("--survey-cpu-iters", type=int, default=4,
+                    help="CPU baselines at the survey's subdomain count: iterations per port (0 skips them)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--spmm-reps", type=int, default=50)
@@ -136,6 +145,10 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(a))
+    if a.shard_of and (a.gpus != 1 or not (0 <= a.shard < a.shard_of)):
+        raise SystemExit("--shard-of G needs --gpus 1 and 0 <= --shard < G")
+    if a.alg == "auto":
+        a.alg = "fused" if (a.gpus > 1 or a.shard_of > 1) else "odir"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -179,8 +192,11 @@ def main():
     nnz = len(val)
     t_setup = time.perf_counter()
     prob = prealps_amd.EcgProblem(rowptr, colind, val, nparts, part, scale=True, device=local_rank,
-                                  distributed=distributed, partitioner=(a.nparts > 0))
+                                  distributed=distributed, partitioner=(a.nparts > 0),
+                                  shard=(a.shard, a.shard_of) if a.shard_of > 1 else None)
     L = prob.L
+    if a.no_graphs:
+        L.preAlps_hip_graphs(0)
     prob.create_block_jacobi()
     check(L.preAlps_hip_prepare_operator(a.t), "prepare_operator")   # the SpMM plan is part of the setup
     t_setup = time.perf_counter() - t_setup
@@ -190,9 +206,11 @@ def main():
         dist.all_gather_object(kinds, prob.comm_kind)
         if len(set(kinds)) != 1:
             raise SystemExit("bench.py: ranks disagree on the communication binding: %s" % kinds)
-        if backend == "nccl" and prob.comm_kind != "rccl" and rank == 0:
-            print("bench.py: native RCCL binding not in use (comm = %s): collectives go through "
-                  "torch.distributed callbacks" % prob.comm_kind, file=sys.stderr)
+        if backend == "nccl" and prob.comm_kind != "rccl" and os.environ.get("PREALPS_COMM") != "torch":
+            # a multi-GPU number measured through Python callbacks would not be the product's: refuse it
+            raise SystemExit("bench.py: the nccl backend is in use but the library's native RCCL binding is not "
+                             "(comm = %s); PREALPS_COMM=torch measures the torch.distributed hooks on purpose"
+                             % prob.comm_kind)
     rhs = prob.reference_rhs()
     alg = {"odir": pl.ORTHODIR, "omin": pl.ORTHOMIN, "fused": pl.ORTHODIR_FUSED}[a.alg]
     e = prob.new_ecg(a.t, alg, pl.NO_BS_RED, 1e-5, 100000)
@@ -213,8 +231,11 @@ def main():
 
     run_iterations(prob, e, rhs, L, a.warmup, state)
     barrier()
+    dev_s = C.c_double()
+    check(L.preAlps_hip_timer_start(), "timer_start")      # hipEvents on the library stream around the same region
     t0 = time.perf_counter()
     run_iterations(prob, e, rhs, L, a.steps, state)
+    check(L.preAlps_hip_timer_stop(C.byref(dev_s)), "timer_stop")
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
@@ -306,12 +327,13 @@ def main():
     out = {
         "metric": "ECG iters/sec + SpMM HBM GB/s (% roofline), 3D-elasticity n~1M t=4",
         "value": its, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": 1e3 * dt / a.steps, "device_ms_per_step": 1e3 * dev_s.value / a.steps,
+        "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s (N=%d, nnz=%d), ECG %s + block-Jacobi, t=%d, tol 1e-5" % (wname, N, nnz, a.alg, a.t),
                    "nparts": int(nparts), "partition": "library k-way" if a.nparts > 0 else "boxes of %s nodes" % (list(box),),
                    "parallelism": "rows x%d" % world,
-                   "comm": prob.comm_kind, "halo_rows_per_rank": halo_rows,
+                   "comm": prob.comm_kind, "hip_graphs": not a.no_graphs and os.environ.get("PREALPS_ECG_GRAPH", "1") != "0", "halo_rows_per_rank": halo_rows,
                    "restarts_in_timed_region": state["restarts"],
                    "iterations_to_converge": state["last_iters"], "setup_seconds": t_setup,
                    "setup_breakdown_s": {k: prob.stat("setup_" + k + "_s") for k in ("build", "plan", "bj_factor", "bj_layout")},
@@ -326,15 +348,31 @@ def main():
                      "note": "each timed launch follows one preconditioner apply (cache state of the solver loop)"},
         "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "factor_bytes": prob.stat("bj_factor_bytes"),
                          "achieved_GBs": bj_bytes / bj_s / 1e9,
-                         # the 4-column sweep reads the paired copy of the records (8 % larger at band 35)
-                         "streamed_record_bytes": (prob.stat("bj_pairs_bytes") if a.t <= 4 and prob.stat("bj_pairs_bytes") > 0
+                         # panels of up to 4 columns read ONE copy of the band for both sweeps (bj_g4.hip), or the
+                         # paired copy of both sweeps' records where that kernel does not apply
+                         "streamed_record_bytes": (prob.stat("bj_g4_bytes") if a.t <= 4 and prob.stat("bj_g4_bytes") > 0 else
+                                                   prob.stat("bj_pairs_bytes") if a.t <= 4 and prob.stat("bj_pairs_bytes") > 0
                                                    else prob.stat("bj_factor_bytes")),
-                         "note": "achieved_GBs counts the plain factor (algorithmic bytes) + the panels"},
+                         "streamed_GBs": ((prob.stat("bj_g4_bytes") if a.t <= 4 and prob.stat("bj_g4_bytes") > 0 else
+                                           prob.stat("bj_factor_bytes")) + 16.0 * m_loc * a.t) / bj_s / 1e9,
+                         "note": "achieved_GBs counts the plain two-sweep factor of SURVEY 8(d) (algorithmic bytes) + the "
+                                 "panels; streamed_GBs what the kernel really reads and writes"},
         "phases": {"iterations": a.phase_iters, "device_us_per_iteration": per_it,
                    "ecg_struct_timers_s": ecg_fields,
                    "note": "hipEvent pairs per phase (max over ranks); dense = gram + trsm + update + small; the pass "
                            "syncs after every phase, so its total is above ms_per_step"},
     }
+    if a.shard_of > 1:
+        kern = sum(per_it.get(k, 0.0) for k in PHASE_KEYS)
+        out["scaling"] = "rehearsal"
+        out["shard"] = {"of": a.shard_of, "rank": a.shard, "rows": m_loc, "nnz": nnz_loc, "halo_rows": halo,
+                        "send_rows": int(prob.stat("send_rows")), "bj_blocks": int(prob.stat("bj_parts_local")),
+                        "iteration_device_us": 1e6 * dev_s.value / a.steps,
+                        "sum_of_phase_device_us": kern, "launch_gap_us": 1e6 * dev_s.value / a.steps - kern,
+                        "note": "one rank of a %d-GPU run on one GPU (preAlps_hip_loopback): its rows, SpMM plan (interior / "
+                                "halo-reading halves, pack, side-stream exchange), block solve and reductions with the "
+                                "collectives replaced by no-ops; value = iterations/s of THIS shard alone, not a "
+                                "multi-GPU measurement" % a.shard_of}
     if rank == 0 and phases:
         phase_table("%s on %d x MI355X (device time, %d iterations)" % ({"odir": "ODIR", "omin": "OMIN", "fused": "F-ODIR"}[a.alg], world, a.phase_iters),
                     world, a.phase_iters, phases, ecg_fields)
@@ -417,7 +455,7 @@ def main():
             if alg != pl.ORTHODIR_FUSED:
                 check(L.preAlps_BlockOperator(e2.P, e2.AP), "BlockOperator")
             st2 = {"rci": rci2, "restarts": 0, "last_iters": 0, "last_res": float("nan")}
-            n2 = max(5, a.steps // 5)
+            n2 = max(20, a.steps // 5)
             run_iterations(prob2, e2, rhs2, L, 3, st2)
             prob2.sync()
             t1 = time.perf_counter()
@@ -428,13 +466,71 @@ def main():
             for _ in range(10):
                 check(L.preAlps_BlockJacobiApply(e2.AP, e2.Z), "BlockJacobiApply")
             check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
+            apply_s = sec.value / 10
+            fbytes = prob2.stat("bj_factor_bytes")
+            # fetched bytes per apply from the committed two-pass PMC run of this configuration
+            fetched, fsrc = None, None
+            for rnd in (ROUND, "r02"):
+                path = os.path.join(ROOT, "profiles", "%s_nd_apply_pmc.json" % rnd)
+                if a.workload == "elasticity" and a.n == 70 and a.t == 4 and os.path.exists(path):
+                    with open(path) as f:
+                        fetched = json.load(f).get("fetched_bytes_per_apply")
+                    fsrc = "profiles/%s_nd_apply_pmc.json" % rnd
+                    break
             out["survey_nparts"] = {"nparts": int(np2), "subdomain_box": [edge, edge, edge],
                                     "iterations_per_s": n2 / dt2, "ms_per_step": 1e3 * dt2 / n2, "steps": n2,
-                                    "block_solve_us": 1e5 * sec.value, "factor_bytes": prob2.stat("bj_factor_bytes"),
+                                    "block_solve_us": 1e6 * apply_s, "factor_bytes": fbytes,
                                     "sparse_factor_blocks": int(prob2.stat("bj_nd_blocks")),
                                     "bj_max_bandwidth": int(prob2.stat("bj_max_bandwidth")), "setup_seconds": setup2,
+                                    "roofline": {"kernel": "k_nd_forward + k_nd_backward (one launch per tree level)",
+                                                 "bound": "hbm", "achieved": fbytes / apply_s / 1e9, "peak": HBM_PEAK_GBS,
+                                                 "unit": "GB/s", "frac": fbytes / apply_s / 1e9 / HBM_PEAK_GBS,
+                                                 "algorithmic_bytes_per_apply": fbytes, "traffic": fetched,
+                                                 "traffic_source": fsrc, "avg_apply_us": 1e6 * apply_s,
+                                                 "note": "algorithmic bytes = both stored copies of the panels, each streamed "
+                                                         "once per apply"},
                                     "note": "SURVEY 8(d) subdomain count; blocks of this size get the nested-dissection "
                                             "factor (nd.c), not the band kernels"}
+            if not a.no_cpu and a.survey_cpu_iters > 0:
+                # CPU ports in the reference's own regime (one large sparse-factored block per rank,
+                # src/preconditioners/block_jacobi.c:26-63,93-109) + the parity line, same matrix / partition / rhs
+                from oracle import oracle as O
+                from oracle import mkl_path as M
+                import scipy.sparse as sp
+                k2 = a.survey_cpu_iters
+                gpu2 = prob2.solve(rhs2, a.t, ortho_alg=alg, max_iter=k2)
+                A2 = sp.csr_matrix((val, colind.astype(np.int32), rowptr), shape=(N, N))
+                B2, perm2, rowpos2 = O.permute_by_part(O.symrac_scale(A2), prob2.part_vector(), np2)
+                rhs2_cpu = O.reference_rhs(rowpos2)
+                sv = out["survey_nparts"]
+                cands2 = []
+                tf0 = time.perf_counter()
+                ecg2 = O.ECG(B2, rowpos2, a.t, {"odir": O.ORTHODIR, "omin": O.ORTHOMIN, "fused": O.ORTHODIR_FUSED}[a.alg],
+                             O.NO_BS_RED, 1e-5, k2)
+                tfac2 = time.perf_counter() - tf0
+                r2 = ecg2.solve(rhs2_cpu)
+                kk = min(len(gpu2.res), len(r2["res"]))
+                rel2 = np.abs(gpu2.res[:kk] - r2["res"][:kk]) / np.abs(r2["res"][:kk])
+                sv["parity"] = {"max_rel_diff_res": float(rel2.max()) if kk else None, "iterations_compared": int(kk),
+                                "gpu_res": [float(x) for x in gpu2.res[:kk]], "cpu_res": [float(x) for x in r2["res"][:kk]]}
+                cands2.append((r2["iters"] / r2["t_total"], O.lib().orc_num_threads(),
+                               "C/OpenMP port (envelope Cholesky per block): %d iterations, operator %.3fs precond %.3fs of "
+                               "%.3fs, factorisation %.1fs outside the rate" % (r2["iters"], r2["t_op"], r2["t_prec"], r2["t_total"], tfac2)))
+                del ecg2
+                if a.alg == "odir" and M.load_mkl() is not None:
+                    try:
+                        e_cpu2 = M.MklEcg(B2, rowpos2, a.t, 1e-5, k2, threads=min(host_cpu_share(), 128))
+                        rm2 = e_cpu2.solve(rhs2_cpu)
+                        cands2.append((rm2["iters"] / rm2["t_total"], int(rm2["threads"]),
+                                       "MKL kernels, the reference's configuration (mkl_dcsrmm %.3fs, PARDISO solves %.3fs, BLAS "
+                                       "dense %.3fs of %.3fs for %d iterations, PARDISO factorisation %.1fs outside the rate)"
+                                       % (rm2["t_op"], rm2["t_prec"], rm2["t_dense"], rm2["t_total"], rm2["iters"], e_cpu2.t_factor)))
+                    except Exception as ex:
+                        cands2.append((0.0, 0, "MKL path failed: %s" % ex))
+                best2 = max(cands2, key=lambda c: c[0])
+                sv["cpu_baseline"] = {"value": best2[0], "unit": "iterations/s", "cores": best2[1], "kind": "port",
+                                      "sample": "same workload at %d subdomains, %d ECG iterations per port; " % (np2, k2) +
+                                                "; ".join("[%s] = %.2f it/s" % (c[2], c[0]) for c in cands2)}
             prob2.close()
     if rank == 0:
         print(json.dumps(out))

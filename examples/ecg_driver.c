@@ -6,6 +6,12 @@
  *   gcc -std=gnu11 -Iinclude examples/ecg_driver.c -Lprealps_amd -lprealps_hip \
  *       -Wl,-rpath,$PWD/prealps_amd -lm -o ecg_driver
  *   PREALPS_NPARTS=8 ./ecg_driver -m tests/golden/LFAT5.mtx -e 2 -o 0 -r 0
+ *
+ * One MPI rank per GPU, like the reference (add -DPREALPS_USE_SYSTEM_MPI -I$MPI/include and link
+ * libmpi): the library takes rank and size from the communicator, binds device and RCCL itself and
+ * distributes the matrix from rank 0 -- the driver needs nothing but MPI_Init / MPI_Finalize:
+ *   PREALPS_NPARTS=4096 mpiexec -n 8 ./ecg_driver -m A.mtx -e 4
+ * -x prefix writes each rank's part of the solution to prefix.<rank> (raw doubles).
  */
 #include <getopt.h>
 #include <math.h>
@@ -19,15 +25,21 @@
 
 int main(int argc, char** argv) {
   double tol = 1e-5;
-  int maxIter = 1000, enlFac = 1, ortho_alg = 0, bs_red = 0, c;
+  int maxIter = 1000, enlFac = 1, ortho_alg = 0, bs_red = 0, c, rank = 0;
   const char* file = NULL;
-  while ((c = getopt(argc, argv, "e:i:m:o:r:t:")) != -1) switch (c) {
+  const char* dump = NULL;
+#ifdef PREALPS_USE_SYSTEM_MPI
+  MPI_Init(&argc, &argv);
+  MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+#endif
+  while ((c = getopt(argc, argv, "e:i:m:o:r:t:x:")) != -1) switch (c) {
       case 'e': enlFac = atoi(optarg); break;
       case 'i': maxIter = atoi(optarg); break;
       case 'm': file = optarg; break;
       case 'o': ortho_alg = atoi(optarg); break;
       case 'r': bs_red = atoi(optarg); break;
       case 't': tol = atof(optarg); break;
+      case 'x': dump = optarg; break;
       default: fprintf(stderr, "usage: %s -m A.mtx -e t [-o 0|1] [-r 0|1] [-i maxit] [-t tol]\n", argv[0]); return 2;
     }
   if (!file) { fprintf(stderr, "-m matrix.mtx is required\n"); return 2; }
@@ -68,10 +80,19 @@ int main(int argc, char** argv) {
     }
   }
   preAlps_ECGFinalize(&ecg, sol);
-  preAlps_ECGPrint(&ecg, 0);
+  if (rank == 0) preAlps_ECGPrint(&ecg, 0);
+  if (dump) {
+    char name[1024];
+    snprintf(name, sizeof(name), "%s.%d", dump, rank);
+    FILE* f = fopen(name, "wb");
+    if (f) { fwrite(sol, sizeof(double), (size_t)m, f); fclose(f); }
+  }
   free(rhs); free(sol);
   preAlps_BlockJacobiFree();
   preAlps_OperatorFree();
   preAlps_hip_shutdown();
+#ifdef PREALPS_USE_SYSTEM_MPI
+  MPI_Finalize();
+#endif
   return 0;
 }

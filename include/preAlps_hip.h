@@ -57,6 +57,10 @@ int preAlps_hip_set_comm(preAlps_allreduce_fn allreduce,
 int preAlps_hip_rccl_available(void);   /* 0: librccl.so loads; ranks vote on this before the collective init */
 int preAlps_hip_rccl_unique_id(char* id128);
 int preAlps_hip_rccl_init(const char* id128, int rank, int size);
+/* One shard of a `size`-process run rehearsed in a single process: rank / size as given, the
+ * all-reduce hook is the identity and halo rows arrive as zeros (the process then iterates on its own
+ * diagonal block of the partitioned matrix with the launches of a real rank).  For measurements. */
+int preAlps_hip_loopback(int rank, int size);
 /* Collective: checks the installed hooks with one all-reduce and one ring exchange. */
 int preAlps_hip_comm_selftest(void);
 
@@ -109,6 +113,9 @@ int preAlps_hip_reference_rhs(double* rhs_local);
  * examples/test_ecg_bench_fused.c:243-259). res_hist may be NULL. */
 int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol,
                      double* res_hist, int* bs_hist, int max_hist, int* n_hist);
+/* 1 / 0: the two driver loops above and below replay each half of an iteration from a HIP graph
+ * captured on its first passes (default: on for one process, PREALPS_ECG_GRAPH overrides). */
+void preAlps_hip_graphs(int on);
 /* The same loop advanced by nsteps full iterations from the current RCI state,
  * restarting from rhs when the stopping test fires (counts go to the optional
  * out-parameters).  Used for timing a fixed number of iterations. */

@@ -1,0 +1,480 @@
+// bj_g4.hip -- the band block solve for panels of up to 4 columns on the f64 matrix cores, from ONE
+// copy of the factor (block_jacobi.c:93-109 of the reference: PARDISO phase 33 on every diagonal
+// block; here Z = blockdiag(A)^-1 X with the band Cholesky factors of block_jacobi.c / k_bj_factor).
+//
+// The register recurrence (k_bj_apply_pairs, kernels.hip) streams two copies of the band -- columns of
+// L for the forward sweep, rows for the backward one -- and spends ~20 wave instructions per pivot.
+// Here both sweeps read the same records, blocked by groups of FOUR pivots:
+//
+//   * With Lt = L D^-1 (unit lower, D = diag L) the solve is z = Lt^-T D^-2 Lt^-1 x.  The record of
+//     group g = pivots 4g .. 4g+3 holds the strictly lower 4 x 4 corner Lt(g, g) and the w rows
+//     below it, Lt(4g+4 .. 4g+3+w, g): the plain band entries, (w + 4) rows x 4 pivots.
+//     Forward:  y_g = Lt(g, g)^-1 x_g by substitution (three steps), then x(below) -= Lt(below, g) y_g;
+//     backward: r = y_g - Lt(below, g)^T z(below), then z_g = Lt(g, g)^-T r by substitution:
+//     the exact transpose, from the same record -- 8 N (w + 4) bytes for BOTH sweeps instead of
+//     16 N (w + 1).  Same arithmetic as the classic sweeps, other summation order.
+//     (A first version stored the group in selective-inversion form, [Lt(g,g)^-1 - I ; -Lt(below,g)
+//     Lt(g,g)^-1], which needs no substitution at all; on the elasticity matrix, whose scaled factors
+//     have |Lt| up to 1e5, it lost 7 digits -- 2.5e-8 against 1.3e-15 -- and was dropped.)
+//   * v_mfma_f64_4x4x4 computes four independent 4 x 4 x 4 products; on gfx950 the operands sit as
+//         A[i][k] of block q: lane 16 k + 4 q + i     B[k][j]: lane 16 k + 4 q + j
+//         D[i][j] of block q: lane 16 i + 4 q + j     (tools/probe/mfma_f64_4x4x4.hip)
+//     so a register pair that holds 16 rows x 4 columns of the panel as D (row 4 q + i of the tile in
+//     block q, column j) IS the B operand of the backward product (contraction over the tile's rows)
+//     and the accumulator of the forward one.  The whole block (up to 16 tiles = 256 rows) lives in
+//     registers between the sweeps: the forward result is never written out.
+//   * The four rows of a group sit in the four 16-lane rows of their tile register (one quad of each);
+//     the substitution moves them with ds_bpermute: once to copy the quad into every quad (the B operand
+//     of the forward product), three times to hand a solved row to the rows that depend on it.
+//   * Records are streamed HBM -> LDS by LDS-DMA in chunks of two groups, double buffered per wave,
+//     forward in ascending and backward in descending order; a lane fetches its A-operand entry with
+//     one ds_read_b64 (rows outside the record are clamped onto its all-zero row).
+//
+// HBM bytes per apply: 8 N (w + 4) + 16 N t.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include "pa_device.h"
+
+// a launch that a replayed graph segment makes in its place is skipped (runtime.hip: pa_rt_skip)
+#define PA_LAUNCH(...) do { if (!pa_rt_skipping()) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+inline hipStream_t cur_stream() { return (hipStream_t)pa_rt_stream(); }
+
+// ---------------------------------------------------------------------------------- set-up ----
+// Records from the plain forward records of kernels.hip (rec[j * wr + d - 1] = L(j+d, j) / L(j, j)):
+// group g of block p at Lg4[off2[p] + g * 4 (w + 4)], four doubles [position][pivot]:
+//   positions 0 .. w-1     rows rho = w+3 .. 4 of the group (row 4g + rho of the block), NEGATED: the
+//                          product adds them;
+//   position  w            zeros (where every row outside the record is sent);
+//   positions w+1 .. w+3   rows 1 .. 3 of the strictly lower corner Lt(g, g) (zero on and above the
+//                          diagonal), as they are.
+// Chunks of two groups; the groups a block does not have are zero.
+__global__ __launch_bounds__(256) void k_bj_g4_setup(const int* __restrict__ list, const int* __restrict__ nrows,
+                                                      const int* __restrict__ bw, const long long* __restrict__ off,
+                                                      const long long* __restrict__ off2,
+                                                      const double* __restrict__ L, double* __restrict__ Lg4) {
+  const int p = list[blockIdx.x];
+  const int b = nrows[p], w = bw[p], wr = (w + 2) & ~1, nr = w + 4;
+  const double* __restrict__ rec = L + off[p];
+  double* __restrict__ dst = Lg4 + off2[p];
+  const int ngrp = 2 * ((b + 7) / 8);
+  for (int e = threadIdx.x; e < ngrp * nr * 4; e += blockDim.x) {
+    const int g = e / (4 * nr), r = e - g * 4 * nr, pos = r >> 2, pv = r & 3;
+    const int piv = 4 * g + pv;
+    double v = 0.0;
+    if (pos != w) {
+      const int rho = pos < w ? w + 3 - pos : pos - w;     // row of the group
+      const int row = 4 * g + rho, d = row - piv;
+      if (row < b && piv < b && d >= 1 && d <= w) {
+        v = rec[(size_t)piv * wr + d - 1];
+        if (pos < w) v = -v;
+      }
+    }
+    dst[e] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------- apply ----
+__device__ __forceinline__ void g4_issue_chunk(const double* __restrict__ rec, int chunk_doubles, int chunk,
+                                               double* lbuf, int lane) {
+  const int nbytes = chunk_doubles * 8;
+  const char* g = reinterpret_cast<const char*>(rec) + (size_t)chunk * nbytes + lane * 16;
+  char* l = reinterpret_cast<char*>(lbuf);
+  for (int o = 0; o < nbytes; o += 1024)
+    __builtin_amdgcn_global_load_lds((glb_ptr)(g + o), (lds_ptr)(l + o), 16, 0, 0);
+}
+
+// wait until at most `n` of the wave's VMEM operations are outstanding (they complete in order: the
+// youngest n are the LDS-DMA instructions of the chunk that was requested last)
+__device__ __forceinline__ void g4_wait_vm(int n) {
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// a value of a 16-lane row rotated by 4 * n lanes inside the row (DPP row_ror)
+template <int N>
+__device__ __forceinline__ double row_ror(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 | N, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 | N, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// s_waitcnt lgkmcnt(0) that the compiler sees as the producer of everything read before it
+#define G4_WAIT_1(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a))
+#define G4_WAIT_2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b))
+template <int DQ>
+__device__ __forceinline__ void g4_wait_cf(double (&cf)[DQ], double& c0, double& c1, double& c2, int& plo, int& phi) {
+  if constexpr (DQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]));
+  else if constexpr (DQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]));
+  else if constexpr (DQ == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]));
+  else if constexpr (DQ == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]));
+  else if constexpr (DQ == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]), "+v"(cf[7]));
+}
+
+// the value lane `from` (a byte address: 4 * lane) holds, for every lane; issued by hand like the
+// ds_reads (behind an LDS-DMA the compiler would drain all VMEM in front of a DS instruction it emits)
+#ifndef G4_BPERM_ASM
+#define G4_BPERM_ASM 1
+#endif
+__device__ __forceinline__ void g4_bperm_issue(int from, double v, int& plo, int& phi) {
+#if G4_BPERM_ASM
+  // (s_nop: the value permuted was usually written by the instruction just before -- a double-precision
+  // VALU operation or a matrix instruction -- and the hazard recogniser does not look into inline assembly)
+  asm volatile("s_nop 4\n\tds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4"
+               : "=&v"(plo), "=&v"(phi) : "v"(from), "v"(__double2loint(v)), "v"(__double2hiint(v)));
+#else
+  plo = __builtin_amdgcn_ds_bpermute(from, __double2loint(v));
+  phi = __builtin_amdgcn_ds_bpermute(from, __double2hiint(v));
+#endif
+}
+__device__ __forceinline__ double g4_bperm(int from, double v) {
+  int plo, phi;
+  g4_bperm_issue(from, v, plo, phi);
+#if G4_BPERM_ASM
+  G4_WAIT_2(plo, phi);
+#endif
+  return __hiloint2double(phi, plo);
+}
+
+// Per-lane constants of a sweep (lane = 16 hi + 4 blk + lo):
+//   cX     w + 3 - (row of this lane inside a tile as the A operand of this sweep sees it)
+//   aX     byte offset of this lane's pivot column inside a record row
+//   cg     byte offset of this lane's entries of the 4 x 4 corner: forward row hi (its columns 0..2 at
+//          +0, +8, +16), backward column hi (of rows 3, 2, 1 at +96, +64, +32) -- relative to position w
+//   bsrc   4 * lane(hi, block 0, lo);  b16 = 4 * (lane & 15)
+struct g4_lane { int cX; unsigned aX; unsigned cg; int bsrc, b16, blk; };
+
+// One group of four pivots, forward: Q = tile of the pivots, GQ = their block inside it, `cur` = LDS
+// byte address of the group's record.
+template <int NT, int DQ, int Q, int GQ>
+__device__ __forceinline__ void g4_fwd_group(double (&T)[NT], unsigned cur, int w, g4_lane ln) {
+  // (opaque copy: without it the compiler keeps the clamped index of every (tile offset, group) pair
+  // of the unrolled sweeps alive in registers and spills)
+  asm volatile("" : "+v"(ln.cX));
+  int plo, phi;
+  // T[Q] was last written by the previous group's matrix instruction, and the DS instruction below is
+  // inline assembly: the compiler's hazard recogniser does not see that it READS that register pair
+  // (a DGEMM 4x4x4 result needs 9 wait states before a memory instruction may read it;
+  // GCNHazardRecognizer: DMFMA4x4WriteVgprMemExpReadWaitStates).  Without the wait the last tile of a
+  // block -- one matrix instruction per group, nothing behind it -- handed stale rows on.
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+  g4_bperm_issue(ln.bsrc | (GQ << 4), T[Q], plo, phi);          // the group's quad into every quad
+  double c0, c1, c2;
+  {
+    const unsigned ad = cur + (unsigned)w * 32u + ln.cg;           // row hi of the corner: columns 0, 1, 2
+    asm volatile("ds_read_b64 %0, %1" : "=v"(c0) : "v"(ad));
+    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(c1) : "v"(ad));
+    asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(c2) : "v"(ad));
+  }
+  double cf[DQ];
+#pragma unroll
+  for (int dq = 0; dq < DQ; ++dq) {
+    cf[dq] = 0.0;
+    if (Q + dq < NT) {
+      const unsigned s = min((unsigned)(ln.cX - (16 * dq - 4 * GQ)), (unsigned)w);
+      const unsigned ad = cur + s * 32u + ln.aX;
+      asm volatile("ds_read_b64 %0, %1" : "=v"(cf[dq]) : "v"(ad));
+    }
+  }
+  g4_wait_cf<DQ>(cf, c0, c1, c2, plo, phi);
+  double y = __hiloint2double(phi, plo);
+  // y_g = Lt(g, g)^-1 x_g: row k, once final, goes to the rows below it (c_k = 0 on the others)
+  y = fma(-c0, g4_bperm(ln.b16, y), y);
+  y = fma(-c1, g4_bperm(ln.b16 | (1 << 6), y), y);
+  y = fma(-c2, g4_bperm(ln.b16 | (2 << 6), y), y);
+  T[Q] = (ln.blk == GQ) ? y : T[Q];
+#pragma unroll
+  for (int dq = 0; dq < DQ; ++dq)
+    if (Q + dq < NT) T[Q + dq] = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], y, T[Q + dq], 0, 0, 0);
+}
+
+// The same group, backward: r = y_g - Lt(below, g)^T z(below), then z_g = Lt(g, g)^-T r.
+template <int NT, int DQ, int Q, int GQ>
+__device__ __forceinline__ void g4_bwd_group(double (&T)[NT], unsigned cur, int w, g4_lane ln) {
+  asm volatile("" : "+v"(ln.cX));
+  int plo, phi;
+  g4_bperm_issue(ln.bsrc | (GQ << 4), T[Q], plo, phi);
+  double c3, c2, c1;
+  {
+    const unsigned ad = cur + (unsigned)w * 32u + ln.cg;           // column hi of the corner: rows 3, 2, 1
+    asm volatile("ds_read_b64 %0, %1 offset:96" : "=v"(c3) : "v"(ad));
+    asm volatile("ds_read_b64 %0, %1 offset:64" : "=v"(c2) : "v"(ad));
+    asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(c1) : "v"(ad));
+  }
+  double cf[DQ];
+#pragma unroll
+  for (int dq = 0; dq < DQ; ++dq) {
+    cf[dq] = 0.0;
+    if (Q + dq < NT) {
+      const unsigned s = min((unsigned)(ln.cX - (16 * dq - 4 * GQ)), (unsigned)w);
+      const unsigned ad = cur + s * 32u + ln.aX;
+      asm volatile("ds_read_b64 %0, %1" : "=v"(cf[dq]) : "v"(ad));
+    }
+  }
+  g4_wait_cf<DQ>(cf, c3, c2, c1, plo, phi);
+  double acc = 0.0;
+#pragma unroll
+  for (int dq = 0; dq < DQ; ++dq)
+    if (Q + dq < NT) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], T[Q + dq], acc, 0, 0, 0);
+  // every block of the accumulator holds the sum over ITS four rows of each tile: add the four
+  // blocks (rotations by 4 and 8 lanes inside the 16-lane rows)
+  acc += row_ror<4>(acc);
+  acc += row_ror<8>(acc);
+  double r = __hiloint2double(phi, plo) + acc;
+  r = fma(-c3, g4_bperm(ln.b16 | (3 << 6), r), r);
+  r = fma(-c2, g4_bperm(ln.b16 | (2 << 6), r), r);
+  r = fma(-c1, g4_bperm(ln.b16 | (1 << 6), r), r);
+  T[Q] = (ln.blk == GQ) ? r : T[Q];
+}
+
+// Chunk c (two groups) is in LDS buffer c & 1.  Entering it, the other buffer is free (its chunk was
+// consumed before): the next chunk of the sweep is requested FIRST, then the wave waits for everything
+// but that request -- two chunks are in flight while it waits, which halves the time a lone block
+// spends on memory latency (the blocks of the last, partly filled round run at that speed).
+template <int NT, int DQ, int Q, int H>
+__device__ __forceinline__ void g4_fwd_chunk(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+                                             int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
+                                             int early) {
+  constexpr int C = 2 * Q + H;
+  if (8 * (C + 1) < b) {
+    if (!(early & 1)) g4_wait_vm(0);
+    g4_issue_chunk(rec, chunk_doubles, C + 1, lds0 + ((C + 1) & 1) * lstride, lane);
+    if (early & 1) g4_wait_vm((chunk_doubles + 127) >> 7);
+  } else {
+    g4_wait_vm(0);
+  }
+  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & 1) * lstride);
+  g4_fwd_group<NT, DQ, Q, 2 * H>(T, cur, w, ln);
+  g4_fwd_group<NT, DQ, Q, 2 * H + 1>(T, cur + (unsigned)(w + 4) * 32u, w, ln);
+  asm volatile("" ::: "memory");
+}
+template <int NT, int DQ, int Q>
+__device__ __forceinline__ void g4_fwd_tiles(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+                                             int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
+                                             int early) {
+  if constexpr (Q < NT) {
+    if (16 * Q < b) {
+      g4_fwd_chunk<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
+      if (16 * Q + 8 < b) g4_fwd_chunk<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
+      g4_fwd_tiles<NT, DQ, Q + 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
+    }
+  }
+}
+
+template <int NT, int DQ, int Q, int H>
+__device__ __forceinline__ void g4_bwd_chunk(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+                                             int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
+                                             int early) {
+  constexpr int C = 2 * Q + H;
+  if (C > 0 && 8 * (C + 1) < b) {      // (the last two chunks are still where the forward sweep left them)
+    if (!(early & 1)) g4_wait_vm(0);
+    g4_issue_chunk(rec, chunk_doubles, C - 1, lds0 + ((C - 1) & 1) * lstride, lane);
+    if (early & 1) g4_wait_vm((chunk_doubles + 127) >> 7);
+  } else {
+    g4_wait_vm(0);
+  }
+  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & 1) * lstride);
+  g4_bwd_group<NT, DQ, Q, 2 * H + 1>(T, cur + (unsigned)(w + 4) * 32u, w, ln);
+  g4_bwd_group<NT, DQ, Q, 2 * H>(T, cur, w, ln);
+  asm volatile("" ::: "memory");
+}
+template <int NT, int DQ, int Q>
+__device__ __forceinline__ void g4_bwd_tiles(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+                                             int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
+                                             int early) {
+  if constexpr (Q >= 0) {
+    if (16 * Q < b) {
+      if (16 * Q + 8 < b) g4_bwd_chunk<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
+      g4_bwd_chunk<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
+    }
+    g4_bwd_tiles<NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
+  }
+}
+
+// One wavefront per block.  NT tiles of 16 rows (b <= 16 NT), DQ = tiles a group's record reaches
+// (w + 15 < 16 DQ).  `xs` = row stride of the panels in doubles (2, 4; 8 / 16 when the kernel is
+// launched on a 4-column slice of a wider panel), `ncol` <= 4 columns starting at `in` / `out`.
+template <int NT, int DQ, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_bj_g4(
+    const int* __restrict__ list, int count, const int* __restrict__ row0, const int* __restrict__ nrows,
+    const int* __restrict__ bw, const long long* __restrict__ off2, const int* __restrict__ map_f,
+    const double* __restrict__ Lg4, const double* __restrict__ invd_f, int lds_per_wave, int xs, int ncol, int early,
+    const double* __restrict__ in, double* __restrict__ out) {
+  extern __shared__ double smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int pi = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (pi >= count) return;
+  const int p = __builtin_amdgcn_readfirstlane(list[pi]);
+  const int r0 = __builtin_amdgcn_readfirstlane(row0[p]);
+  const int b = __builtin_amdgcn_readfirstlane(nrows[p]);
+  const int w = __builtin_amdgcn_readfirstlane(bw[p]);
+  const long long o64 = off2[p];
+  const size_t o = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(o64 >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)o64);
+  const double* __restrict__ rec = Lg4 + o;
+  double* lds0 = smem + (size_t)wave * lds_per_wave;
+  const int lstride = lds_per_wave >> 1;
+  const int chunk_doubles = 8 * (w + 4);
+  const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
+  // tile layout (D / B operand): row 4 blk + hi of the tile, column lo
+  const int trow = 4 * blk + hi;
+  // A operand, forward: row 4 blk + lo of the tile against pivot hi; backward: row 4 blk + hi against pivot lo
+  g4_lane lf;
+  lf.cX = w + 3 - (4 * blk + lo);
+  lf.aX = (unsigned)hi * 8u;
+  lf.cg = (unsigned)hi * 32u;
+  lf.bsrc = (lane & ~12) << 2;                    // byte address of lane (hi, block 0, lo) for ds_bpermute
+  lf.b16 = (lane & 15) << 2;
+  lf.blk = blk;
+
+  g4_issue_chunk(rec, chunk_doubles, 0, lds0, lane);
+  double T[NT];
+  const int* __restrict__ mp = map_f + r0;
+  {
+    unsigned rowoff[NT];        // (the host checks that m * xs fits 31 bits)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int j = 16 * q + trow;
+      rowoff[q] = ((unsigned)r0 + (unsigned)mp[j < b ? j : 0]) * (unsigned)xs + lo;
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) T[q] = (16 * q + trow < b && lo < ncol) ? in[rowoff[q]] : 0.0;
+  }
+
+  g4_fwd_tiles<NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, early);
+
+  // y = D^-2 a
+  {
+    const double* __restrict__ dv = invd_f + r0;
+    double d[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) { const int j = 16 * q + trow; d[q] = dv[j < b ? j : 0]; }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) T[q] *= d[q] * d[q];
+  }
+  // (the last chunk of the forward sweep is the first of the backward one: it is still in its buffer,
+  // and so is the one before it -- g4_bwd_chunk does not fetch that one again)
+  if (!(early & 2))      // (PREALPS_BJ_G4_EARLY & 2: debugging aid -- stop after the forward sweep and the scaling)
+  {
+    int l2 = lane;
+    asm volatile("" : "+v"(l2));                   // (recomputed here rather than kept across the forward sweep)
+    const int hi2 = l2 >> 4, blk2 = (l2 >> 2) & 3, lo2 = l2 & 3;
+    g4_lane lb;
+    lb.cX = w + 3 - (4 * blk2 + hi2);
+    lb.aX = (unsigned)lo2 * 8u;
+    lb.cg = (unsigned)hi2 * 8u;
+    lb.bsrc = (l2 & ~12) << 2;
+    lb.b16 = (l2 & 15) << 2;
+    lb.blk = blk2;
+    g4_bwd_tiles<NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, early);
+  }
+
+  {
+    int l3 = lane;
+    asm volatile("" : "+v"(l3));                   // (addresses recomputed, not carried through both sweeps)
+    const int trow3 = 4 * ((l3 >> 2) & 3) + (l3 >> 4), lo3 = l3 & 3;
+    unsigned rowoff[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int j = 16 * q + trow3;
+      rowoff[q] = ((unsigned)r0 + (unsigned)mp[j < b ? j : 0]) * (unsigned)xs + lo3;
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+      if (16 * q + trow3 < b && lo3 < ncol) out[rowoff[q]] = T[q];
+  }
+}
+
+char g_err[256];
+int kfail(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  fprintf(stderr, "[prealps_hip] kernel launch failed: %s\n", g_err);
+  return 1;
+}
+
+template <int NT, int DQ, int OCC>
+int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int xs, int ncol, const double* in, double* out) {
+  const int cbuf = (8 * (wmax + 4) + 127) & ~127;        // doubles, a multiple of 1 KiB
+  const int per_wave = 2 * cbuf;
+  int waves = (160 * 1024) / (per_wave * 8);
+  if (waves > 4) waves = 4;
+  if (waves < 1) return 1;
+  const size_t lds = (size_t)waves * per_wave * 8;
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NT, DQ, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return kfail("hipFuncSetAttribute(k_bj_g4)");
+    configured = lds;
+  }
+  const int blocks = (count + waves - 1) / waves;
+  static int early = -1;
+  if (early < 0) { const char* e = getenv("PREALPS_BJ_G4_EARLY"); early = e ? atoi(e) : 1; }
+  PA_LAUNCH((k_bj_g4<NT, DQ, OCC>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
+                     pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, xs, ncol, early, in, out);
+  return kfail("k_bj_g4");
+}
+
+template <int NT, int DQ>
+int launch(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int xs, int ncol, const double* in, double* out) {
+  return launch_occ<NT, DQ, (NT <= 12 && DQ <= 5) ? 5 : 4>(list, count, pl, wmax, xs, ncol, in, out);
+}
+
+template <int NT>
+int launch_dq(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int xs, int ncol, const double* in, double* out) {
+  const int dq = ((wmax + 15) >> 4) + 1;
+  switch (dq) {
+    case 1: case 2: case 3: return launch<NT, 3>(list, count, pl, wmax, xs, ncol, in, out);
+    case 4: return launch<NT, 4>(list, count, pl, wmax, xs, ncol, in, out);
+    case 5: return launch<NT, 5>(list, count, pl, wmax, xs, ncol, in, out);
+    case 6: return launch<NT, 6>(list, count, pl, wmax, xs, ncol, in, out);
+    case 7: return launch<NT, 7>(list, count, pl, wmax, xs, ncol, in, out);
+    case 8: return launch<NT, 8>(list, count, pl, wmax, xs, ncol, in, out);
+    default: return 1;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pa_bj_g4_max_rows(void) { return 256; }
+int pa_bj_g4_max_band(void) { return 112; }
+
+int pa_k_bj_g4_setup(const int* list, int count, const int* nrows, const int* bw, const long long* off,
+                      const long long* off2, const double* L, double* Lg4) {
+  if (count <= 0) return 0;
+  PA_LAUNCH(k_bj_g4_setup, dim3(count), dim3(256), 0, cur_stream(), list, nrows, bw, off, off2, L, Lg4);
+  return kfail("k_bj_g4_setup");
+}
+
+/* One class of blocks (all with at most bmax rows and bands up to wmax) on a panel of row stride xs:
+ * the four columns starting at `in` / `out`. */
+int pa_k_bj_g4(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int bmax, int xs, int ncol,
+                const double* in, double* out) {
+  if (count <= 0) return 0;
+  if (bmax <= 192) return launch_dq<12>(list, count, pl, wmax, xs, ncol, in, out);
+  if (bmax <= 224) return launch_dq<14>(list, count, pl, wmax, xs, ncol, in, out);
+  return launch_dq<16>(list, count, pl, wmax, xs, ncol, in, out);
+}
+
+}  // extern "C"

@@ -36,6 +36,8 @@ typedef struct {
   double* d_Lf; double* d_Lb; double* d_invd_f; double* d_invd_b;
   double* d_Lf2; double* d_Lb2; long long* d_off2;     /* paired records of the narrow classes (optional) */
   double pairs_bytes;
+  double* d_Lg4; double g4_bytes;                      /* one-copy records of bj_g4.hip (optional) */
+  int class_g4[16]; int class_bmax[16];
   /* classes by register sets */
   int nclass; int class_R[16]; int class_count[16]; int class_wmax[16]; int* class_list[16];
   const int* class_list_c[16];
@@ -67,13 +69,14 @@ int pa_bj_max_bandwidth(void) { return g_bj.created ? g_bj.max_bw : 0; }
 int pa_bj_nparts(void) { return g_bj.created ? g_bj.np : 0; }
 int pa_bj_nd_blocks(void) { return g_bj.created ? g_bj.nd_blocks : 0; }
 double pa_bj_pairs_bytes(void) { return g_bj.created ? g_bj.pairs_bytes : 0.0; }
+double pa_bj_g4_bytes(void) { return g_bj.created ? g_bj.g4_bytes : 0.0; }
 
 void preAlps_BlockJacobiFree(void) {
   pa_bj_t* s = &g_bj;
   pa_rt_free(s->d_row0); pa_rt_free(s->d_nrows); pa_rt_free(s->d_bw); pa_rt_free(s->d_off);
   pa_rt_free(s->d_map_f); pa_rt_free(s->d_map_b);
   pa_rt_free(s->d_Lf); pa_rt_free(s->d_Lb); pa_rt_free(s->d_invd_f); pa_rt_free(s->d_invd_b);
-  pa_rt_free(s->d_Lf2); pa_rt_free(s->d_Lb2); pa_rt_free(s->d_off2);
+  pa_rt_free(s->d_Lf2); pa_rt_free(s->d_Lb2); pa_rt_free(s->d_off2); pa_rt_free(s->d_Lg4);
   for (int c = 0; c < 16; ++c) pa_rt_free(s->class_list[c]);
   pa_nd_free();
   memset(s, 0, sizeof(*s));
@@ -420,9 +423,10 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
         R = W <= 1024 ? -1 : (W <= 2048 ? -2 : -4);
       }
       for (c = 0; c < s->nclass; ++c) if (s->class_R[c] == R) break;
-      if (c == s->nclass) { s->class_R[c] = R; s->class_count[c] = 0; s->class_wmax[c] = 0; s->nclass++; }
+      if (c == s->nclass) { s->class_R[c] = R; s->class_count[c] = 0; s->class_wmax[c] = 0; s->class_bmax[c] = 0; s->nclass++; }
       cls[q] = c; s->class_count[c]++;
       if (bw[q] > s->class_wmax[c]) s->class_wmax[c] = bw[q];
+      if (nrows[q] > s->class_bmax[c]) s->class_bmax[c] = nrows[q];
     }
     for (int c = 0; c < s->nclass && !rc; ++c) {
       int* list = (int*)malloc(s->class_count[c] * sizeof(int));
@@ -544,36 +548,61 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
     else if (r2) rc = 1;
     free(ndl); free(grow0);
   }
-  /* The sweep records of the classes R = 2, 3 (bands up to 128) a second time in pairs of steps
-   * (k_bj_pairs), read by k_bj_apply_pairs at up to 4 columns: two 16-byte LDS reads per four steps
-   * instead of four clamped 8-byte reads (elasticity 70^3, band 35: 177 -> 166 us per apply; Poisson
-   * 100^3, band 25: 172 -> 150 us).  The plain records stay for the 8- and 16-column kernels.
-   * PREALPS_BJ_PAIRS=0 turns it off. */
-  if (!rc && !(getenv("PREALPS_BJ_PAIRS") && atoi(getenv("PREALPS_BJ_PAIRS")) == 0)) {
+  /* Second layouts of the narrow classes for panels of up to 4 columns, made on the device from the
+   * plain forward records:
+   *  - bj_g4.hip (default, PREALPS_BJ_G4=0 turns it off): ONE copy for both sweeps in selective-
+   *    inversion form by groups of four pivots, for classes whose blocks have at most
+   *    pa_bj_g4_max_rows() rows and bands up to pa_bj_g4_max_band();
+   *  - k_bj_pairs (classes R = 2, 3 that bj_g4 does not take; PREALPS_BJ_PAIRS=0 turns it off): both
+   *    sweeps' records in pairs of steps for k_bj_apply_pairs.
+   * Same size per block either way: 8 ceil(b / 8) (w + 4) doubles per copy.  The plain records stay for
+   * the 8- and 16-column kernels. */
+  if (!rc) {
+    const int want_g4 = !(getenv("PREALPS_BJ_G4") && atoi(getenv("PREALPS_BJ_G4")) == 0) && (long long)m * 16 < 2147483647LL;
+    const int want_pairs = !(getenv("PREALPS_BJ_PAIRS") && atoi(getenv("PREALPS_BJ_PAIRS")) == 0);
+    int any_g4 = 0, any_pairs = 0, cls_pairs[16];
+    for (int c = 0; c < s->nclass; ++c) {
+      s->class_g4[c] = want_g4 && s->class_R[c] > 0 && s->class_wmax[c] <= pa_bj_g4_max_band() &&
+                        s->class_bmax[c] <= pa_bj_g4_max_rows();
+      cls_pairs[c] = want_pairs && !s->class_g4[c] && (s->class_R[c] == 2 || s->class_R[c] == 3);
+      any_g4 |= s->class_g4[c]; any_pairs |= cls_pairs[c];
+    }
     long long* off2 = (long long*)calloc((size_t)np + 1, sizeof(long long));
     long long tot2 = 0;
-    int any = 0;
-    for (int c = 0; c < s->nclass; ++c) any |= s->class_R[c] == 2 || s->class_R[c] == 3;
-    if (off2 && any) {
+    if (off2 && (any_g4 || any_pairs)) {
       for (int q = 0; q < np; ++q) {
-        const int R = (bw[q] + 127) / 64;
-        if (is_nd[q] || bw[q] > wide_from || (R != 2 && R != 3)) continue;
-        off2[q] = tot2;
+        if (is_nd[q] || bw[q] > wide_from) continue;
+        off2[q] = tot2;                                   /* (blocks of the other classes: unused) */
         tot2 += 8LL * ((nrows[q] + 7) / 8) * (bw[q] + 4);
       }
-      s->d_Lf2 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
-      s->d_Lb2 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
       s->d_off2 = (long long*)pa_rt_malloc(((size_t)np + 1) * sizeof(long long));
-      if (!s->d_Lf2 || !s->d_Lb2 || !s->d_off2 || pa_rt_h2d(s->d_off2, off2, ((size_t)np + 1) * sizeof(long long)) ||
-          pa_rt_memset(s->d_Lf2 + tot2, 0, 512 * sizeof(double)) || pa_rt_memset(s->d_Lb2 + tot2, 0, 512 * sizeof(double)))
-        rc = PA_FAIL("allocating the paired sweep records failed: %s", pa_rt_error());
-      for (int c = 0; c < s->nclass && !rc; ++c)
-        if (s->class_R[c] == 2 || s->class_R[c] == 3)
-          if (pa_k_bj_pairs(s->class_list[c], s->class_count[c], s->d_nrows, s->d_bw, s->d_off, s->d_off2, s->d_Lf, s->d_Lf2) ||
-              pa_k_bj_pairs(s->class_list[c], s->class_count[c], s->d_nrows, s->d_bw, s->d_off, s->d_off2, s->d_Lb, s->d_Lb2))
-            rc = PA_FAIL("k_bj_pairs failed");
+      if (!s->d_off2 || pa_rt_h2d(s->d_off2, off2, ((size_t)np + 1) * sizeof(long long)))
+        rc = PA_FAIL("allocating the second sweep records failed: %s", pa_rt_error());
+      if (!rc && any_g4) {
+        s->d_Lg4 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
+        if (!s->d_Lg4 || pa_rt_memset(s->d_Lg4, 0, ((size_t)tot2 + 512) * sizeof(double)))
+          rc = PA_FAIL("allocating the one-copy sweep records failed: %s", pa_rt_error());
+        for (int c = 0; c < s->nclass && !rc; ++c)
+          if (s->class_g4[c] &&
+              pa_k_bj_g4_setup(s->class_list[c], s->class_count[c], s->d_nrows, s->d_bw, s->d_off, s->d_off2, s->d_Lf, s->d_Lg4))
+            rc = PA_FAIL("k_bj_g4_setup failed");
+        if (!rc) s->g4_bytes = 8.0 * (double)tot2;
+      }
+      if (!rc && any_pairs) {
+        s->d_Lf2 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
+        s->d_Lb2 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
+        if (!s->d_Lf2 || !s->d_Lb2 ||
+            pa_rt_memset(s->d_Lf2 + tot2, 0, 512 * sizeof(double)) || pa_rt_memset(s->d_Lb2 + tot2, 0, 512 * sizeof(double)))
+          rc = PA_FAIL("allocating the paired sweep records failed: %s", pa_rt_error());
+        for (int c = 0; c < s->nclass && !rc; ++c)
+          if (cls_pairs[c])
+            if (pa_k_bj_pairs(s->class_list[c], s->class_count[c], s->d_nrows, s->d_bw, s->d_off, s->d_off2, s->d_Lf, s->d_Lf2) ||
+                pa_k_bj_pairs(s->class_list[c], s->class_count[c], s->d_nrows, s->d_bw, s->d_off, s->d_off2, s->d_Lb, s->d_Lb2))
+              rc = PA_FAIL("k_bj_pairs failed");
+        if (!rc) s->pairs_bytes = 2.0 * 8.0 * (double)tot2;
+      }
+      if (!rc && pa_rt_sync()) rc = PA_FAIL("%s", pa_rt_error());
     }
-    if (!rc && any) s->pairs_bytes = 2.0 * 8.0 * (double)tot2;
     free(off2);
   }
   for (int q = 0; q < np; ++q) { free(bands[q]); free(coo_off[q]); free(coo_val[q]); }   /* (NULL where already released) */
@@ -587,6 +616,7 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
   pl->map_f = s->d_map_f; pl->map_b = s->d_map_b; pl->Lf = s->d_Lf; pl->Lb = s->d_Lb;
   pl->invd_f = s->d_invd_f; pl->invd_b = s->d_invd_b;
   pl->Lf2 = s->d_Lf2; pl->Lb2 = s->d_Lb2; pl->off2 = s->d_off2;
+  pl->Lg4 = s->d_Lg4; pl->class_g4 = s->class_g4; pl->class_bmax = s->class_bmax;
   pl->nclass = s->nclass; pl->class_R = s->class_R; pl->class_count = s->class_count;
   pl->class_wmax = s->class_wmax;
   pl->class_list = s->class_list_c;

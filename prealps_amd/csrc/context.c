@@ -38,13 +38,15 @@ static void* g_ev1 = NULL;
  * 16 CPUs' worth of quota on a 256-thread host, 256 threads only take turns (measured on the MI355X
  * box: the OpenMP loops of the CPU baseline run 4x slower with 128 threads than with 16). */
 static int host_cpu_share(void);
+static int g_solo = 0;
+void pa_host_solo(int on) { g_solo = on ? 1 : 0; }
 int pa_host_threads(void) {
   int t = 1;
 #ifdef _OPENMP
   t = omp_get_max_threads();          /* OMP_NUM_THREADS, if the caller set it */
 #endif
   /* the ranks of a multi-GPU run share the node's CPUs (one node: preAlps_hip_set_world) */
-  int cap = host_cpu_share() / (g_size > 1 ? g_size : 1);
+  int cap = host_cpu_share() / (g_size > 1 && !g_solo ? g_size : 1);
   if (cap < 1) cap = 1;
   return t < cap ? t : cap;
 }
@@ -84,6 +86,7 @@ double pa_wtime(void) {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+void pa_time_abort(void);
 int pa_fail_at(const char* func, const char* fmt, ...) {
   char msg[900];
   va_list va;
@@ -91,6 +94,7 @@ int pa_fail_at(const char* func, const char* fmt, ...) {
   vsnprintf(msg, sizeof(msg), fmt, va);
   va_end(va);
   snprintf(g_last_error, sizeof(g_last_error), "%s: %s", func, msg);
+  pa_time_abort();      /* an entry point that fails inside a timed region leaves no region open */
   if (g_abort_mode) {
     /* same shape as the reference's abort banner */
     fprintf(stderr, "\nABORTING from %s : [Proc: %d] %s\n\n", func, g_rank, msg);
@@ -118,6 +122,7 @@ void preAlps_hip_shutdown(void) {
   pa_rt_event_destroy(g_ev1);
   g_ev0 = g_ev1 = NULL;
   pa_rccl_shutdown();
+  pa_mpi_release();
   pa_rt_shutdown();
 }
 
@@ -185,6 +190,26 @@ int preAlps_hip_rccl_init(const char* id128, int rank, int size) {
   g_allreduce = pa_rccl_allreduce; g_exchange = pa_rccl_exchange; g_comm_ctx = NULL;
   return 0;
 }
+/* Rehearsal of ONE shard of a `size`-process run in a single process (bench.py --shard-of): this
+ * process plans and owns the rows of `rank`, sums over the processes are its own sums, halo rows
+ * arrive as zeros -- i.e. it solves with the diagonal block A(rank, rank) of the partitioned matrix,
+ * an SPD problem of its own, through exactly the kernels, launches and stream choreography (pack,
+ * side-stream exchange, interior / halo-reading SpMM halves, reductions) the rank would run. */
+static int loop_allreduce(void* ctx, double* dev_buf, int count) { (void)ctx; (void)dev_buf; (void)count; return 0; }
+static int loop_exchange(void* ctx, const double* dev_send, const int* send_counts, double* dev_recv,
+                         const int* recv_counts, const int* peers, int npeers) {
+  (void)ctx; (void)dev_send; (void)send_counts; (void)peers;
+  size_t n = 0;
+  for (int i = 0; i < npeers; ++i) n += (size_t)recv_counts[i];
+  return pa_rt_memset(dev_recv, 0, n * sizeof(double));
+}
+int preAlps_hip_loopback(int rank, int size) {
+  if (preAlps_hip_set_world(rank, size)) return 1;
+  g_allreduce = loop_allreduce; g_exchange = loop_exchange; g_comm_ctx = NULL;
+  return 0;
+}
+int pa_comm_is_loopback(void) { return g_allreduce == loop_allreduce; }
+
 /* Round-trip check of whatever hooks are installed: sum of (rank+1) over the ranks, and a
  * ring exchange (send our rank to rank+1, receive from rank-1).  0 = both came back right. */
 int preAlps_hip_comm_selftest(void) {
@@ -241,9 +266,10 @@ int pa_exchange(const double* dev_send, const int* send_counts, double* dev_recv
 }
 
 /* ---- timing --------------------------------------------------------------- */
+static int g_time_depth = 0;
+void pa_time_abort(void) { g_time_depth = 0; }
 static const char* k_time_keys[PA_T_COUNT] = {"operator", "precond", "gram", "trsm",
                                               "update", "small", "comm"};
-static int g_time_depth = 0;
 
 void preAlps_hip_timing(int enable) {
   g_timing = enable ? 1 : 0;
@@ -252,6 +278,7 @@ void preAlps_hip_timing(int enable) {
     g_ev1 = pa_rt_event_create();
   }
 }
+int pa_timing_enabled(void) { return g_timing; }
 void preAlps_hip_timing_reset(void) { memset(g_times, 0, sizeof(g_times)); }
 
 void pa_time_begin(int key) {

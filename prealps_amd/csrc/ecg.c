@@ -31,6 +31,12 @@
 
 #define PA_ECG_MAGIC 0x45434731u
 
+/* 1: the driver loops of this library (preAlps_ECGSolve / preAlps_ECGAdvance) replay the launches of
+ * an iteration from HIP graphs captured on the first passes (see graph_begin below); -1 = decide from
+ * PREALPS_ECG_GRAPH and the process group at the next reset. */
+static int g_graphs = -1;
+void preAlps_hip_graphs(int on) { g_graphs = on; }
+
 /* The reference brackets every BLAS / MPI call with MPI_Wtime (ecg.c:316-320 ...).  Launches
  * are asynchronous here, so the host clock only sees the enqueue; with preAlps_hip_timing(1)
  * the phase's hipEvent pair is read instead (one stream sync per phase) and the timer fields
@@ -61,6 +67,13 @@ typedef struct {
   int fuse;           /* NO_BS_RED: two-pass first half (PREALPS_ECG_FUSE=0 keeps the four-pass one) */
   int lazy_stop;      /* several processes: the residual norm rides on the beta all-reduce (see below) */
   double* lazy_ptr;   /* where the first half left [res2, potrf status] for that */
+  /* graphs (driver loops of this library): an iteration is two segments -- 0: the first half up to
+   * the residual norm, 1: preconditioner apply + second half + product -- and the panel pointers
+   * rotate with period 6 (three P slots x two AP slots), so there are 2 x 6 graphs */
+  int use_graphs;
+  int phase;          /* iterations since the last reset, mod 6 */
+  void* graph[2][6];
+  unsigned char seen[2][6];
 } ecg_priv_t;
 
 static ecg_priv_t* priv_of(preAlps_ECG_t* ecg) {
@@ -172,6 +185,18 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
     pv->lazy_stop = pa_world_size() > 1 && pv->fuse && ecg->bs_red == NO_BS_RED &&
                     ecg->ortho_alg != ORTHODIR_FUSED && ecg->enlFac >= 2 && (f ? atoi(f) : 1);
     pv->lazy_ptr = NULL; }
+  /* graphs: one process (or the one-shard rehearsal of preAlps_hip_loopback, whose sums are free, so
+   * the stopping test need not ride on one); PREALPS_ECG_GRAPH=0 turns them off, =2 forces them for
+   * any process group (the hooks must then be capturable: RCCL is, host-staged ones are not) */
+  {
+    const char* ge = getenv("PREALPS_ECG_GRAPH");
+    int want = g_graphs >= 0 ? g_graphs : (ge ? atoi(ge) : 1);
+    int group_ok = pa_world_size() == 1 || pa_comm_is_loopback() || want == 2;
+    pv->use_graphs = want && group_ok && pv->rotate && pv->fuse && ecg->ortho_alg != ORTHODIR_FUSED &&
+                     !pa_timing_enabled();
+    if (pv->use_graphs) pv->lazy_stop = 0;
+    pv->phase = 0;
+  }
   pa_set_desc(ecg->X, M, t, m, t, ts);
   pa_set_desc(ecg->R, M, t, m, t, ts);
   pa_set_desc(ecg->Z, M, t, m, t, ts);
@@ -249,7 +274,8 @@ int _preAlps_ECGSplit(double* x, CPLM_Mat_Dense_t* XSplit, int colIndex) {
  * `end` waits for the event only -- not for the stream -- so work queued after
  * `begin` (the preconditioner apply of the same iteration) keeps the GPU busy
  * while the host reads the norm. */
-static int stopping_begin(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
+static int stopping_end(preAlps_ECG_t* ecg, ecg_priv_t* pv, int* stop);
+static int stopping_queue(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   int T = ecg->enlFac;
   int single = pa_world_size() == 1;
   if (pv->rtr_valid < 2) {
@@ -270,8 +296,53 @@ static int stopping_begin(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
     PA_CHECK(pa_rt_d2h_async(pv->h_pin, src, 2 * sizeof(double)));
   }
   pv->rtr_valid = 0;
+  return 0;
+}
+static int stopping_begin(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
+  if (stopping_queue(ecg, pv)) return 1;
   PA_CHECK(pa_rt_event_record(pv->ev_res));
   return 0;
+}
+
+/* ---- graph segments ------------------------------------------------------------------------
+ * seg_begin .. seg_end bracket the host code of one segment.  First pass of a (segment, phase): the
+ * code runs as it is.  Second pass: the stream is captured while it runs (nothing executes), the
+ * graph is instantiated and launched.  From then on the host code still runs -- it rotates
+ * pointers and counts -- with every launch suppressed (pa_rt_skip), and the graph is launched in
+ * its place: one launch instead of three to six per segment. */
+static int seg_begin(ecg_priv_t* pv, int seg) {
+  if (!pv->use_graphs || pa_timing_enabled()) return 0;    /* (phase timers put events between the launches) */
+  if (pv->graph[seg][pv->phase]) { pa_rt_skip(1); return 2; }
+  if (pv->seen[seg][pv->phase]++ == 0) return 0;
+  if (pa_rt_capture_begin()) { pv->use_graphs = 0; return 0; }   /* (nothing queued yet: go on without graphs) */
+  return 1;
+}
+static int seg_end(ecg_priv_t* pv, int seg, int mode, int body_rc) {
+  if (mode == 2) pa_rt_skip(0);
+  if (mode == 1) {
+    void* exec = NULL;
+    int rc = pa_rt_capture_end(&exec);
+    if (rc || body_rc) { pa_rt_graph_free(exec); return PA_FAIL("capturing an iteration segment failed: %s", pa_rt_error()); }
+    pv->graph[seg][pv->phase] = exec;
+  }
+  if (body_rc) return 1;
+  if (mode && pa_rt_graph_launch(pv->graph[seg][pv->phase])) return PA_FAIL("%s", pa_rt_error());
+  return 0;
+}
+/* One full iteration from the state "AP = A P is there" (rci 0) to the same state: the order of
+ * examples/test_ecg_prealps_op.c:208-221 with the apply, the second half and the product queued
+ * before the host looks at the residual norm (they do not touch X or R and are unused after a stop). */
+static int graph_iteration(preAlps_ECG_t* ecg, ecg_priv_t* pv, int* rci_request, int* stop) {
+  int mode = seg_begin(pv, 0);
+  int rc = preAlps_ECGIterate(ecg, rci_request) || stopping_queue(ecg, pv);
+  if (seg_end(pv, 0, mode, rc)) return 1;
+  PA_CHECK(pa_rt_event_record(pv->ev_res));
+  mode = seg_begin(pv, 1);
+  rc = (ecg->ortho_alg == ORTHOMIN ? preAlps_BlockJacobiApply(ecg->R, ecg->Z) : preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) ||
+       preAlps_ECGIterate(ecg, rci_request) || preAlps_BlockOperator(ecg->P, ecg->AP);
+  if (seg_end(pv, 1, mode, rc)) return 1;
+  pv->phase = (pv->phase + 1) % 6;
+  return stopping_end(ecg, pv, stop);
 }
 
 static int stopping_end(preAlps_ECG_t* ecg, ecg_priv_t* pv, int* stop) {
@@ -656,6 +727,7 @@ void _preAlps_ECGFree(preAlps_ECG_t* ecg) {
     pa_rt_host_free(pv->h_pin);
     pa_rt_host_free(pv->h_pin_i);
     pa_rt_event_destroy(pv->ev_res);
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) pa_rt_graph_free(pv->graph[a][b]);
     pv->magic = 0;
   }
   free(ecg->X); free(ecg->R); free(ecg->V); free(ecg->AV); free(ecg->alpha); free(ecg->beta);
@@ -708,7 +780,15 @@ int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_h
   int rci = 0, stop = 0, nh = 0;
   if (preAlps_ECGInitialize(ecg, rhs, &rci)) return 1;
   if (preAlps_BlockJacobiApply(ecg->R, ecg->P)) return 1;
-  if (ecg->ortho_alg != ORTHODIR_FUSED) {
+  ecg_priv_t* pvg = priv_of(ecg);
+  if (pvg && pvg->use_graphs) {
+    if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+    while (stop != 1) {
+      if (graph_iteration(ecg, pvg, &rci, &stop)) return 1;
+      if (res_hist && nh < max_hist) { res_hist[nh] = ecg->res; if (bs_hist) bs_hist[nh] = ecg->bs; }
+      ++nh;
+    }
+  } else if (ecg->ortho_alg != ORTHODIR_FUSED) {
     if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
     while (stop != 1) {
       if (preAlps_ECGIterate(ecg, &rci)) return 1;
@@ -774,6 +854,24 @@ int preAlps_ECGAdvance(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int ns
       }
     }
     return 0;
+  }
+  {
+    ecg_priv_t* pvg = priv_of(ecg);
+    if (pvg && pvg->use_graphs && *rci_request == 0) {
+      while (done < nsteps) {
+        if (graph_iteration(ecg, pvg, rci_request, &stop)) return 1;
+        ++done;
+        if (stop == 1) {
+          if (restarts) ++*restarts;
+          if (last_iters) *last_iters = ecg->iter;
+          if (last_res) *last_res = ecg->res;
+          if (_preAlps_ECGReset(ecg, rhs, rci_request)) return 1;
+          if (preAlps_BlockJacobiApply(ecg->R, ecg->P)) return 1;
+          if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+        }
+      }
+      return 0;
+    }
   }
   while (done < nsteps) {
     if (preAlps_ECGIterate(ecg, rci_request)) return 1;

@@ -12,6 +12,9 @@
 #include <cstdlib>
 #include "pa_device.h"
 
+// a launch that a replayed graph segment makes in its place is skipped (runtime.hip: pa_rt_skip)
+#define PA_LAUNCH(...) do { if (!pa_rt_skipping()) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 namespace {
 
 constexpr int WG = 256;           // 4 wavefronts of 64
@@ -2429,7 +2432,7 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
       configured = lds;
     }
     const int cpx = (nlist + 7) / 8;
-    hipLaunchKernelGGL((k_spmm_runs<TC, TS>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+    PA_LAUNCH((k_spmm_runs<TC, TS>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
                        pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
                        pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
     return kfail("k_spmm_runs");
@@ -2444,7 +2447,7 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
       configured = lds;
     }
     const int cpx = (nlist + 7) / 8;
-    hipLaunchKernelGGL((k_spmm_staged<TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+    PA_LAUNCH((k_spmm_staged<TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
                        pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
                        pl->blk_ext_off, pl->ext_rows, order, nlist, X, Xh, Y);
     return kfail("k_spmm_staged");
@@ -2457,11 +2460,11 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
   static int nt = -1;
   if (nt < 0) { const char* e = getenv("PREALPS_SPMM_NT"); nt = e ? atoi(e) : 0; }
   if (nt)
-    hipLaunchKernelGGL((k_spmm<TS, true>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+    PA_LAUNCH((k_spmm<TS, true>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
                        pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
                        pl->blk_win, order, nlist, win_cap, X, Xh, Y);
   else
-    hipLaunchKernelGGL((k_spmm<TS, false>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+    PA_LAUNCH((k_spmm<TS, false>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
                        pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
                        pl->blk_win, order, nlist, win_cap, X, Xh, Y);
   return kfail("k_spmm");
@@ -2496,7 +2499,7 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
         return kfail("hipFuncSetAttribute(k_bj_apply)");                                          \
       configured = lds;                                                                           \
     }                                                                                             \
-    hipLaunchKernelGGL((k_bj_apply<TS, RR, CH, XS, 1>), dim3(blocks), dim3(64 * waves), lds,          \
+    PA_LAUNCH((k_bj_apply<TS, RR, CH, XS, 1>), dim3(blocks), dim3(64 * waves), lds,          \
                        cur_stream(), list, count, pl->row0, pl->nrows, pl->bw, pl->off,           \
                        pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f, pl->invd_b, per_wave, nbuf, in, out); \
   } break;
@@ -2521,11 +2524,11 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
           conf2[R - 2] = lds2;
         }
         if (R == 2)
-          hipLaunchKernelGGL((k_bj_apply_pairs<TS, 2, CH, XS>), dim3(blocks2), dim3(64 * wv2), lds2, cur_stream(), list, count,
+          PA_LAUNCH((k_bj_apply_pairs<TS, 2, CH, XS>), dim3(blocks2), dim3(64 * wv2), lds2, cur_stream(), list, count,
                              pl->row0, pl->nrows, pl->bw, pl->off2, pl->map_f, pl->map_b, pl->Lf2, pl->Lb2, pl->invd_f,
                              pl->invd_b, pw2, nbuf2, in, out);
         else
-          hipLaunchKernelGGL((k_bj_apply_pairs<TS, 3, CH, XS>), dim3(blocks2), dim3(64 * wv2), lds2, cur_stream(), list, count,
+          PA_LAUNCH((k_bj_apply_pairs<TS, 3, CH, XS>), dim3(blocks2), dim3(64 * wv2), lds2, cur_stream(), list, count,
                              pl->row0, pl->nrows, pl->bw, pl->off2, pl->map_f, pl->map_b, pl->Lf2, pl->Lb2, pl->invd_f,
                              pl->invd_b, pw2, nbuf2, in, out);
         return kfail("k_bj_apply_pairs");
@@ -2538,11 +2541,11 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
     if (occ < 0) { const char* e = getenv("PREALPS_BJ_OCC"); occ = e ? atoi(e) : 0; }
     if (R == 2 && occ >= 5 && lds <= 64 * 1024) {
       if (occ == 5)
-        hipLaunchKernelGGL((k_bj_apply<TS, 2, CH, XS, 5>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
+        PA_LAUNCH((k_bj_apply<TS, 2, CH, XS, 5>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
                            pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
                            pl->invd_b, per_wave, nbuf, in, out);
       else
-        hipLaunchKernelGGL((k_bj_apply<TS, 2, CH, XS, 6>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
+        PA_LAUNCH((k_bj_apply<TS, 2, CH, XS, 6>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
                            pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
                            pl->invd_b, per_wave, nbuf, in, out);
       return kfail("k_bj_apply");
@@ -2577,7 +2580,7 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
     const size_t lds = (size_t)waves * per_wave * 8;
     const int blocks = (count + waves - 1) / waves;
 #define BJM_LAUNCH(NTT)                                                                              \
-    hipLaunchKernelGGL((k_bj_mfma<TS, NTT>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, \
+    PA_LAUNCH((k_bj_mfma<TS, NTT>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, \
                        pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb,   \
                        pl->invd_f, pl->invd_b, per_wave, in, out)
     if (wmax <= 48) BJM_LAUNCH(4); else if (wmax <= 80) BJM_LAUNCH(6); else BJM_LAUNCH(8);
@@ -2620,11 +2623,11 @@ static int bj_launch_wide(const pa_bj_plan_t* pl, int wmax, const int* list, int
   }
   if constexpr (TS * R <= 16) {
     if (nw <= 12)
-      hipLaunchKernelGGL((k_bj_wide<TS, R, 768>), dim3(count), dim3(64 * nw), 0, cur_stream(), list, count,
+      PA_LAUNCH((k_bj_wide<TS, R, 768>), dim3(count), dim3(64 * nw), 0, cur_stream(), list, count,
                          pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb,
                          pl->invd_f, pl->invd_b, in, out);
     else
-      hipLaunchKernelGGL((k_bj_wide<TS, R, 1024>), dim3(count), dim3(64 * nw), 0, cur_stream(), list, count,
+      PA_LAUNCH((k_bj_wide<TS, R, 1024>), dim3(count), dim3(64 * nw), 0, cur_stream(), list, count,
                          pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb,
                          pl->invd_f, pl->invd_b, in, out);
   }
@@ -2654,7 +2657,7 @@ static int bj_factor_big_launch(const int* list, int count, int wmax, const int*
       return kfail("hipFuncSetAttribute(k_bj_factor_big)");
     configured = lds;
   }
-  hipLaunchKernelGGL((k_bj_factor_big<NB>), dim3(count), dim3(1024), lds, cur_stream(), list, row0, nrows, bw,
+  PA_LAUNCH((k_bj_factor_big<NB>), dim3(count), dim3(1024), lds, cur_stream(), list, row0, nrows, bw,
                      boff, band, fail);
   return kfail("k_bj_factor_big");
 }
@@ -2668,8 +2671,8 @@ static int nd_launch_fwd(const nd_args& a, const int* cfront, const int* crow0, 
   constexpr int TS = XS <= 8 ? XS : 8;        // 16-column panels in two column groups (LDS, registers)
   constexpr int QB = TS >= 8 ? 2 : 4;
   const dim3 grid(nwg, XS / TS);
-  if (nwg < few) hipLaunchKernelGGL((k_nd_forward<TS, XS, QB>), grid, dim3(ND_CHUNK * QB), 0, cur_stream(), a, cfront, crow0, in);
-  else hipLaunchKernelGGL((k_nd_forward<TS, XS, 1>), grid, dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, in);
+  if (nwg < few) PA_LAUNCH((k_nd_forward<TS, XS, QB>), grid, dim3(ND_CHUNK * QB), 0, cur_stream(), a, cfront, crow0, in);
+  else PA_LAUNCH((k_nd_forward<TS, XS, 1>), grid, dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, in);
   return kfail("k_nd_forward");
 }
 
@@ -2681,8 +2684,8 @@ static int nd_launch_bwd(const nd_args& a, const int* cfront, const int* ccol0, 
   constexpr int TS = XS <= 8 ? XS : 8;
   constexpr int WB = TS >= 8 ? 8 : 16;
   const dim3 grid(nwg, XS / TS);
-  if (nwg < few) hipLaunchKernelGGL((k_nd_backward<TS, XS, WB>), grid, dim3(64 * WB), 0, cur_stream(), a, cfront, ccol0, out);
-  else hipLaunchKernelGGL((k_nd_backward<TS, XS, 4>), grid, dim3(256), 0, cur_stream(), a, cfront, ccol0, out);
+  if (nwg < few) PA_LAUNCH((k_nd_backward<TS, XS, WB>), grid, dim3(64 * WB), 0, cur_stream(), a, cfront, ccol0, out);
+  else PA_LAUNCH((k_nd_backward<TS, XS, 4>), grid, dim3(256), 0, cur_stream(), a, cfront, ccol0, out);
   return kfail("k_nd_backward");
 }
 
@@ -2705,15 +2708,15 @@ int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* X
 int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendbuf) {
   if (n <= 0) return 0;
   const int blocks = (int)(((long long)n * ts + WG - 1) / WG);
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_pack_rows<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), n,
+  TS_DISPATCH(ts, PA_LAUNCH((k_pack_rows<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), n,
                                      idx, X, sendbuf));
   return kfail("k_pack_rows");
 }
 
 int pa_k_probe(int which, size_t bytes, const double* src, double* dst) {
   const size_t n2 = bytes / 16;
-  if (which == 0) hipLaunchKernelGGL(k_probe_copy, dim3(8192), dim3(WG), 0, cur_stream(), n2, (const double2*)src, (double2*)dst);
-  else hipLaunchKernelGGL(k_probe_read, dim3(8192), dim3(WG), 0, cur_stream(), n2, (const double2*)src, dst);
+  if (which == 0) PA_LAUNCH(k_probe_copy, dim3(8192), dim3(WG), 0, cur_stream(), n2, (const double2*)src, (double2*)dst);
+  else PA_LAUNCH(k_probe_read, dim3(8192), dim3(WG), 0, cur_stream(), n2, (const double2*)src, dst);
   return kfail("k_probe");
 }
 
@@ -2723,20 +2726,20 @@ int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
   if (ts == 16) {   // matrix cores (k_gram_mfma16)
-    if (A1) hipLaunchKernelGGL((k_gram_mfma16<2>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
-    else hipLaunchKernelGGL((k_gram_mfma16<1>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
+    if (A1) PA_LAUNCH((k_gram_mfma16<2>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
+    else PA_LAUNCH((k_gram_mfma16<1>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
     return kfail("k_gram_mfma16");
   }
   if (ts == 8) {
-    if (A1) hipLaunchKernelGGL((k_gram_mfma8<2>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
-    else hipLaunchKernelGGL((k_gram_mfma8<1>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
+    if (A1) PA_LAUNCH((k_gram_mfma8<2>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
+    else PA_LAUNCH((k_gram_mfma8<1>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
     return kfail("k_gram_mfma8");
   }
   if (A1) {
-    TS_DISPATCH(ts, hipLaunchKernelGGL((k_gram<TS_, 2>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+    TS_DISPATCH(ts, PA_LAUNCH((k_gram<TS_, 2>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                        A0, A1, B, partials));
   } else {
-    TS_DISPATCH(ts, hipLaunchKernelGGL((k_gram<TS_, 1>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+    TS_DISPATCH(ts, PA_LAUNCH((k_gram<TS_, 1>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                        A0, A1, B, partials));
   }
   return kfail("k_gram");
@@ -2757,7 +2760,7 @@ int pa_k_gram_finish(int m, int ts, const double* A0, const double* A1, const do
       if (pa_k_finish(partials, nblk, 2, ts, t, T, t, out, t + T)) return 1;
       return pa_k_potrf_alpha(out, t, T, mu, alpha, info);
     }
-    hipLaunchKernelGGL(k_finish_potrf_alpha, dim3(1), dim3(1024), 0, cur_stream(), partials, nblk, 2, ts,
+    PA_LAUNCH(k_finish_potrf_alpha, dim3(1), dim3(1024), 0, cur_stream(), partials, nblk, 2, ts,
                        t, T, out, mu, alpha, info);
     return kfail("k_finish_potrf_alpha");
   }
@@ -2769,26 +2772,26 @@ int pa_k_finish(const double* partials, int nblk, int npan, int ts, int a_lo, in
   const int ne = (a_lo + a_hi) * nb;
   if (ne <= 0) return 0;
   const int groups = ne > 128 ? (ne + 63) / 64 : 1;    // one workgroup unless the block is large
-  hipLaunchKernelGGL(k_finish, dim3(groups), dim3(1024), 0, cur_stream(), partials, nblk, npan, ts, a_lo,
+  PA_LAUNCH(k_finish, dim3(groups), dim3(1024), 0, cur_stream(), partials, nblk, npan, ts, a_lo,
                      a_hi, nb, out, ld_out);
   return kfail("k_finish");
 }
 
 int pa_k_potrf(double* W, int t, int* info) {
-  hipLaunchKernelGGL(k_potrf, dim3(1), dim3(64), 0, cur_stream(), W, t, info);
+  PA_LAUNCH(k_potrf, dim3(1), dim3(64), 0, cur_stream(), W, t, info);
   return kfail("k_potrf");
 }
 
 int pa_k_fused_small(double* mu, int t, int nrhs, int bm, int bn, int ldb, double* alpha,
                      double* beta, int* info) {
-  hipLaunchKernelGGL(k_fused_small, dim3(1), dim3(64), 0, cur_stream(), mu, t, nrhs, bm, bn, ldb,
+  PA_LAUNCH(k_fused_small, dim3(1), dim3(64), 0, cur_stream(), mu, t, nrhs, bm, bn, ldb,
                      alpha, beta, info);
   return kfail("k_fused_small");
 }
 
 int pa_k_trsm(int m, int ts, int t, const double* U, double* P, double* AP) {
   if (t <= 0) return 0;
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_trsm<TS_>), dim3(grid_rows(m)), dim3(WG), 0, cur_stream(),
+  TS_DISPATCH(ts, PA_LAUNCH((k_trsm<TS_>), dim3(grid_rows(m)), dim3(WG), 0, cur_stream(),
                                      m, t, U, P, AP));
   return kfail("k_trsm");
 }
@@ -2799,17 +2802,17 @@ int pa_k_update_xr(int m, int ts, int t, int nc, const double* alpha, const doub
   int blocks = grid_rows(m, 2);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_update_xr<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+  TS_DISPATCH(ts, PA_LAUNCH((k_update_xr<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                      t, nc, alpha, P, AP, X, R, rtr_partials));
   if (kfail("k_update_xr")) return 1;
   if (trace_nc <= 0) return 0;
-  hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, blocks, ts, trace_nc,
+  PA_LAUNCH(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, blocks, ts, trace_nc,
                      res2, info, host);
   return kfail("k_trace_finish");
 }
 
 int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha, int* info) {
-  hipLaunchKernelGGL(k_potrf_alpha, dim3(1), dim3(64), 0, cur_stream(), buf, t, T, mu, alpha, info);
+  PA_LAUNCH(k_potrf_alpha, dim3(1), dim3(64), 0, cur_stream(), buf, t, T, mu, alpha, info);
   return kfail("k_potrf_alpha");
 }
 
@@ -2823,16 +2826,16 @@ int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double
   static int use_mfma = -1;
   if (use_mfma < 0) { const char* e = getenv("PREALPS_TRSM_MFMA"); use_mfma = e ? atoi(e) : 1; }
   if (ts == 16 && use_mfma)
-    hipLaunchKernelGGL((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials);
+    PA_LAUNCH((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials);
   else if (ts == 8 && use_mfma)
-    hipLaunchKernelGGL((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials);
+    PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials);
   else {
-    TS_DISPATCH(ts, hipLaunchKernelGGL((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+    TS_DISPATCH(ts, PA_LAUNCH((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                        t, nc, U, alpha, P, AP, X, R, rtr_partials));
   }
   if (kfail("k_trsm_update")) return 1;
   if (trace_nc <= 0) return 0;
-  hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, blocks, ts, trace_nc,
+  PA_LAUNCH(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, blocks, ts, trace_nc,
                      res2, info, host);
   return kfail("k_trace_finish");
 }
@@ -2841,14 +2844,14 @@ int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nbl
   int blocks = grid_rows(m, 4);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_colnorm2<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
+  TS_DISPATCH(ts, PA_LAUNCH((k_colnorm2<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                      R, rtr_partials));
   return kfail("k_colnorm2");
 }
 
 int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2,
                       const int* info) {
-  hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, nblk, ts, nc,
+  PA_LAUNCH(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, nblk, ts, nc,
                      res2, info, (double*)nullptr);
   return kfail("k_trace_finish");
 }
@@ -2857,43 +2860,43 @@ int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta,
                   const double* V0, const double* V1, double* Z) {
   if (nc <= 0) return 0;
   if (ts == 16) {   // matrix cores (k_update_z_mfma16), one 16-row tile per wavefront and step
-    hipLaunchKernelGGL(k_update_z_mfma16, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
+    PA_LAUNCH(k_update_z_mfma16, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
                        beta, ldb, V0, V1, Z);
     return kfail("k_update_z_mfma16");
   }
   if (ts == 8) {
-    hipLaunchKernelGGL(k_update_z_mfma8, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
+    PA_LAUNCH(k_update_z_mfma8, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
                        beta, ldb, V0, V1, Z);
     return kfail("k_update_z_mfma8");
   }
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+  TS_DISPATCH(ts, PA_LAUNCH((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
                                      cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z));
   return kfail("k_update_z");
 }
 
 int pa_k_copy_cols(int m, int ts, int nc, const double* src, double* dst) {
   if (nc <= 0) return 0;
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_copy_cols<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+  TS_DISPATCH(ts, PA_LAUNCH((k_copy_cols<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
                                      cur_stream(), m, nc, src, dst));
   return kfail("k_copy_cols");
 }
 
 int pa_k_right_mult(int m, int ts, int t, const double* Q, double* A) {
   if (t <= 0) return 0;
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_right_mult<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+  TS_DISPATCH(ts, PA_LAUNCH((k_right_mult<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
                                      cur_stream(), m, t, Q, A));
   return kfail("k_right_mult");
 }
 
 int pa_k_permute_cols(int m, int ts, int n, const int* piv, double* A) {
   if (n <= 0) return 0;
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_permute_cols<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+  TS_DISPATCH(ts, PA_LAUNCH((k_permute_cols<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
                                      cur_stream(), m, n, piv, A));
   return kfail("k_permute_cols");
 }
 
 int pa_k_rowsum(int m, int ts, int nc, const double* X, double* sol) {
-  TS_DISPATCH(ts, hipLaunchKernelGGL((k_rowsum<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
+  TS_DISPATCH(ts, PA_LAUNCH((k_rowsum<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
                                      cur_stream(), m, nc, X, sol));
   return kfail("k_rowsum");
 }
@@ -2912,7 +2915,7 @@ int pa_k_bj_factor(const int* list, int count, int wmax, const int* row0, const 
       return kfail("hipFuncSetAttribute(k_bj_factor)");
     configured = lds;
   }
-  hipLaunchKernelGGL(k_bj_factor, dim3(count), dim3(WG), lds, cur_stream(), list, row0, nrows, bw, off, boff,
+  PA_LAUNCH(k_bj_factor, dim3(count), dim3(WG), lds, cur_stream(), list, row0, nrows, bw, off, boff,
                      band, Lf, Lb, invd_f, invd_b, fail);
   return kfail("k_bj_factor");
 }
@@ -2921,7 +2924,7 @@ int pa_k_scatter(size_t n, const long long* off, const double* val, double* dst)
   if (n == 0) return 0;
   size_t blocks = (n + WG - 1) / WG;
   if (blocks > 65535) blocks = 65535;
-  hipLaunchKernelGGL(k_scatter, dim3((unsigned)blocks), dim3(WG), 0, cur_stream(), n, off, val, dst);
+  PA_LAUNCH(k_scatter, dim3((unsigned)blocks), dim3(WG), 0, cur_stream(), n, off, val, dst);
   return kfail("k_scatter");
 }
 
@@ -2934,7 +2937,7 @@ int pa_k_bj_factor_big(const int* list, int count, int wmax, int wide_from, cons
   else if (wmax <= 2048) rc = bj_factor_big_launch<8>(list, count, wmax, row0, nrows, bw, boff, band, fail);
   else rc = bj_factor_big_launch<4>(list, count, wmax, row0, nrows, bw, boff, band, fail);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_bj_layout_big, dim3(512, count), dim3(WG), 0, cur_stream(), list, row0, nrows, bw, off,
+  PA_LAUNCH(k_bj_layout_big, dim3(512, count), dim3(WG), 0, cur_stream(), list, row0, nrows, bw, off,
                      boff, band, wide_from, Lf, Lb, invd_f, invd_b);
   return kfail("k_bj_layout_big");
 }
@@ -2962,7 +2965,7 @@ int pa_k_nd_apply(const pa_nd_plan_t* pl, int ts, const double* in, double* out)
 int pa_k_bj_pairs(const int* list, int count, const int* nrows, const int* bw, const long long* off,
                   const long long* off2, const double* L, double* L2) {
   if (count <= 0) return 0;
-  hipLaunchKernelGGL(k_bj_pairs, dim3(count), dim3(WG), 0, cur_stream(), list, nrows, bw, off, off2, L, L2);
+  PA_LAUNCH(k_bj_pairs, dim3(count), dim3(WG), 0, cur_stream(), list, nrows, bw, off, off2, L, L2);
   return kfail("k_bj_pairs");
 }
 
@@ -2970,6 +2973,11 @@ int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out)
   for (int c = 0; c < pl->nclass; ++c) {
     if (pl->class_count[c] <= 0) continue;
     int rc = 1;
+    if (pl->Lg4 && pl->class_g4[c] && ts <= 4) {   /* one copy of the factor, matrix cores (bj_g4.hip) */
+      rc = pa_k_bj_g4(pl, pl->class_list[c], pl->class_count[c], pl->class_wmax[c], pl->class_bmax[c], ts, ts, in, out);
+      if (rc) return rc;
+      continue;
+    }
     if (pl->class_R[c] < 0) {   /* wide bands: one workgroup per subdomain, -class_R register sets */
       const int Rw = -pl->class_R[c];
       if (Rw == 1) rc = bj_wide_dispatch<1>(pl, ts, pl->class_wmax[c], pl->class_list[c], pl->class_count[c], in, out);

@@ -91,26 +91,79 @@ static int cmp_int(const void* a, const void* b) {
 }
 
 /* A = local row panel (global column ids), the block = rows [r0, r0 + b) x columns [g0, g0 + b) */
+/* A supernode of ns > width columns is cut into pieces of equal width rounded up to a multiple of 64
+ * (so a piece may exceed `width` by up to 63 columns); the count follows from the ROUNDED width, so
+ * no piece is empty. */
+static int chain_pieces(int ns, int width, int* w_out) {
+  int np = (ns + width - 1) / width;
+  int w = ((ns + np - 1) / np + 63) & ~63;
+  if (w_out) *w_out = w;
+  return (ns + w - 1) / w;
+}
+
 static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, int b, int leaf_rows) {
   memset(B, 0, sizeof(*B));
   B->b = b; B->row0 = r0;
-  /* local pattern of the diagonal block */
-  int* lrp = (int*)malloc(((size_t)b + 1) * sizeof(int));
-  size_t cnt = 0;
+  /* The diagonal block with a structurally symmetric pattern: entry (i, j) is taken from row i
+   * where it is stored there, else from row j (a `general` MatrixMarket file may hold a symmetric
+   * matrix with explicit zeros dropped on one side only; operator.c accepts those, and both the
+   * dissection -- a separator must cut the graph in both directions -- and the lower triangle
+   * below need the whole pattern). */
+  int* lrp = (int*)calloc((size_t)b + 1, sizeof(int));
   if (!lrp) return 1;
-  lrp[0] = 0;
-  for (int i = 0; i < b; ++i) {
-    for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) { int c = A->colInd[k]; if (c >= g0 && c < g0 + b) ++cnt; }
-    lrp[i + 1] = (int)cnt;
-  }
-  int* lci = (int*)malloc((cnt ? cnt : 1) * sizeof(int));
-  if (!lci) { free(lrp); return 1; }
-  cnt = 0;
   for (int i = 0; i < b; ++i)
-    for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) { int c = A->colInd[k]; if (c >= g0 && c < g0 + b) lci[cnt++] = c - g0; }
+    for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) {
+      int c = A->colInd[k];
+      if (c >= g0 && c < g0 + b) { lrp[i + 1]++; if (c - g0 != i) lrp[c - g0 + 1]++; }
+    }
+  for (int i = 0; i < b; ++i) lrp[i + 1] += lrp[i];
+  size_t cnt = (size_t)lrp[b];
+  int* lci = (int*)malloc((cnt ? cnt : 1) * sizeof(int));
+  double* lv = (double*)malloc((cnt ? cnt : 1) * sizeof(double));
+  int* fillp = (int*)malloc(((size_t)b + 1) * sizeof(int));
+  if (!lci || !lv || !fillp) { free(lrp); free(lci); free(lv); free(fillp); return 1; }
+  memcpy(fillp, lrp, ((size_t)b + 1) * sizeof(int));
+  /* own entries first (ascending columns), mirrored ones behind them: marked by ~column */
+  for (int i = 0; i < b; ++i)
+    for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) {
+      int c = A->colInd[k];
+      if (c >= g0 && c < g0 + b) { lci[fillp[i]] = c - g0; lv[fillp[i]++] = A->val[k]; }
+    }
+  for (int i = 0; i < b; ++i)
+    for (int k = A->rowPtr[r0 + i]; k < A->rowPtr[r0 + i + 1]; ++k) {
+      int c = A->colInd[k];
+      if (c >= g0 && c < g0 + b && c - g0 != i) { lci[fillp[c - g0]] = ~i; lv[fillp[c - g0]++] = A->val[k]; }
+    }
+  free(fillp);
+  {
+    /* per row: merge the two ascending runs, an own entry wins over its mirror image */
+    int maxl = 0;
+    for (int i = 0; i < b; ++i) if (lrp[i + 1] - lrp[i] > maxl) maxl = lrp[i + 1] - lrp[i];
+    int* tc = (int*)malloc((size_t)(maxl ? maxl : 1) * sizeof(int));
+    double* tv = (double*)malloc((size_t)(maxl ? maxl : 1) * sizeof(double));
+    if (!tc || !tv) { free(lrp); free(lci); free(lv); free(tc); free(tv); return 1; }
+    int out = 0, begin = 0;
+    for (int i = 0; i < b; ++i) {
+      int e = lrp[i + 1], p = begin, q = begin, l = 0;
+      while (q < e && lci[q] >= 0) ++q;         /* [begin, q) own, [q, e) mirrored */
+      int pe = q;
+      while (p < pe || q < e) {
+        int cp_ = p < pe ? lci[p] : 2147483647, cq = q < e ? ~lci[q] : 2147483647;
+        if (cp_ <= cq) { tc[l] = cp_; tv[l++] = lv[p++]; if (cq == cp_) ++q; }
+        else { tc[l] = cq; tv[l++] = lv[q++]; }
+      }
+      begin = e;
+      lrp[i] = out;
+      memcpy(lci + out, tc, (size_t)l * sizeof(int));
+      memcpy(lv + out, tv, (size_t)l * sizeof(double));
+      out += l;
+    }
+    lrp[b] = out;
+    free(tc); free(tv);
+  }
   int rc = pa_nd_order(b, lrp, lci, leaf_rows, &B->tree);
-  free(lrp); free(lci);
-  if (rc) return 1;
+  if (rc) { free(lrp); free(lci); free(lv); return 1; }
+#define ND_FREE_LOCAL() do { free(lrp); free(lci); free(lv); } while (0)
   /* Very wide supernodes (the top separators of blocks of 100 k rows and more) are cut into chains of
    * at most `width` columns (PREALPS_ND_WIDTH, 2048), each piece the only child of the next: it bounds
    * the work of inverting a pivot triangle and forming G (n^2 (n / 3 + m) per front) and the unused
@@ -124,21 +177,22 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
     const int n0 = B->tree.nsn;
     int extra_tot = 0;
     int* base = (int*)malloc(((size_t)n0 + 1) * sizeof(int));
-    if (!base) return 1;
+    if (!base) { ND_FREE_LOCAL(); return 1; }
     for (int s = 0; s < n0; ++s) {
       int ns = B->tree.first[s + 1] - B->tree.first[s];
       base[s] = s + extra_tot;
-      if (width >= 64 && ns > width) extra_tot += (ns + width - 1) / width - 1;
+      if (width >= 64 && ns > width) extra_tot += chain_pieces(ns, width, NULL) - 1;
     }
     base[n0] = n0 + extra_tot;
     if (extra_tot > 0) {
       int n2 = n0 + extra_tot;
       int* first2 = (int*)malloc(((size_t)n2 + 1) * sizeof(int));
       int* parent2 = (int*)malloc((size_t)n2 * sizeof(int));
-      if (!first2 || !parent2) { free(base); free(first2); free(parent2); return 1; }
+      if (!first2 || !parent2) { free(base); free(first2); free(parent2); ND_FREE_LOCAL(); return 1; }
       for (int s = 0; s < n0; ++s) {
         int c0 = B->tree.first[s], ns = B->tree.first[s + 1] - c0, np = base[s + 1] - base[s];
-        int w = ((ns + np - 1) / np + 63) & ~63;              /* piece width: even shares, multiples of 64 */
+        int w = ns;                                            /* piece width: even shares, multiples of 64 */
+        if (np > 1) chain_pieces(ns, width, &w);
         for (int k = 0; k < np; ++k) {
           int id = base[s] + k, lo = c0 + k * w;
           if (lo > c0 + ns) lo = c0 + ns;
@@ -161,7 +215,7 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
   B->m = (int*)calloc((size_t)nsn, sizeof(int));
   B->below = (int**)calloc((size_t)nsn, sizeof(int*));
   B->cp = (int*)calloc((size_t)b + 1, sizeof(int));
-  if (!ip || !sn_of || !B->child || !B->height || !B->m || !B->below || !B->cp) { free(ip); free(sn_of); return 1; }
+  if (!ip || !sn_of || !B->child || !B->height || !B->m || !B->below || !B->cp) { free(ip); free(sn_of); ND_FREE_LOCAL(); return 1; }
   for (int i = 0; i < b; ++i) ip[perm[i]] = i;
   for (int s = 0; s < nsn; ++s) {
     B->child[2 * s] = B->child[2 * s + 1] = -1;
@@ -170,39 +224,35 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
   for (int s = 0; s < nsn; ++s) {
     int p = B->tree.parent[s];
     if (p < 0) continue;
-    if (p <= s) { free(ip); free(sn_of); return 1; }       /* postorder violated */
-    if (B->child[2 * p] < 0) B->child[2 * p] = s; else if (B->child[2 * p + 1] < 0) B->child[2 * p + 1] = s; else { free(ip); free(sn_of); return 1; }
+    if (p <= s) { free(ip); free(sn_of); ND_FREE_LOCAL(); return 1; }       /* postorder violated */
+    if (B->child[2 * p] < 0) B->child[2 * p] = s; else if (B->child[2 * p + 1] < 0) B->child[2 * p + 1] = s; else { free(ip); free(sn_of); ND_FREE_LOCAL(); return 1; }
     if (B->height[s] + 1 > B->height[p]) B->height[p] = B->height[s] + 1;
   }
   /* lower triangle by columns in the new order: column j = row perm[j] of the (symmetric) block */
   for (int j = 0; j < b; ++j) {
     int old = perm[j], c2 = 0;
-    for (int k = A->rowPtr[r0 + old]; k < A->rowPtr[r0 + old + 1]; ++k) {
-      int c = A->colInd[k];
-      if (c >= g0 && c < g0 + b && ip[c - g0] >= j) ++c2;
-    }
+    for (int k = lrp[old]; k < lrp[old + 1]; ++k) if (ip[lci[k]] >= j) ++c2;
     B->cp[j + 1] = B->cp[j] + c2;
   }
   B->ri = (int*)malloc((size_t)(B->cp[b] ? B->cp[b] : 1) * sizeof(int));
   B->cv = (double*)malloc((size_t)(B->cp[b] ? B->cp[b] : 1) * sizeof(double));
-  if (!B->ri || !B->cv) { free(ip); free(sn_of); return 1; }
+  if (!B->ri || !B->cv) { free(ip); free(sn_of); ND_FREE_LOCAL(); return 1; }
   {
     typedef struct { int r; double v; } rv_t;
     int maxc = 0;
     for (int j = 0; j < b; ++j) if (B->cp[j + 1] - B->cp[j] > maxc) maxc = B->cp[j + 1] - B->cp[j];
     rv_t* buf = (rv_t*)malloc((size_t)(maxc ? maxc : 1) * sizeof(rv_t));
-    if (!buf) { free(ip); free(sn_of); return 1; }
+    if (!buf) { free(ip); free(sn_of); ND_FREE_LOCAL(); return 1; }
     for (int j = 0; j < b; ++j) {
       int old = perm[j], l = 0;
-      for (int k = A->rowPtr[r0 + old]; k < A->rowPtr[r0 + old + 1]; ++k) {
-        int c = A->colInd[k];
-        if (c >= g0 && c < g0 + b && ip[c - g0] >= j) { buf[l].r = ip[c - g0]; buf[l].v = A->val[k]; ++l; }
-      }
+      for (int k = lrp[old]; k < lrp[old + 1]; ++k)
+        if (ip[lci[k]] >= j) { buf[l].r = ip[lci[k]]; buf[l].v = lv[k]; ++l; }
       for (int a = 1; a < l; ++a) { rv_t x = buf[a]; int q = a; while (q > 0 && buf[q - 1].r > x.r) { buf[q] = buf[q - 1]; --q; } buf[q] = x; }
       for (int a = 0; a < l; ++a) { B->ri[B->cp[j] + a] = buf[a].r; B->cv[B->cp[j] + a] = buf[a].v; }
     }
     free(buf);
   }
+  ND_FREE_LOCAL();
   /* rows below every supernode: entries of its columns and of its children's lists beyond its last column */
   int* mark = (int*)malloc((size_t)b * sizeof(int));
   int* tmp = (int*)malloc((size_t)b * sizeof(int));
@@ -240,6 +290,7 @@ static int nd_symbolic(nd_block_t* B, const CPLM_Mat_CSR_t* A, int r0, int g0, i
 /* Dense partial Cholesky of the first n columns of the f x f front (lower triangle, column
  * major, leading dimension f): L11 L11^T = F11, L21 = F21 L11^-T, F22 <- F22 - L21 L21^T.
  * Returns 0 or 1 + the failing column. */
+__attribute__((target_clones("avx2,fma", "default")))
 static int front_factor(int f, int n, double* F) {
   const int NB = 32;
   for (int jb = 0; jb < n; jb += NB) {
@@ -277,6 +328,7 @@ static int front_factor(int f, int n, double* F) {
  * With these the solves are products (kernels.hip): forward a = T w and contribution -= G w,
  * backward z_1 = T^T D^-1 y_1 - G^T z_2 -- exactly transposed operators, so the block solve stays
  * symmetric.  wk: n * n + n doubles.  Returns the largest entry of T (I + Lhat_11) - I. */
+__attribute__((target_clones("avx2,fma", "default")))
 static double nd_selinv(int n, int m, int ld, double* pf, double* wk) {
   double* Lc = wk;                 /* n x n copy of I + Lhat_11 (column major, ld n) */
   double* t = wk + (size_t)n * n;  /* one column of T */
@@ -665,12 +717,13 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
 #pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 1)
   for (int x = 0; x < nblk; ++x) {
     int q = blocks[x];
-    if (nd_symbolic(&B[x], A, row0[q], grow0[q], nrows[q], leaf_rows)) {
+    int r1 = nd_symbolic(&B[x], A, row0[q], grow0[q], nrows[q], leaf_rows);
+    if (r1) {
 #pragma omp critical
-      rc = 1;
+      { if (r1 > rc) rc = r1; }
     }
   }
-  if (rc) { for (int x = 0; x < nblk; ++x) nd_block_free(&B[x]); free(B); return PA_FAIL("nested dissection of the diagonal blocks failed (out of memory)"); }
+  if (rc) { for (int x = 0; x < nblk; ++x) nd_block_free(&B[x]); free(B); return PA_FAIL("nested dissection of the diagonal blocks failed (%s)", rc == 2 ? "a separator does not separate: is the matrix structurally singular?" : "out of memory"); }
   if (trace) { fprintf(stderr, "[nd] ordering + symbolic phase of %d blocks: %.2f s\n", nblk, pa_wtime() - t_phase); t_phase = pa_wtime(); }
   /* global numbering of the supernodes and offsets */
   int nsn = 0, maxh = 0;

@@ -436,17 +436,20 @@ static int g_plan_only = 0;
  * multi-process CPU tests exercise.  BlockOperator is unavailable in this mode. */
 void preAlps_hip_plan_only(int on) { g_plan_only = on ? 1 : 0; }
 
-int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, const double* val,
-                                 int nparts, const int* part, int scale) {
-  if (!g_plan_only) PA_REQUIRE_GPU();
-  if (g_op.info.built) preAlps_OperatorFree();
-  double t_build0 = pa_wtime();
-  pa_operator_t* o = &g_op;
-  pa_operator_info_t* in = &o->info;
-  int rank = pa_world_rank(), size = pa_world_size();
-  if (N < 1 || nparts < 1 || nparts > N) return PA_FAIL("invalid sizes N=%d nparts=%d", N, nparts);
-  if (nparts < size)
-    return PA_FAIL("Each process needs at least one block (nparts = %d < %d = processes)", nparts, size);
+/* ---- the build, in three steps ------------------------------------------------------------
+ * (1) order_and_scale: what needs the whole matrix -- the diagonal check, the scaling vector of
+ *     SymRACScaling and the ordering that groups rows part by part (rank 0 only when the set-up is
+ *     distributed);
+ * (2) build_panel: this process's row panel from its raw rows (scaled, renumbered, sorted), the
+ *     halo slots and who owns them;
+ * (3) the send lists: from the whole matrix when every process holds it, else by asking the
+ *     owners (pa_mpi_swap_lists);  then the upload. */
+#define TRACE_DECL double t_tr = pa_wtime(); const int tr = getenv("PREALPS_SETUP_TRACE") != NULL
+#define TRACE(what) do { if (tr) { double n_ = pa_wtime(); fprintf(stderr, "[setup] %-28s %.3f s\n", what, n_ - t_tr); t_tr = n_; } } while (0)
+
+static int order_and_scale(int N, const int* rowPtr, const int* colInd, const double* val, int nparts,
+                           const int* part, int scale, pa_operator_info_t* in, double** d_out, int** iperm_out) {
+  TRACE_DECL;
   {
     int bad_row = -1;
 #pragma omp parallel for num_threads(pa_host_threads()) schedule(static)
@@ -460,13 +463,12 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     }
     if (bad_row >= 0) return PA_FAIL("Diagonal is not set correctly (row %d)", bad_row);
   }
-  double t_tr = pa_wtime(); const int tr = getenv("PREALPS_SETUP_TRACE") != NULL;
-#define TRACE(what) do { if (tr) { double n_ = pa_wtime(); fprintf(stderr, "[setup] %-28s %.3f s\n", what, n_ - t_tr); t_tr = n_; } } while (0)
   TRACE("diagonal check");
-  /* 1. SymRACScaling: d_i = 1/sqrt(max_j |a_ij|) */
+  /* SymRACScaling: d_i = 1/sqrt(max_j |a_ij|) */
   double* d = NULL;
   if (scale) {
     d = (double*)malloc((size_t)N * sizeof(double));
+    if (!d) return PA_FAIL("out of host memory");
     int zero_row = 0;
 #pragma omp parallel for num_threads(pa_host_threads()) schedule(static) reduction(|| : zero_row)
     for (int i = 0; i < N; ++i) {
@@ -478,11 +480,12 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     if (zero_row) { free(d); return PA_FAIL("Impossible to scale the matrix, rcmin=0"); }
   }
   TRACE("scaling");
-  /* 2. ordering: rows grouped part by part, original order inside a part */
+  /* ordering: rows grouped part by part, original order inside a part */
   in->N = N; in->nparts = nparts;
-  in->rowPos = (int*)calloc(nparts + 1, sizeof(int));
+  in->rowPos = (int*)calloc((size_t)nparts + 1, sizeof(int));
   in->perm = (int*)malloc((size_t)N * sizeof(int));
   int* iperm = (int*)malloc((size_t)N * sizeof(int));
+  if (!in->rowPos || !in->perm || !iperm) { free(d); free(iperm); return PA_FAIL("out of host memory"); }
   for (int i = 0; i < N; ++i) {
     int p = part ? part[i] : (int)(((long long)i * nparts) / N);
     if (p < 0 || p >= nparts) { free(d); free(iperm); return PA_FAIL("partition entry %d of row %d out of range", p, i); }
@@ -493,8 +496,8 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     in->rowPos[p + 1] += in->rowPos[p];
   }
   {
-    int* fill = (int*)malloc(nparts * sizeof(int));
-    memcpy(fill, in->rowPos, nparts * sizeof(int));
+    int* fill = (int*)malloc((size_t)nparts * sizeof(int));
+    memcpy(fill, in->rowPos, (size_t)nparts * sizeof(int));
     for (int i = 0; i < N; ++i) {
       int p = part ? part[i] : (int)(((long long)i * nparts) / N);
       in->perm[fill[p]] = i;
@@ -503,24 +506,38 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     free(fill);
   }
   TRACE("ordering");
-  /* 3. the row panel of this process */
+  *d_out = d; *iperm_out = iperm;
+  return 0;
+}
+
+/* Rows [row_off, row_off + m) of the permuted, scaled matrix from their raw form: row i of the panel
+ * is row (whole ? perm[row_off + i] : i) of (rp, ci, v), columns in the ORIGINAL numbering.  Leaves the
+ * panel (global permuted column ids, sorted), the halo slots (halo_cols ascending, lcol) and the
+ * receive counts per process in `o`; `mark_out` (N ints: halo slot + 1) is handed to the caller. */
+static int build_panel(pa_operator_t* o, const int* rp, const int* ci, const double* v, int whole,
+                       const double* d, const int* iperm, long long nnz_global, int** recv_by_proc_out) {
+  pa_operator_info_t* in = &o->info;
+  TRACE_DECL;
+  const int N = in->N, nparts = in->nparts, rank = pa_world_rank(), size = pa_world_size();
   in->part0 = (int)((long long)rank * nparts / size);
   in->part1 = (int)((long long)(rank + 1) * nparts / size);
   in->row_off = in->rowPos[in->part0];
   int m = in->rowPos[in->part1] - in->row_off;
   in->m = m;
+#define SRC(i) (whole ? in->perm[in->row_off + (i)] : (i))
   size_t lnnz = 0;
-  for (int i = 0; i < m; ++i) { int old = in->perm[in->row_off + i]; lnnz += rowPtr[old + 1] - rowPtr[old]; }
-  if (lnnz > 2147483000u) { free(d); free(iperm); return PA_FAIL("local panel has too many nonzeros for int32 indices"); }
+  for (int i = 0; i < m; ++i) { int r = SRC(i); lnnz += (size_t)(rp[r + 1] - rp[r]); }
+  if (lnnz > 2147483000u) return PA_FAIL("local panel has too many nonzeros for int32 indices");
   CPLM_Mat_CSR_t* A = &in->A;
   A->rowPtr = (int*)malloc((size_t)(m + 1) * sizeof(int));
   A->colInd = (int*)big_alloc((lnnz ? lnnz : 1) * sizeof(int));
   A->val = (double*)big_alloc((lnnz ? lnnz : 1) * sizeof(double));
+  if (!A->rowPtr || !A->colInd || !A->val) return PA_FAIL("out of host memory for the row panel (%zu entries)", lnnz);
   A->rowPtr[0] = 0;
   {
     int maxlen = 0;
     for (int i = 0; i < m; ++i) {
-      int old = in->perm[in->row_off + i]; int l = rowPtr[old + 1] - rowPtr[old];
+      int r = SRC(i); int l = rp[r + 1] - rp[r];
       if (l > maxlen) maxlen = l;
       A->rowPtr[i + 1] = A->rowPtr[i] + l;
     }
@@ -531,11 +548,11 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
       cv_t* buf = (cv_t*)malloc((maxlen ? maxlen : 1) * sizeof(cv_t));
 #pragma omp for schedule(static)
       for (int i = 0; i < m; ++i) {
-        int old = in->perm[in->row_off + i];
+        int old = in->perm[in->row_off + i], r = whole ? old : i;
         int l = 0, sorted = 1;
-        for (int k = rowPtr[old]; k < rowPtr[old + 1]; ++k, ++l) {
-          buf[l].c = iperm[colInd[k]];
-          buf[l].v = d ? d[old] * val[k] * d[colInd[k]] : val[k];
+        for (int k = rp[r]; k < rp[r + 1]; ++k, ++l) {
+          buf[l].c = iperm[ci[k]];
+          buf[l].v = d ? d[old] * v[k] * d[ci[k]] : v[k];
           if (l > 0 && buf[l].c < buf[l - 1].c) sorted = 0;
         }
         if (!sorted) qsort(buf, l, sizeof(cv_t), cmp_cv);
@@ -545,27 +562,26 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
       }
       free(buf);
     }
-    if (dup_row >= 0) {
-      free(d); free(iperm);
+    if (dup_row >= 0)
       return PA_FAIL("row %d holds the same column twice: sum duplicate entries before building the operator", dup_row);
-    }
   }
+#undef SRC
   TRACE("permute + sort rows");
-  free(d);
-  A->info.M = N; A->info.N = N; A->info.nnz = rowPtr[N]; A->info.m = m; A->info.n = N;
+  A->info.M = N; A->info.N = N; A->info.nnz = (int)(nnz_global > 2147483647LL ? 2147483647LL : nnz_global);
+  A->info.m = m; A->info.n = N;
   A->info.lnnz = (int)lnnz; A->info.blockSize = 1; A->info.format = FORMAT_CSR;
   A->info.structure = UNSYMMETRIC;
   o->lnnz = (int)lnnz;
-  /* 4. halo: off-process columns, grouped by owner (ascending global index) */
+  /* halo: off-process columns, grouped by owner (ascending global index) */
   int lo = in->row_off, hi = in->row_off + m;
   int* mark = (int*)calloc((size_t)N, sizeof(int)); /* halo slot + 1 */
+  if (!mark) return PA_FAIL("out of host memory");
   int halo = 0;
   for (size_t k = 0; k < lnnz; ++k) { int c = A->colInd[k]; if ((c < lo || c >= hi) && !mark[c]) { mark[c] = 1; ++halo; } }
   int* halo_cols = (int*)malloc((halo ? halo : 1) * sizeof(int));
   { int q = 0; for (int c = 0; c < N; ++c) if (mark[c]) { halo_cols[q] = c; mark[c] = ++q; } }
   in->halo = halo;
   TRACE("halo marks");
-  /* peers and receive counts */
   o->peers = (int*)malloc((size > 0 ? size : 1) * sizeof(int));
   o->recv_rows = (int*)calloc(size, sizeof(int));
   o->send_rows = (int*)calloc(size, sizeof(int));
@@ -574,15 +590,76 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   int* recv_by_proc = (int*)calloc(size, sizeof(int));
   for (int q = 0; q < halo; ++q)
     recv_by_proc[owner_of_part(part_of_row(in->rowPos, nparts, halo_cols[q]), nparts, size)]++;
+  /* device CSR with local column ids */
+  int* lcol = (int*)big_alloc((lnnz + 8) * sizeof(int));
+  if (!lcol) { free(mark); free(recv_by_proc); return PA_FAIL("out of host memory"); }
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(static)
+  for (long long k = 0; k < (long long)lnnz; ++k) { int c = A->colInd[k]; lcol[k] = (c >= lo && c < hi) ? c - lo : m + mark[c] - 1; }
+  for (size_t k = lnnz; k < lnnz + 8; ++k) lcol[k] = 0;
+  free(mark);
+  o->halo_cols = halo_cols;
+  o->lcol = lcol;
+  TRACE("local columns");
+  *recv_by_proc_out = recv_by_proc;
+  return 0;
+}
+
+/* peers / send_rows / recv_rows / send_idx from need-lists: asked[] = for every process g (in rank
+ * order) the local rows of ours it reads, asked_cnt[g] of them, ascending. */
+static int finish_peers(pa_operator_t* o, const int* recv_by_proc, int* asked_local, const int* asked_cnt) {
+  int size = pa_world_size();
+  o->nsend = 0; o->npeers = 0;
+  for (int g = 0; g < size; ++g) {
+    if (asked_cnt[g] || recv_by_proc[g]) {
+      o->peers[o->npeers] = g; o->recv_rows[o->npeers] = recv_by_proc[g]; o->send_rows[o->npeers] = asked_cnt[g];
+      o->npeers++;
+    }
+    o->nsend += asked_cnt[g];
+  }
+  o->send_idx = asked_local;
+  return 0;
+}
+
+static int upload_operator(pa_operator_t* o, double t_build0) {
+  pa_operator_info_t* in = &o->info;
+  if (g_plan_only) { in->built = 1; return 0; }
+  int rc = 0;
+  if (o->nsend > 0) {
+    o->d_send_idx = (int*)pa_rt_malloc((size_t)o->nsend * sizeof(int));
+    rc = !o->d_send_idx || pa_rt_h2d(o->d_send_idx, o->send_idx, (size_t)o->nsend * sizeof(int));
+  }
+  if (rc) return PA_FAIL("uploading the operator failed: %s", pa_rt_error());
+  in->built = 1;
+  g_setup_build_s = pa_wtime() - t_build0;
+  return 0;
+}
+
+int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, const double* val,
+                                 int nparts, const int* part, int scale) {
+  if (!g_plan_only) PA_REQUIRE_GPU();
+  if (g_op.info.built) preAlps_OperatorFree();
+  double t_build0 = pa_wtime();
+  pa_operator_t* o = &g_op;
+  pa_operator_info_t* in = &o->info;
+  int rank = pa_world_rank(), size = pa_world_size();
+  if (N < 1 || nparts < 1 || nparts > N) return PA_FAIL("invalid sizes N=%d nparts=%d", N, nparts);
+  if (nparts < size)
+    return PA_FAIL("Each process needs at least one block (nparts = %d < %d = processes)", nparts, size);
+  double* d = NULL; int* iperm = NULL; int* recv_by_proc = NULL;
+  if (order_and_scale(N, rowPtr, colInd, val, nparts, part, scale, in, &d, &iperm)) return 1;
+  if (build_panel(o, rowPtr, colInd, val, 1, d, iperm, (long long)rowPtr[N], &recv_by_proc)) { free(d); free(iperm); return 1; }
+  free(d);
+  TRACE_DECL;
+  int m = in->m, lo = in->row_off, hi = in->row_off + m;
   /* Send lists, exactly: process g receives from us the rows of ours that occur as columns in
    * ITS rows (ascending) -- which is how g numbers its halo slots.  Every process holds the
-   * whole matrix at build time, so this needs no communication and, unlike taking "our rows
-   * that touch a column of g", it stays right for a pattern that is not structurally symmetric
-   * (a `general` .mtx with explicit zeros dropped on one side). */
+   * whole matrix here, so this needs no communication and, unlike taking "our rows that touch a
+   * column of g", it stays right for a pattern that is not structurally symmetric (a `general`
+   * .mtx with explicit zeros dropped on one side). */
   unsigned char* need = NULL;   /* need[g * m + i]: process g reads our local row i */
   if (size > 1) {
     need = (unsigned char*)calloc((size_t)size * (m ? m : 1), 1);
-    if (!need) { free(iperm); free(mark); free(recv_by_proc); return PA_FAIL("out of host memory for the halo plan"); }
+    if (!need) { free(iperm); free(recv_by_proc); return PA_FAIL("out of host memory for the halo plan"); }
 #pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 4096)
     for (int i = 0; i < N; ++i) {
       int r = iperm[i];
@@ -595,45 +672,21 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
     }
   }
   free(iperm);
-  size_t send_cap = 1024;
+  size_t send_cap = 1024, nsend = 0;
   int* send_idx = (int*)malloc(send_cap * sizeof(int));
-  o->nsend = 0;
-  o->npeers = 0;
+  int* asked_cnt = (int*)calloc(size, sizeof(int));
   for (int g = 0; g < size; ++g) {
-    int cnt = 0;
-    if (need && g != rank)
-      for (int i = 0; i < m; ++i) if (need[(size_t)g * m + i]) {
-        if ((size_t)o->nsend + 1 > send_cap) { send_cap *= 2; send_idx = (int*)realloc(send_idx, send_cap * sizeof(int)); }
-        send_idx[o->nsend++] = i; ++cnt;
-      }
-    if (cnt || recv_by_proc[g]) {
-      o->peers[o->npeers] = g; o->recv_rows[o->npeers] = recv_by_proc[g]; o->send_rows[o->npeers] = cnt;
-      o->npeers++;
+    if (!need || g == rank) continue;
+    for (int i = 0; i < m; ++i) if (need[(size_t)g * m + i]) {
+      if (nsend + 1 > send_cap) { send_cap *= 2; send_idx = (int*)realloc(send_idx, send_cap * sizeof(int)); }
+      send_idx[nsend++] = i; asked_cnt[g]++;
     }
   }
   free(need);
-  free(recv_by_proc);
+  finish_peers(o, recv_by_proc, send_idx, asked_cnt);
+  free(recv_by_proc); free(asked_cnt);
   TRACE("peer lists");
-  /* 5. device CSR with local column ids */
-  int* lcol = (int*)big_alloc((lnnz + 8) * sizeof(int));
-#pragma omp parallel for num_threads(pa_host_threads()) schedule(static)
-  for (long long k = 0; k < (long long)lnnz; ++k) { int c = A->colInd[k]; lcol[k] = (c >= lo && c < hi) ? c - lo : m + mark[c] - 1; }
-  for (size_t k = lnnz; k < lnnz + 8; ++k) lcol[k] = 0;
-  free(mark);
-  o->halo_cols = halo_cols;
-  o->send_idx = send_idx;
-  o->lcol = lcol;
-  TRACE("local columns");
-  if (g_plan_only) { in->built = 1; return 0; }
-  int rc = 0;
-  if (o->nsend > 0) {
-    o->d_send_idx = (int*)pa_rt_malloc((size_t)o->nsend * sizeof(int));
-    rc = !o->d_send_idx || pa_rt_h2d(o->d_send_idx, send_idx, (size_t)o->nsend * sizeof(int));
-  }
-  if (rc) return PA_FAIL("uploading the operator failed: %s", pa_rt_error());
-  in->built = 1;
-  g_setup_build_s = pa_wtime() - t_build0;
-  return 0;
+  return upload_operator(o, t_build0);
 }
 
 /* MatrixMarket coordinate real general|symmetric; 0-based files are detected
@@ -700,39 +753,181 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
   return 0;
 }
 
-/* The number of subdomains is PREALPS_NPARTS (default: the process count, as in the
- * reference).  The partition comes from the library's k-way graph partitioner
+/* The partition vector of the whole matrix, as preAlps_OperatorBuild picks it: from
+ * PREALPS_PARTITION_FILE (one part id per line, e.g. METIS output), contiguous row blocks with
+ * PREALPS_PARTITION=contiguous (*part_out = NULL), else the library's k-way graph partitioner
  * (partition.c), which stands where the reference calls METIS_PartGraphKway
- * (utils/operator.c:77-97 -> utils/cplm_core/cplm_matcsr_core.c:394-457); or from
- * PREALPS_PARTITION_FILE (one part id per line, e.g. METIS output); or, with
- * PREALPS_PARTITION=contiguous, from contiguous blocks of rows (the partition the
- * recorded reference runs of BASELINE.md used). */
+ * (utils/operator.c:77-97 -> utils/cplm_core/cplm_matcsr_core.c:394-457). */
+static int choose_partition(int N, const int* rp, const int* ci, int nparts, int** part_out) {
+  int* part = NULL;
+  *part_out = NULL;
+  const char* pf = getenv("PREALPS_PARTITION_FILE");
+  if (pf && *pf) {
+    FILE* f = fopen(pf, "r");
+    if (!f) return PA_FAIL("Impossible to open the file %s", pf);
+    part = (int*)malloc((size_t)N * sizeof(int));
+    for (int i = 0; part && i < N; ++i)
+      if (fscanf(f, "%d", &part[i]) != 1) { fclose(f); free(part); return PA_FAIL("partition file %s is too short", pf); }
+    fclose(f);
+    if (!part) return PA_FAIL("out of host memory");
+  } else {
+    const char* how = getenv("PREALPS_PARTITION");
+    if (!(how && !strcmp(how, "contiguous")) && nparts > 1) {
+      if (nparts > N) return PA_FAIL("invalid sizes N=%d nparts=%d", N, nparts);
+      part = (int*)malloc((size_t)N * sizeof(int));
+      if (!part || preAlps_hip_partition_kway(N, rp, ci, nparts, part)) { free(part); return 1; }
+    }
+  }
+  *part_out = part;
+  return 0;
+}
+
+/* One MPI rank per GPU (the reference's own mode: utils/operator.c:38-134).  Rank 0 reads, scales
+ * and partitions the matrix -- with the whole CPU share of the node, the other ranks sleep --
+ * broadcasts the ordering and the scaling vector (12 bytes per row) and sends every rank the raw
+ * rows of its panel (CPLM_MatCSRGetRowPanel + CPLM_MatCSRSend, utils/operator.c:99-108;
+ * utils/cplm_light/cplm_matcsr.c:382-497); each rank then scales, renumbers and sorts its own rows,
+ * finds its halo and asks the owners for exactly those rows.  No rank but 0 ever holds more than
+ * its panel. */
+static int build_distributed(const char* file, int rank, int size) {
+  double t_build0 = pa_wtime();
+  pa_operator_t* o = &g_op;
+  pa_operator_info_t* in = &o->info;
+  TRACE_DECL;
+  int N = 0; int* rp = NULL; int* ci = NULL; double* v = NULL;
+  double* d = NULL; int* iperm = NULL;
+  long long hdr[4] = {0, 0, 0, 0};          /* rc, N, nparts, nnz */
+  const int abort_mode_rc = 1;
+  if (rank == 0) {
+    pa_host_solo(1);
+    int rc = load_mtx(file, &N, &rp, &ci, &v);
+    TRACE("rank 0: read the matrix");
+    int nparts = env_int("PREALPS_NPARTS", size);
+    int* part = NULL;
+    if (!rc && (nparts < size || nparts > N))
+      rc = PA_FAIL("Each process needs at least one block (nparts = %d, %d processes, %d rows)", nparts, size, N);
+    rc = rc || choose_partition(N, rp, ci, nparts, &part);
+    TRACE("rank 0: partition");
+    rc = rc || order_and_scale(N, rp, ci, v, nparts, part, 1, in, &d, &iperm);
+    free(part);
+    pa_host_solo(0);
+    hdr[0] = rc ? abort_mode_rc : 0; hdr[1] = N; hdr[2] = nparts; hdr[3] = rc ? 0 : rp[N];
+  }
+  if (pa_mpi_bcast(hdr, sizeof(hdr), 0)) return 1;
+  if (hdr[0]) {
+    free(rp); free(ci); free(v); free(d); free(iperm);
+    return rank == 0 ? 1 : PA_FAIL("rank 0 could not read or partition %s", file);
+  }
+  N = (int)hdr[1];
+  int nparts = (int)hdr[2];
+  if (rank != 0) {
+    in->N = N; in->nparts = nparts;
+    in->rowPos = (int*)malloc(((size_t)nparts + 1) * sizeof(int));
+    in->perm = (int*)malloc((size_t)N * sizeof(int));
+    iperm = (int*)malloc((size_t)N * sizeof(int));
+    d = (double*)malloc((size_t)N * sizeof(double));
+    if (!in->rowPos || !in->perm || !iperm || !d) return PA_FAIL("out of host memory");
+  }
+  if (pa_mpi_bcast(in->rowPos, ((size_t)nparts + 1) * sizeof(int), 0) || pa_mpi_bcast(in->perm, (size_t)N * sizeof(int), 0) ||
+      pa_mpi_bcast(d, (size_t)N * sizeof(double), 0))
+    return 1;
+  if (rank != 0)
+    for (int k = 0; k < N; ++k) iperm[in->perm[k]] = k;
+  TRACE("ordering + scaling vector (broadcast)");
+  int* recv_by_proc = NULL;
+  if (rank == 0) {
+    /* raw rows of every other panel: row lengths, column ids, values -- three messages per rank */
+    size_t cap = 0;
+    int* bl = NULL; int* bc = NULL; double* bv = NULL;
+    for (int g = 1; g < size; ++g) {
+      int p0 = (int)((long long)g * nparts / size), p1 = (int)((long long)(g + 1) * nparts / size);
+      int r0 = in->rowPos[p0], mg = in->rowPos[p1] - r0;
+      size_t nz = 0;
+      for (int i = 0; i < mg; ++i) { int old = in->perm[r0 + i]; nz += (size_t)(rp[old + 1] - rp[old]); }
+      if (nz > cap || !bl) {
+        free(bc); free(bv);
+        cap = nz + nz / 8 + 16;
+        bc = (int*)big_alloc(cap * sizeof(int)); bv = (double*)big_alloc(cap * sizeof(double));
+      }
+      bl = (int*)realloc(bl, ((size_t)mg + 1) * sizeof(int));
+      if (!bl || !bc || !bv) return PA_FAIL("out of host memory for the panel of rank %d", g);
+      bl[0] = 0;
+      for (int i = 0; i < mg; ++i) { int old = in->perm[r0 + i]; bl[i + 1] = bl[i] + (rp[old + 1] - rp[old]); }
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(static)
+      for (int i = 0; i < mg; ++i) {
+        int old = in->perm[r0 + i];
+        memcpy(bc + bl[i], ci + rp[old], (size_t)(rp[old + 1] - rp[old]) * sizeof(int));
+        memcpy(bv + bl[i], v + rp[old], (size_t)(rp[old + 1] - rp[old]) * sizeof(double));
+      }
+      if (pa_mpi_send(bl, ((size_t)mg + 1) * sizeof(int), g, 41) || pa_mpi_send(bc, nz * sizeof(int), g, 42) ||
+          pa_mpi_send(bv, nz * sizeof(double), g, 43))
+        return 1;
+    }
+    free(bl); free(bc); free(bv);
+    TRACE("rank 0: panels sent");
+    if (build_panel(o, rp, ci, v, 1, d, iperm, hdr[3], &recv_by_proc)) return 1;
+    free(rp); free(ci); free(v);
+  } else {
+    int p0 = (int)((long long)rank * nparts / size), p1 = (int)((long long)(rank + 1) * nparts / size);
+    int mg = in->rowPos[p1] - in->rowPos[p0];
+    int* lrp = (int*)malloc(((size_t)mg + 1) * sizeof(int));
+    if (!lrp || pa_mpi_recv(lrp, ((size_t)mg + 1) * sizeof(int), 0, 41)) return PA_FAIL("receiving the panel failed");
+    size_t nz = (size_t)lrp[mg];
+    int* lci = (int*)big_alloc((nz ? nz : 1) * sizeof(int));
+    double* lv = (double*)big_alloc((nz ? nz : 1) * sizeof(double));
+    if (!lci || !lv) return PA_FAIL("out of host memory for the row panel (%zu entries)", nz);
+    if (pa_mpi_recv(lci, nz * sizeof(int), 0, 42) || pa_mpi_recv(lv, nz * sizeof(double), 0, 43)) return 1;
+    TRACE("panel received");
+    int rc = build_panel(o, lrp, lci, lv, 0, d, iperm, hdr[3], &recv_by_proc);
+    free(lrp); free(lci); free(lv);
+    if (rc) return 1;
+  }
+  free(d);
+  /* send lists: every rank asks the owners for the rows behind its halo slots (halo_cols is
+   * ascending, hence grouped by owner); what a rank is asked for, in that order, is what it packs */
+  int* asked = NULL;
+  int* asked_cnt = (int*)calloc((size_t)size, sizeof(int));
+  if (!asked_cnt || pa_mpi_swap_lists(o->halo_cols, recv_by_proc, &asked, asked_cnt)) return 1;
+  {
+    long long tot = 0;
+    for (int g = 0; g < size; ++g) tot += asked_cnt[g];
+    for (long long k = 0; k < tot; ++k) {
+      int r = asked[k] - in->row_off;
+      if (r < 0 || r >= in->m) return PA_FAIL("a neighbour asked for row %d, which this rank does not own", asked[k]);
+      asked[k] = r;
+    }
+  }
+  free(iperm);
+  finish_peers(o, recv_by_proc, asked, asked_cnt);
+  free(recv_by_proc); free(asked_cnt);
+  TRACE("peer lists (exchanged)");
+  return upload_operator(o, t_build0);
+}
+
+/* The number of subdomains is PREALPS_NPARTS (default: the process count, as in the
+ * reference).  Started by an MPI launcher (the reference driver: MPI_Init, then
+ * preAlps_OperatorBuild(file, MPI_COMM_WORLD)), rank and size come from `comm`, the device from
+ * the rank's position on its node, the process-group hooks bind to RCCL (or to MPI through the
+ * host when ranks share a device) and the set-up is distributed from rank 0: no caller change
+ * (mpi_glue.c).  PREALPS_PLAN_ONLY=1: plan the sharding without touching a GPU. */
 int preAlps_OperatorBuild(const char* matrixFilename, MPI_Comm comm) {
-  (void)comm;
   size_t len = strlen(matrixFilename);
   if (len < 3 || strcmp(matrixFilename + len - 3, "mtx") != 0)
     return PA_FAIL("Only MatrixMarket (.mtx) files are supported: %s", matrixFilename);
+  if (env_int("PREALPS_PLAN_ONLY", 0)) g_plan_only = 1;
+  int mrank = 0, msize = 1;
+  if (pa_mpi_attach(comm, &mrank, &msize)) {
+    if (g_op.info.built) preAlps_OperatorFree();
+    if (preAlps_hip_set_world(mrank, msize)) return 1;
+    if (!g_plan_only && pa_mpi_bind()) return 1;
+    return build_distributed(matrixFilename, mrank, msize);
+  }
   int N = 0; int* rp = NULL; int* ci = NULL; double* v = NULL;
   int rc = load_mtx(matrixFilename, &N, &rp, &ci, &v);
   if (rc) return rc;
   int nparts = env_int("PREALPS_NPARTS", pa_world_size());
   int* part = NULL;
-  const char* pf = getenv("PREALPS_PARTITION_FILE");
-  if (pf && *pf) {
-    FILE* f = fopen(pf, "r");
-    if (!f) { free(rp); free(ci); free(v); return PA_FAIL("Impossible to open the file %s", pf); }
-    part = (int*)malloc((size_t)N * sizeof(int));
-    for (int i = 0; i < N; ++i)
-      if (fscanf(f, "%d", &part[i]) != 1) { fclose(f); free(part); free(rp); free(ci); free(v); return PA_FAIL("partition file %s is too short", pf); }
-    fclose(f);
-  } else {
-    const char* how = getenv("PREALPS_PARTITION");
-    if (!(how && !strcmp(how, "contiguous")) && nparts > 1) {
-      if (nparts > N) { free(rp); free(ci); free(v); return PA_FAIL("invalid sizes N=%d nparts=%d", N, nparts); }
-      part = (int*)malloc((size_t)N * sizeof(int));
-      if (!part || preAlps_hip_partition_kway(N, rp, ci, nparts, part)) { free(part); free(rp); free(ci); free(v); return 1; }
-    }
-  }
+  if (choose_partition(N, rp, ci, nparts, &part)) { free(rp); free(ci); free(v); return 1; }
   rc = preAlps_OperatorBuildFromCSR(N, rp, ci, v, nparts, part, 1);
   free(part); free(rp); free(ci); free(v);
   return rc;
@@ -883,6 +1078,7 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "bj_parts_local")) *value = pa_bj_nparts();
   else if (!strcmp(key, "bj_nd_blocks")) *value = pa_bj_nd_blocks();
   else if (!strcmp(key, "bj_pairs_bytes")) *value = pa_bj_pairs_bytes();
+  else if (!strcmp(key, "bj_g4_bytes")) *value = pa_bj_g4_bytes();
   else if (!strcmp(key, "bj_nd_inverse_dev")) *value = pa_nd_inverse_deviation();
   else return 1;
   return 0;

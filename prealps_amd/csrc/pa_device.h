@@ -37,6 +37,14 @@ int pa_rt_event_record(void* e);
 int pa_rt_event_wait(void* e);
 double pa_rt_event_elapsed_s(void* a, void* b);
 int pa_rt_num_cus(void);
+int pa_rt_device_count(void);
+/* graphs (runtime.hip): capture the work queued on the current stream, replay it later */
+int pa_rt_capture_begin(void);
+int pa_rt_capture_end(void** exec_out);
+int pa_rt_graph_launch(void* exec);
+void pa_rt_graph_free(void* exec);
+void pa_rt_skip(int on);      /* 1: asynchronous device operations become no-ops (a graph queues them) */
+int pa_rt_skipping(void);
 
 /* ---- native RCCL hooks (comm_rccl.hip) --------------------------------- */
 const char* pa_rccl_error(void);
@@ -172,6 +180,12 @@ typedef struct {
   /* optional (NULL: absent): the same records in pairs for the classes R = 2, 3 (k_bj_pairs), block p at
    * off2[p]: per chunk of 8 steps two sub-blocks of [2 pivot pairs][w + 4 target rows] double2 */
   const double* Lf2; const double* Lb2; const long long* off2;
+  /* optional (NULL: absent): ONE copy of the factor for both sweeps of panels of up to 4 columns, in
+   * selective-inversion form by groups of four pivots (bj_g4.hip), block p at off2[p]: per group
+   * (w + 4) rows x 4 pivots of M = [T - I ; -G], eligible classes flagged in class_g4 */
+  const double* Lg4;
+  const int* class_g4;    /* host array, nclass: 1 = every block of the class has a record in Lg4 */
+  const int* class_bmax;   /* host array, nclass: most rows of a block in the class */
   const double* invd_f;    /* 1 / L(j,j) in forward step order (m entries) */
   const double* invd_b;    /* ... in backward step order */
   int nclass;              /* parts grouped by register sets R = ceil((w+64)/64) of the one-wavefront kernel */
@@ -180,9 +194,18 @@ typedef struct {
   const int* class_wmax;   /* host array: widest band in the class (sizes the LDS chunks) */
   const int* const* class_list; /* host array of device pointers to part ids */
 } pa_bj_plan_t;
+int pa_k_bj_g4(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int bmax, int xs, int ncol,
+                const double* in, double* out);
 int pa_bj_max_R(void);
 int pa_k_bj_pairs(const int* list, int count, const int* nrows, const int* bw, const long long* off,
                   const long long* off2, const double* L, double* L2);
+/* bj_g4.hip: the records of Lg4 from the plain forward records, and the block solve that reads them
+ * (blocks of at most pa_bj_g4_max_rows() rows, bands up to pa_bj_g4_max_band()); `in` / `out` point
+ * at the first of up to four columns of panels with row stride xs. */
+int pa_bj_g4_max_rows(void);
+int pa_bj_g4_max_band(void);
+int pa_k_bj_g4_setup(const int* list, int count, const int* nrows, const int* bw, const long long* off,
+                      const long long* off2, const double* L, double* Lg4);
 /* Band Cholesky on the device for blocks with bandwidth <= pa_bj_factor_wmax(): `band` holds
  * each listed block's rows in factor order, (w+1) doubles per row (A(i, i-d) at d), at offset
  * boff[part]; writes the forward / backward sweep records and 1/L(j,j) straight into Lf, Lb

@@ -29,13 +29,30 @@ int pa_host_threads(void);            /* OpenMP threads worth starting here (cgr
 /* ---- process group ------------------------------------------------------ */
 int pa_world_rank(void);
 int pa_world_size(void);
+int pa_comm_is_loopback(void);
 /* sum a device buffer over the processes (no-op for one process) */
 int pa_allreduce(double* dev_buf, int count);
 int pa_exchange(const double* dev_send, const int* send_counts, double* dev_recv,
                 const int* recv_counts, const int* peers, int npeers);
 
+/* ---- an MPI launcher around us (mpi_glue.c): resolved at run time, MPICH ABI -------------- */
+int pa_mpi_attach(MPI_Comm comm, int* rank, int* size);   /* 1: take rank / size from comm (> 1 ranks) */
+int pa_mpi_active(void);
+const char* pa_mpi_binding(void);                         /* "rccl", "mpi-host-staged", "none" */
+int pa_mpi_bind(void);                                    /* device of this rank + the two hooks; collective */
+int pa_mpi_bcast(void* buf, size_t bytes, int root);      /* waiting ranks sleep between polls */
+int pa_mpi_send(const void* buf, size_t bytes, int dest, int tag);
+int pa_mpi_recv(void* buf, size_t bytes, int src, int tag);
+int pa_mpi_min_int(int* v);
+int pa_mpi_max_int(int* v);
+int pa_mpi_barrier(void);
+int pa_mpi_swap_lists(const int* want, const int* want_cnt, int** asked, int* asked_cnt);
+void pa_mpi_release(void);
+void pa_host_solo(int on);            /* 1: the other ranks of the node sleep: pa_host_threads() = the whole CPU share */
+
 /* ---- phase timing ------------------------------------------------------- */
 enum { PA_T_OPERATOR, PA_T_PRECOND, PA_T_GRAM, PA_T_TRSM, PA_T_UPDATE, PA_T_SMALL, PA_T_COMM, PA_T_COUNT };
+int pa_timing_enabled(void);
 void pa_time_begin(int key);
 double pa_time_end(int key);   /* device seconds of the closed outermost region, else -1 */
 
@@ -83,6 +100,7 @@ int pa_bj_max_bandwidth(void);
 double pa_bj_setup_seconds(int which);   /* 0: ordering + band Cholesky, 1: sweep layouts + upload */
 int pa_bj_nparts(void);
 int pa_bj_nd_blocks(void);
+double pa_bj_g4_bytes(void);        /* bytes of the one-copy records of bj_g4.hip, 0 if absent */
 double pa_bj_pairs_bytes(void);     /* bytes of the paired sweep records (both sweeps), 0 if absent */
 
 #endif

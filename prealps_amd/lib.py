@@ -77,7 +77,7 @@ EXPORTS = [
     "preAlps_hip_timing_reset", "preAlps_hip_get_time",
     "preAlps_hip_partition_kway", "preAlps_hip_rccl_available",
     "preAlps_hip_panel_gram", "preAlps_hip_panel_update", "preAlps_hip_panel_trsm_update",
-    "preAlps_hip_nd_selfcheck",
+    "preAlps_hip_nd_selfcheck", "preAlps_hip_loopback", "preAlps_hip_graphs",
 ]
 
 _lib = None
@@ -146,6 +146,7 @@ def load():
     L.preAlps_hip_nd_selfcheck.argtypes = [C.c_int, pi, pi, pd, C.c_int, pd]
     L.preAlps_hip_partition_kway.argtypes = [C.c_int, pi, pi, C.c_int, pi]
     L.preAlps_hip_timing.restype = None
+    L.preAlps_hip_graphs.restype = None
     L.preAlps_hip_timing_reset.restype = None
     L.preAlps_hip_shutdown.restype = None
     L.preAlps_hip_set_abort_mode.restype = None

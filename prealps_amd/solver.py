@@ -180,10 +180,11 @@ class EcgProblem:
     the library, as in the reference) and solves on them."""
 
     def __init__(self, rowptr, colind, val, nparts, part=None, scale=True, device=None,
-                 distributed=False, use_torch_stream=False, partitioner=False):
+                 distributed=False, use_torch_stream=False, partitioner=False, shard=None):
         """part: explicit partition vector; None = contiguous row blocks, or -- with
         partitioner=True -- the library's k-way graph partitioner (what preAlps_OperatorBuild
-        uses where the reference calls METIS)."""
+        uses where the reference calls METIS).  shard = (r, G): rehearse rank r of a G-process run in
+        this one process (preAlps_hip_loopback)."""
         self.L = L = _l.load()
         import os
         dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
@@ -193,6 +194,9 @@ class EcgProblem:
             import torch
             torch.cuda.set_device(dev)
             self.comm_kind, self.hooks = bind_process_group(L)
+        if shard is not None:
+            check(L.preAlps_hip_loopback(int(shard[0]), int(shard[1])), "preAlps_hip_loopback")
+            self.comm_kind = "loopback %d/%d" % (shard[0], shard[1])
         if use_torch_stream:
             import torch
             check(L.preAlps_hip_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)),

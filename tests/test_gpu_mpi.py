@@ -1,0 +1,107 @@
+"""One MPI rank per GPU, the reference's own mode (examples/test_ecg_prealps_op.c:69,158): drivers
+that only call MPI_Init and hand MPI_COMM_WORLD to preAlps_OperatorBuild.  On the one-GPU box both
+ranks land on the same device, which RCCL refuses, so the library binds its host-staged MPI hooks
+(mpi_glue.c) -- the panel distribution from rank 0, the exchanged send lists, the side-stream halo
+exchange and the all-reduces all run for real; results are compared with the single-process oracle."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import prealps_amd
+from prealps_amd import gen
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MPIEXEC = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+MPI_INC, MPI_LIB = "/opt/conda/include", "/opt/conda/lib"
+have_mpi = os.path.exists(MPIEXEC) and os.path.exists(os.path.join(MPI_INC, "mpi.h"))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "test_ecg_prealps_op_mpi")
+
+
+def _problem(n, nparts):
+    from oracle import oracle as O
+    from prealps_amd.solver import partition_kway
+    rp, ci, v = gen.poisson3d_csr(n)
+    part = partition_kway(rp, ci, nparts)          # what preAlps_OperatorBuild computes for the same file
+    A = sp.csr_matrix((v, ci, rp), shape=(n ** 3, n ** 3))
+    B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, nparts)
+    return (rp, ci, v), B, perm, rowpos
+
+
+def _write_mtx(path, rp, ci, v):
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    keep = rows >= ci
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real symmetric\n%d %d %d\n" % (n, n, keep.sum()))
+        for r, c, x in zip(rows[keep], ci[keep], v[keep]):
+            f.write("%d %d %.17g\n" % (r + 1, c + 1, x))
+
+
+@pytest.mark.skipif(not have_mpi, reason="no MPI launcher in this image")
+@pytest.mark.parametrize("alg,t", [(0, 4), (1, 2)])
+def test_mpi_driver_two_ranks_one_gpu_matches_oracle(tmp_path, alg, t):
+    """examples/ecg_driver.c built against the system MPI: nothing in it but MPI_Init/Finalize and the
+    reference's call sequence; iteration count, residual and the gathered solution against the oracle."""
+    from oracle import oracle as O
+    n, nparts, world = 12, 8, 2
+    (rp, ci, v), B, perm, rowpos = _problem(n, nparts)
+    mtx = str(tmp_path / "a.mtx")
+    _write_mtx(mtx, rp, ci, v)
+    prealps_amd.load()
+    exe = str(tmp_path / "ecg_driver_mpi")
+    subprocess.check_call(["gcc", "-std=gnu11", "-DPREALPS_USE_SYSTEM_MPI", "-I" + MPI_INC, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "ecg_driver.c"), "-L" + os.path.join(ROOT, "prealps_amd"),
+                           "-lprealps_hip", os.path.join(MPI_LIB, "libmpi.so.12"), "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu",
+                           "-Wl,-rpath," + os.path.join(ROOT, "prealps_amd"), "-Wl,-rpath," + MPI_LIB, "-lm", "-o", exe])
+    env = dict(os.environ, PREALPS_NPARTS=str(nparts), PREALPS_SETUP_TRACE="1", OMP_NUM_THREADS="4")
+    r = subprocess.run([MPIEXEC, "-n", str(world), exe, "-m", mtx, "-e", str(t), "-o", str(alg), "-x", str(tmp_path / "sol")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "hooks: mpi-host-staged" in r.stderr          # two ranks on one device: RCCL is not an option
+    it = int(re.search(r"iter: (\d+)", r.stdout).group(1))
+    res = float(re.search(r"res : (\S+)", r.stdout).group(1))
+    ref = O.ECG(B, rowpos, t, ortho_alg=O.ORTHODIR if alg == 0 else O.ORTHOMIN).solve(O.reference_rhs(rowpos))
+    assert it == ref["iters"], (it, ref["iters"])
+    np.testing.assert_allclose(res, ref["final_res"], rtol=2e-6)      # (printed with 7 digits)
+    x = np.concatenate([np.fromfile(str(tmp_path / "sol") + ".%d" % k) for k in range(world)])
+    np.testing.assert_allclose(x, ref["x"], rtol=1e-7, atol=1e-10 * np.abs(ref["x"]).max())
+
+
+@pytest.mark.skipif(not (have_mpi and os.path.exists(REF_BIN)), reason="needs MPI and the prebuilt reference driver (oracle/Makefile)")
+def test_unmodified_reference_driver_two_ranks_one_gpu(tmp_path):
+    """The reference's examples/test_ecg_prealps_op.c, compiled unchanged where the reference tree
+    was present (oracle/_ref/, built by oracle/Makefile) and started with two ranks on this GPU."""
+    from oracle import oracle as O
+    n, nparts, world, t = 12, 8, 2, 4
+    (rp, ci, v), B, perm, rowpos = _problem(n, nparts)
+    mtx = str(tmp_path / "a.mtx")
+    _write_mtx(mtx, rp, ci, v)
+    env = dict(os.environ, PREALPS_NPARTS=str(nparts), PREALPS_SETUP_TRACE="1", OMP_NUM_THREADS="4")
+    r = subprocess.run([MPIEXEC, "-n", str(world), REF_BIN, "-m", mtx, "-e", str(t), "-o", "0", "-r", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    it = int(re.search(r"iter: (\d+)", r.stdout).group(1))
+    res = float(re.search(r"res : (\S+)", r.stdout).group(1))
+    # the driver's rhs (its lines 172-184): every rank draws its m values from srand(0), the norm is
+    # global, element 0 of every rank stays unscaled
+    libc = C.CDLL("libc.so.6")
+    rhs = np.zeros(n ** 3)
+    bounds = [int(rowpos[k * nparts // world]) for k in range(world + 1)]
+    for k in range(world):
+        libc.srand(0)
+        m = bounds[k + 1] - bounds[k]
+        rhs[bounds[k]:bounds[k + 1]] = [libc.rand() / 2147483647.0 for _ in range(m)]
+    normb = np.sqrt((rhs ** 2).sum())
+    for k in range(world):
+        rhs[bounds[k] + 1:bounds[k + 1]] /= normb
+    ref = O.ECG(B, rowpos, t).solve(rhs)
+    assert it == ref["iters"], (it, ref["iters"])
+    np.testing.assert_allclose(res, ref["final_res"], rtol=2e-6)      # (printed with 7 digits)
