@@ -86,7 +86,8 @@ def parse():
                     help="rehearse ONE rank of a G-GPU run on this one GPU (with --shard r): the rank's rows, plan, "
                          "kernels and stream choreography; sums are local, halo rows arrive as zeros")
     ap.add_argument("--shard", type=int, default=0)
-    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel of an iteration (no HIP graphs)")
+    ap.add_argument("--graphs", action="store_true", help="replay the two halves of an iteration from HIP graphs "
+                    "(measured slower than plain launches on ROCm 7.2: off by default)")
     ap.add_argument("--survey-cpu-iters", type=int, default=4,
                     help="CPU baselines at the survey's subdomain count: iterations per port (0 skips them)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -195,8 +196,7 @@ def main():
                                   distributed=distributed, partitioner=(a.nparts > 0),
                                   shard=(a.shard, a.shard_of) if a.shard_of > 1 else None)
     L = prob.L
-    if a.no_graphs:
-        L.preAlps_hip_graphs(0)
+    L.preAlps_hip_graphs(1 if a.graphs else 0)
     prob.create_block_jacobi()
     check(L.preAlps_hip_prepare_operator(a.t), "prepare_operator")   # the SpMM plan is part of the setup
     t_setup = time.perf_counter() - t_setup
@@ -333,7 +333,7 @@ def main():
         "config": {"workload": "%s (N=%d, nnz=%d), ECG %s + block-Jacobi, t=%d, tol 1e-5" % (wname, N, nnz, a.alg, a.t),
                    "nparts": int(nparts), "partition": "library k-way" if a.nparts > 0 else "boxes of %s nodes" % (list(box),),
                    "parallelism": "rows x%d" % world,
-                   "comm": prob.comm_kind, "hip_graphs": not a.no_graphs and os.environ.get("PREALPS_ECG_GRAPH", "1") != "0", "halo_rows_per_rank": halo_rows,
+                   "comm": prob.comm_kind, "hip_graphs": bool(a.graphs), "halo_rows_per_rank": halo_rows,
                    "restarts_in_timed_region": state["restarts"],
                    "iterations_to_converge": state["last_iters"], "setup_seconds": t_setup,
                    "setup_breakdown_s": {k: prob.stat("setup_" + k + "_s") for k in ("build", "plan", "bj_factor", "bj_layout")},

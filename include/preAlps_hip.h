@@ -114,7 +114,7 @@ int preAlps_hip_reference_rhs(double* rhs_local);
 int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol,
                      double* res_hist, int* bs_hist, int max_hist, int* n_hist);
 /* 1 / 0: the two driver loops above and below replay each half of an iteration from a HIP graph
- * captured on its first passes (default: on for one process, PREALPS_ECG_GRAPH overrides). */
+ * captured on its first passes (default: off, or PREALPS_ECG_GRAPH; plain launches measured faster). */
 void preAlps_hip_graphs(int on);
 /* The same loop advanced by nsteps full iterations from the current RCI state,
  * restarting from rhs when the stopping test fires (counts go to the optional

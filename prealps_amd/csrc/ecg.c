@@ -32,8 +32,8 @@
 #define PA_ECG_MAGIC 0x45434731u
 
 /* 1: the driver loops of this library (preAlps_ECGSolve / preAlps_ECGAdvance) replay the launches of
- * an iteration from HIP graphs captured on the first passes (see graph_begin below); -1 = decide from
- * PREALPS_ECG_GRAPH and the process group at the next reset. */
+ * an iteration from HIP graphs captured on the first passes (see seg_begin below); -1 = decide from
+ * PREALPS_ECG_GRAPH (default 0) at the next reset. */
 static int g_graphs = -1;
 void preAlps_hip_graphs(int on) { g_graphs = on; }
 
@@ -185,12 +185,15 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
     pv->lazy_stop = pa_world_size() > 1 && pv->fuse && ecg->bs_red == NO_BS_RED &&
                     ecg->ortho_alg != ORTHODIR_FUSED && ecg->enlFac >= 2 && (f ? atoi(f) : 1);
     pv->lazy_ptr = NULL; }
-  /* graphs: one process (or the one-shard rehearsal of preAlps_hip_loopback, whose sums are free, so
-   * the stopping test need not ride on one); PREALPS_ECG_GRAPH=0 turns them off, =2 forces them for
-   * any process group (the hooks must then be capturable: RCCL is, host-staged ones are not) */
+  /* graphs (opt-in: preAlps_hip_graphs(1) or PREALPS_ECG_GRAPH=1): one process, or the one-shard
+   * rehearsal of preAlps_hip_loopback, whose sums are free, so the stopping test need not ride on one;
+   * =2 forces them for any process group (the hooks must then be capturable: RCCL is, host-staged ones
+   * are not).  Off by default because they measure SLOWER on this stack: 436.5 us per iteration against
+   * 423.2 us with plain launches on the headline problem (same box, 200 iterations each; ROCm 7.2 puts
+   * more idle time between the nodes of a graph than between launches queued on a stream) */
   {
     const char* ge = getenv("PREALPS_ECG_GRAPH");
-    int want = g_graphs >= 0 ? g_graphs : (ge ? atoi(ge) : 1);
+    int want = g_graphs >= 0 ? g_graphs : (ge ? atoi(ge) : 0);
     int group_ok = pa_world_size() == 1 || pa_comm_is_loopback() || want == 2;
     pv->use_graphs = want && group_ok && pv->rotate && pv->fuse && ecg->ortho_alg != ORTHODIR_FUSED &&
                      !pa_timing_enabled();

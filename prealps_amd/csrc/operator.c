@@ -689,8 +689,55 @@ int preAlps_OperatorBuildFromCSR(int N, const int* rowPtr, const int* colInd, co
   return upload_operator(o, t_build0);
 }
 
-/* MatrixMarket coordinate real general|symmetric; 0-based files are detected
- * from the first entry like the reference does; symmetric files are expanded. */
+/* ---- MatrixMarket reader (utils/cplm_light/cplm_matcsr.c:96-243) ----------------------------------
+ * coordinate real general|symmetric; 0-based files are detected from the first entry like the reference
+ * does; symmetric files are expanded; repeated (i, j) entries are summed (in file order).  The file is
+ * mapped and the host threads parse it in line-aligned pieces (an 81 M-nonzero matrix is 1.3 GB of text:
+ * minutes through fscanf, seconds this way); values go through strtod, so they are the doubles
+ * fscanf("%lf") would have produced. */
+typedef struct { int c; double v; } mm_ent_t;
+
+static void mm_sort_row(mm_ent_t* e, int n, mm_ent_t* tmp) {   /* stable, by column */
+  if (n <= 96) {
+    for (int a = 1; a < n; ++a) { mm_ent_t x = e[a]; int q = a; while (q > 0 && e[q - 1].c > x.c) { e[q] = e[q - 1]; --q; } e[q] = x; }
+    return;
+  }
+  int h = n / 2;
+  mm_sort_row(e, h, tmp); mm_sort_row(e + h, n - h, tmp);
+  memcpy(tmp, e, (size_t)h * sizeof(mm_ent_t));
+  int i = 0, j = h, k = 0;
+  while (i < h && j < n) e[k++] = (e[j].c < tmp[i].c) ? e[j++] : tmp[i++];
+  while (i < h) e[k++] = tmp[i++];
+}
+
+/* one "i j v" line starting at p (p < end); returns the position behind the line, NULL on a bad line */
+static const char* mm_parse_line(const char* p, const char* end, int* I, int* J, double* V) {
+  long val[2];
+  for (int f = 0; f < 2; ++f) {
+    while (p < end && (*p == ' ' || *p == '\t')) ++p;
+    int neg = 0;
+    if (p < end && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
+    if (p >= end || *p < '0' || *p > '9') return NULL;
+    long x = 0;
+    while (p < end && *p >= '0' && *p <= '9') { x = 10 * x + (*p - '0'); ++p; }
+    val[f] = neg ? -x : x;
+  }
+  while (p < end && (*p == ' ' || *p == '\t')) ++p;
+  /* the number's characters, NUL terminated for strtod (never reads past the mapping) */
+  char buf[64];
+  int l = 0;
+  while (p + l < end && l < 63 && p[l] != '\n' && p[l] != '\r' && p[l] != ' ' && p[l] != '\t') { buf[l] = p[l]; ++l; }
+  buf[l] = 0;
+  if (l == 0) return NULL;
+  char* stop = NULL;
+  *V = strtod(buf, &stop);
+  if (stop == buf) return NULL;
+  p += l;
+  while (p < end && *p != '\n') ++p;
+  *I = (int)val[0]; *J = (int)val[1];
+  return p < end ? p + 1 : end;
+}
+
 static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, double** v_out) {
   FILE* fd = fopen(file, "r");
   if (!fd) return PA_FAIL("Impossible to open the file %s", file);
@@ -710,46 +757,154 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
     fclose(fd);
     return PA_FAIL("[LoadMatrixMarket] Error: Invalid matrix dimensions in %s", file);
   }
+  long body = ftell(fd);
+  fseek(fd, 0, SEEK_END);
+  long fsize = ftell(fd);
+  if (body < 0 || fsize <= body) { fclose(fd); return PA_FAIL("truncated file %s", file); }
+  const char* map = (const char*)mmap(NULL, (size_t)fsize, PROT_READ, MAP_PRIVATE, fileno(fd), 0);
+  fclose(fd);
+  if (map == MAP_FAILED) return PA_FAIL("cannot map %s", file);
+  (void)madvise((void*)map, (size_t)fsize, MADV_SEQUENTIAL);
+  const char* beg = map + body;
+  const char* end = map + fsize;
+  int T = pa_host_threads();
+  if ((long long)T > nz / 4096 + 1) T = (int)(nz / 4096 + 1);
+  if (T < 1) T = 1;
+  /* pieces that start behind a newline */
+  const char** cut = (const char**)malloc(((size_t)T + 1) * sizeof(char*));
+  long long* first = (long long*)calloc((size_t)T + 1, sizeof(long long));
   int* I = (int*)malloc((size_t)nz * sizeof(int));
   int* J = (int*)malloc((size_t)nz * sizeof(int));
   double* V = (double*)malloc((size_t)nz * sizeof(double));
-  for (long long k = 0; k < nz; ++k)
-    if (fscanf(fd, "%d %d %lf", &I[k], &J[k], &V[k]) != 3) { fclose(fd); free(I); free(J); free(V); return PA_FAIL("bad entry %lld in %s", k, file); }
-  fclose(fd);
-  int base = (I[0] == 0 || J[0] == 0) ? 0 : 1;
-  long long tot = 0;
-  int* cnt = (int*)calloc((size_t)M + 1, sizeof(int));
-  for (long long k = 0; k < nz; ++k) {
-    I[k] -= base; J[k] -= base;
-    if (I[k] < 0 || I[k] >= M || J[k] < 0 || J[k] >= M) { free(I); free(J); free(V); free(cnt); return PA_FAIL("index out of range in %s", file); }
-    cnt[I[k] + 1]++; ++tot;
-    if (is_sym && I[k] != J[k]) { cnt[J[k] + 1]++; ++tot; }
+  if (!cut || !first || !I || !J || !V) { free(cut); free(first); free(I); free(J); free(V); munmap((void*)map, (size_t)fsize); return PA_FAIL("out of host memory for %lld entries", nz); }
+  cut[0] = beg; cut[T] = end;
+  for (int t = 1; t < T; ++t) {
+    const char* p = beg + (size_t)((double)(end - beg) * t / T);
+    if (p < cut[t - 1]) p = cut[t - 1];
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+    cut[t] = nl ? nl + 1 : end;
   }
-  for (int i = 0; i < M; ++i) cnt[i + 1] += cnt[i];
-  int* rp = (int*)malloc(((size_t)M + 1) * sizeof(int));
-  memcpy(rp, cnt, ((size_t)M + 1) * sizeof(int));
-  cv_t* ent = (cv_t*)malloc((size_t)tot * sizeof(cv_t));
-  for (long long k = 0; k < nz; ++k) {
-    ent[cnt[I[k]]].c = J[k]; ent[cnt[I[k]]++].v = V[k];
-    if (is_sym && I[k] != J[k]) { ent[cnt[J[k]]].c = I[k]; ent[cnt[J[k]]++].v = V[k]; }
+  /* lines per piece (blank lines do not count) */
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+  for (int t = 0; t < T; ++t) {
+    long long n = 0;
+    const char* p = cut[t];
+    while (p < cut[t + 1]) {
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(cut[t + 1] - p));
+      const char* le = nl ? nl : cut[t + 1];
+      const char* q = p;
+      while (q < le && (*q == ' ' || *q == '\t' || *q == '\r')) ++q;
+      if (q < le) ++n;
+      p = nl ? nl + 1 : cut[t + 1];
+    }
+    first[t + 1] = n;
   }
-  free(I); free(J); free(V); free(cnt);
-  int* ci = (int*)malloc((size_t)tot * sizeof(int));
-  double* vv = (double*)malloc((size_t)tot * sizeof(double));
-  /* repeated (i, j) entries are legal in coordinate files and mean their sum */
-  long long out = 0;
-  for (int i = 0; i < M; ++i) {
-    int k0 = rp[i], k1 = rp[i + 1];
-    qsort(ent + k0, k1 - k0, sizeof(cv_t), cmp_cv);
-    rp[i] = (int)out;
-    for (int k = k0; k < k1; ++k) {
-      if (k > k0 && ent[k].c == ci[out - 1]) vv[out - 1] += ent[k].v;
-      else { ci[out] = ent[k].c; vv[out] = ent[k].v; ++out; }
+  for (int t = 0; t < T; ++t) first[t + 1] += first[t];
+  int bad = first[T] < nz;     /* (extra lines behind the nz announced are ignored, like fscanf would) */
+  long long bad_line = -1;
+  if (!bad) {
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int t = 0; t < T; ++t) {
+      long long k = first[t];
+      const char* p = cut[t];
+      while (p && p < cut[t + 1] && k < nz) {
+        const char* q = p;
+        while (q < cut[t + 1] && (*q == ' ' || *q == '\t' || *q == '\r')) ++q;
+        if (q < cut[t + 1] && *q == '\n') { p = q + 1; continue; }
+        if (q >= cut[t + 1]) break;
+        p = mm_parse_line(q, cut[t + 1], &I[k], &J[k], &V[k]);
+        if (!p) {
+#pragma omp critical
+          { if (bad_line < 0 || k < bad_line) bad_line = k; }
+          break;
+        }
+        ++k;
+      }
     }
   }
-  rp[M] = (int)out;
-  free(ent);
-  *N_out = M; *rp_out = rp; *ci_out = ci; *v_out = vv;
+  munmap((void*)map, (size_t)fsize);
+  free(cut);
+  if (bad || bad_line >= 0) {
+    long long k = bad ? first[T] : bad_line;
+    free(first); free(I); free(J); free(V);
+    return PA_FAIL("bad entry %lld in %s", k, file);
+  }
+  free(first);
+  int base = (I[0] == 0 || J[0] == 0) ? 0 : 1;
+  /* row histograms per thread (thread t owns entries [t nz / T, (t+1) nz / T)): positions that keep
+   * the file order inside every row, without atomics */
+  int oob = 0;
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(static) reduction(|| : oob)
+  for (long long k = 0; k < nz; ++k) {
+    I[k] -= base; J[k] -= base;
+    if (I[k] < 0 || I[k] >= M || J[k] < 0 || J[k] >= M) oob = 1;
+  }
+  if (oob) { free(I); free(J); free(V); return PA_FAIL("index out of range in %s", file); }
+  int TH = pa_host_threads();
+  while (TH > 1 && (size_t)TH * (size_t)M * sizeof(int) > ((size_t)1 << 30)) TH /= 2;
+  int* hist = (int*)calloc((size_t)TH * (size_t)M, sizeof(int));
+  int* rp = (int*)malloc(((size_t)M + 1) * sizeof(int));
+  if (!hist || !rp) { free(hist); free(rp); free(I); free(J); free(V); return PA_FAIL("out of host memory"); }
+#pragma omp parallel for num_threads(TH) schedule(static, 1)
+  for (int t = 0; t < TH; ++t) {
+    int* h = hist + (size_t)t * M;
+    long long k0 = nz * t / TH, k1 = nz * (t + 1) / TH;
+    for (long long k = k0; k < k1; ++k) { h[I[k]]++; if (is_sym && I[k] != J[k]) h[J[k]]++; }
+  }
+  long long tot = 0;
+  for (int i = 0; i < M; ++i) {
+    rp[i] = (int)tot;
+    for (int t = 0; t < TH; ++t) { int c = hist[(size_t)t * M + i]; hist[(size_t)t * M + i] = (int)tot; tot += c; }
+    if (tot > 2147483000LL) { free(hist); free(rp); free(I); free(J); free(V); return PA_FAIL("%s has too many nonzeros for int32 indices", file); }
+  }
+  rp[M] = (int)tot;
+  mm_ent_t* ent = (mm_ent_t*)big_alloc((size_t)(tot ? tot : 1) * sizeof(mm_ent_t));
+  if (!ent) { free(hist); free(rp); free(I); free(J); free(V); return PA_FAIL("out of host memory for %lld entries", tot); }
+#pragma omp parallel for num_threads(TH) schedule(static, 1)
+  for (int t = 0; t < TH; ++t) {
+    int* h = hist + (size_t)t * M;
+    long long k0 = nz * t / TH, k1 = nz * (t + 1) / TH;
+    for (long long k = k0; k < k1; ++k) {
+      ent[h[I[k]]].c = J[k]; ent[h[I[k]]++].v = V[k];
+      if (is_sym && I[k] != J[k]) { ent[h[J[k]]].c = I[k]; ent[h[J[k]]++].v = V[k]; }
+    }
+  }
+  free(hist); free(I); free(J); free(V);
+  /* sort every row by column (stable), sum repeated entries, compact */
+  int* len = (int*)malloc((size_t)M * sizeof(int));
+  if (!len) { free(ent); free(rp); return PA_FAIL("out of host memory"); }
+#pragma omp parallel num_threads(pa_host_threads())
+  {
+    int cap = 256;
+    mm_ent_t* tmp = (mm_ent_t*)malloc((size_t)cap * sizeof(mm_ent_t));
+#pragma omp for schedule(dynamic, 1024)
+    for (int i = 0; i < M; ++i) {
+      int k0 = rp[i], n = rp[i + 1] - k0;
+      if (n / 2 + 1 > cap) { cap = n; free(tmp); tmp = (mm_ent_t*)malloc((size_t)cap * sizeof(mm_ent_t)); }
+      int sorted = 1;
+      for (int k = 1; k < n && sorted; ++k) sorted = ent[k0 + k - 1].c <= ent[k0 + k].c;
+      if (!sorted && tmp) mm_sort_row(ent + k0, n, tmp);
+      int out = 0;
+      for (int k = 0; k < n; ++k) {
+        if (out > 0 && ent[k0 + k].c == ent[k0 + out - 1].c) ent[k0 + out - 1].v += ent[k0 + k].v;
+        else ent[k0 + out++] = ent[k0 + k];
+      }
+      len[i] = out;
+    }
+    free(tmp);
+  }
+  int* rp2 = (int*)malloc(((size_t)M + 1) * sizeof(int));
+  long long out = 0;
+  for (int i = 0; rp2 && i < M; ++i) { rp2[i] = (int)out; out += len[i]; }
+  int* ci = (int*)big_alloc((size_t)(out ? out : 1) * sizeof(int));
+  double* vv = (double*)big_alloc((size_t)(out ? out : 1) * sizeof(double));
+  if (!rp2 || !ci || !vv) { free(rp2); free(ci); free(vv); free(len); free(ent); free(rp); return PA_FAIL("out of host memory"); }
+  rp2[M] = (int)out;
+#pragma omp parallel for num_threads(pa_host_threads()) schedule(static)
+  for (int i = 0; i < M; ++i)
+    for (int k = 0; k < len[i]; ++k) { ci[rp2[i] + k] = ent[rp[i] + k].c; vv[rp2[i] + k] = ent[rp[i] + k].v; }
+  free(len); free(ent); free(rp);
+  *N_out = M; *rp_out = rp2; *ci_out = ci; *v_out = vv;
   return 0;
 }
 

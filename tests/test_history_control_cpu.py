@@ -1,0 +1,46 @@
+"""The residual histories of two fp64 implementations of the ECG recurrence separate exponentially on
+the elasticity matrices (coefficient jumps of 1e10): tests/test_gpu_configs.py therefore pins only
+the first 20 residuals at 1e-8 there.  This is the control for that choice, without a GPU: the
+C/OpenMP oracle against the reference's own kernels (mkl_dcsrmm + PARDISO, oracle/mkl_path.py) drift
+apart like the HIP path and the oracle do (profiles/r0*_history_divergence.txt, recorded on the GPU
+box by tools/history_probe.py) -- the drift belongs to the recurrence, not to the HIP kernels."""
+import glob
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _recorded_gpu_drift():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_history_divergence.txt")))
+    assert files, "profiles/r0*_history_divergence.txt is missing"
+    for line in open(files[-1]):
+        if line.startswith("30^3 boxes 2x4x8 t=4"):
+            vals = re.search(r"end: ([\d.e+\- ]+)\|", line).group(1).split()
+            return [float(x) for x in vals], os.path.basename(files[-1])
+    raise AssertionError("no 30^3 line in %s" % files[-1])
+
+
+def test_cpu_vs_cpu_drift_matches_the_recorded_gpu_vs_oracle_drift():
+    from oracle import mkl_path as M
+    if M.load_mkl() is None:
+        pytest.skip("libmkl_rt is not on this host")
+    import history_control as H
+    gpu, src = _recorded_gpu_drift()             # rel diff at iterations 1, 5, 10, 20, 40, 80, end (300)
+    case = list(H.cases(30, 100))[1]
+    r = H.control(*case, out=open(os.devnull, "w"))
+    rel = r["rel"]
+    # together to rounding at the start ...
+    assert rel[:10].max() < 1e-12 and max(gpu[:3]) < 1e-12
+    # ... then apart by about a decade every ten iterations, both pairs alike: within a factor 10 of each
+    # other where the growth is still regular (iteration 20), within two decades once it is chaotic
+    for it, g, tol in ((19, gpu[3], 10.0), (39, gpu[4], 100.0), (79, gpu[5], 100.0)):
+        c = max(rel[it], 1e-16)
+        assert g / tol <= c <= g * tol, "iteration %d: CPU-vs-CPU %.1e, GPU-vs-oracle %.1e (%s)" % (it + 1, c, g, src)
+    # and the HIP path is not the outlier: its distance to the oracle stays below 10 x the distance between the CPU paths
+    assert gpu[4] <= 10.0 * rel[39] and gpu[5] <= 10.0 * rel[79]
