@@ -471,12 +471,14 @@ def main():
             # fetched bytes per apply from the committed two-pass PMC run of this configuration
             fetched, fsrc = None, None
             for rnd in (ROUND, "r02"):
-                path = os.path.join(ROOT, "profiles", "%s_nd_apply_pmc.json" % rnd)
+                path = os.path.join(ROOT, "profiles", "%s_nd_apply_pmc.txt" % rnd)
                 if a.workload == "elasticity" and a.n == 70 and a.t == 4 and os.path.exists(path):
-                    with open(path) as f:
-                        fetched = json.load(f).get("fetched_bytes_per_apply")
-                    fsrc = "profiles/%s_nd_apply_pmc.json" % rnd
-                    break
+                    import re
+                    mm = re.search(r"per apply \(\d+ applies\): ([\d.]+) MB", open(path).read())
+                    if mm:
+                        fetched = 1e6 * float(mm.group(1))
+                        fsrc = "profiles/%s_nd_apply_pmc.txt (2 x FETCH_SIZE of every k_nd_* launch, per apply)" % rnd
+                        break
             out["survey_nparts"] = {"nparts": int(np2), "subdomain_box": [edge, edge, edge],
                                     "iterations_per_s": n2 / dt2, "ms_per_step": 1e3 * dt2 / n2, "steps": n2,
                                     "block_solve_us": 1e6 * apply_s, "factor_bytes": fbytes,

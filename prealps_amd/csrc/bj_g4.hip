@@ -23,9 +23,11 @@
 //     block q, column j) IS the B operand of the backward product (contraction over the tile's rows)
 //     and the accumulator of the forward one.  The whole block (up to 16 tiles = 256 rows) lives in
 //     registers between the sweeps: the forward result is never written out.
-//   * The four rows of a group sit in the four 16-lane rows of their tile register (one quad of each);
-//     the substitution moves them with ds_bpermute: once to copy the quad into every quad (the B operand
-//     of the forward product), three times to hand a solved row to the rows that depend on it.
+//   * The four rows of a group sit in the four 16-lane rows of their tile register (one quad of each).
+//     Vector-ALU lane moves (DPP row rotations, v_permlane16_swap / v_permlane32_swap) copy that quad into
+//     every quad and every one of the four rows into all rows; each lane then runs the whole 4 x 4
+//     substitution for its column and keeps the row it stands for: no LDS round trip on the chain from
+//     one group to the next.
 //   * Records are streamed HBM -> LDS by LDS-DMA in chunks of two groups, double buffered per wave,
 //     forward in ascending and backward in descending order; a lane fetches its A-operand entry with
 //     one ds_read_b64 (rows outside the record are clamped onto its all-zero row).
@@ -94,7 +96,7 @@ __device__ __forceinline__ void g4_issue_chunk(const double* __restrict__ rec, i
 // wait until at most `n` of the wave's VMEM operations are outstanding (they complete in order: the
 // youngest n are the LDS-DMA instructions of the chunk that was requested last)
 __device__ __forceinline__ void g4_wait_vm(int n) {
-  switch (n) {
+  switch (n < 15 ? n : 15) {      // (a smaller count than allowed only waits longer)
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
@@ -103,6 +105,13 @@ __device__ __forceinline__ void g4_wait_vm(int n) {
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -115,51 +124,70 @@ __device__ __forceinline__ double row_ror(double v) {
   return __hiloint2double(hi, lo);
 }
 
+typedef double g4_d2 __attribute__((ext_vector_type(2)));
+
 // s_waitcnt lgkmcnt(0) that the compiler sees as the producer of everything read before it
-#define G4_WAIT_1(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a))
-#define G4_WAIT_2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b))
 template <int DQ>
-__device__ __forceinline__ void g4_wait_cf(double (&cf)[DQ], double& c0, double& c1, double& c2, int& plo, int& phi) {
-  if constexpr (DQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]));
-  else if constexpr (DQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]));
-  else if constexpr (DQ == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]));
-  else if constexpr (DQ == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]));
-  else if constexpr (DQ == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]));
-  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo), "+v"(phi), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]), "+v"(cf[7]));
+__device__ __forceinline__ void g4_wait_cf(double (&cf)[DQ], g4_d2& la, g4_d2& lb, double& lc, double& ld) {
+  if constexpr (DQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]));
+  else if constexpr (DQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]));
+  else if constexpr (DQ == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]));
+  else if constexpr (DQ == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]));
+  else if constexpr (DQ == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]), "+v"(cf[7]));
 }
 
-// the value lane `from` (a byte address: 4 * lane) holds, for every lane; issued by hand like the
-// ds_reads (behind an LDS-DMA the compiler would drain all VMEM in front of a DS instruction it emits)
-#ifndef G4_BPERM_ASM
-#define G4_BPERM_ASM 1
-#endif
-__device__ __forceinline__ void g4_bperm_issue(int from, double v, int& plo, int& phi) {
-#if G4_BPERM_ASM
-  // (s_nop: the value permuted was usually written by the instruction just before -- a double-precision
-  // VALU operation or a matrix instruction -- and the hazard recogniser does not look into inline assembly)
-  asm volatile("s_nop 4\n\tds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4"
-               : "=&v"(plo), "=&v"(phi) : "v"(from), "v"(__double2loint(v)), "v"(__double2hiint(v)));
-#else
-  plo = __builtin_amdgcn_ds_bpermute(from, __double2loint(v));
-  phi = __builtin_amdgcn_ds_bpermute(from, __double2hiint(v));
-#endif
+// Lane moves, all in the vector ALU (no LDS round trip on the chain from one group to the next, and all
+// compiler-visible: an earlier version issued ds_bpermute by hand and read stale registers -- the hazard
+// recogniser does not look into inline assembly, and a double-precision result needs wait states before a
+// DS instruction may read it).  Lane = 16 hi + 4 blk + lo (tools/probe/permlane_swap.hip):
+//   DPP row_ror:4n          quad q of every 16-lane row takes quad (q - n) mod 4; bank_mask picks the
+//                           quads that are written
+//   v_permlane16_swap a, b  a' = [a.r0, b.r0, a.r2, b.r2],  b' = [a.r1, b.r1, a.r3, b.r3]   (r = 16-lane rows)
+//   v_permlane32_swap a, b  a' = [a.r0, a.r1, b.r0, b.r1],  b' = [a.r2, a.r3, b.r2, b.r3]
+template <int GQ>
+__device__ __forceinline__ double g4_quad_bcast(double x) {      // quad GQ of every row into all four quads
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  const int slo = lo, shi = hi;
+  lo = __builtin_amdgcn_update_dpp(lo, slo, 0x124, 0xF, 1 << ((GQ + 1) & 3), false);
+  hi = __builtin_amdgcn_update_dpp(hi, shi, 0x124, 0xF, 1 << ((GQ + 1) & 3), false);
+  lo = __builtin_amdgcn_update_dpp(lo, slo, 0x128, 0xF, 1 << ((GQ + 2) & 3), false);
+  hi = __builtin_amdgcn_update_dpp(hi, shi, 0x128, 0xF, 1 << ((GQ + 2) & 3), false);
+  lo = __builtin_amdgcn_update_dpp(lo, slo, 0x12C, 0xF, 1 << ((GQ + 3) & 3), false);
+  hi = __builtin_amdgcn_update_dpp(hi, shi, 0x12C, 0xF, 1 << ((GQ + 3) & 3), false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double g4_bperm(int from, double v) {
-  int plo, phi;
-  g4_bperm_issue(from, v, plo, phi);
-#if G4_BPERM_ASM
-  G4_WAIT_2(plo, phi);
-#endif
-  return __hiloint2double(phi, plo);
+__device__ __forceinline__ void g4_row_bcast(double x, double (&R)[4]) {   // R[k] = row k of x, in every row
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const auto pl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [r0 r0 r2 r2], [r1 r1 r3 r3]
+  const auto ph = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const auto al = __builtin_amdgcn_permlane32_swap(pl[0], pl[0], false, false);   // r0 x 4, r2 x 4
+  const auto ah = __builtin_amdgcn_permlane32_swap(ph[0], ph[0], false, false);
+  const auto bl = __builtin_amdgcn_permlane32_swap(pl[1], pl[1], false, false);   // r1 x 4, r3 x 4
+  const auto bh = __builtin_amdgcn_permlane32_swap(ph[1], ph[1], false, false);
+  R[0] = __hiloint2double((int)ah[0], (int)al[0]);
+  R[2] = __hiloint2double((int)ah[1], (int)al[1]);
+  R[1] = __hiloint2double((int)bh[0], (int)bl[0]);
+  R[3] = __hiloint2double((int)bh[1], (int)bl[1]);
 }
 
 // Per-lane constants of a sweep (lane = 16 hi + 4 blk + lo):
 //   cX     w + 3 - (row of this lane inside a tile as the A operand of this sweep sees it)
 //   aX     byte offset of this lane's pivot column inside a record row
-//   cg     byte offset of this lane's entries of the 4 x 4 corner: forward row hi (its columns 0..2 at
-//          +0, +8, +16), backward column hi (of rows 3, 2, 1 at +96, +64, +32) -- relative to position w
-//   bsrc   4 * lane(hi, block 0, lo);  b16 = 4 * (lane & 15)
-struct g4_lane { int cX; unsigned aX; unsigned cg; int bsrc, b16, blk; };
+struct g4_lane { int cX; unsigned aX; int hi, blk; };
+
+// the six entries of the group's strictly lower 4 x 4 corner (the same for every lane): rows 1, 2, 3 at
+// positions w + 1 .. w + 3 of the record
+__device__ __forceinline__ void g4_corner_issue(unsigned cur, int w, g4_d2& la, g4_d2& lb, double& lc, double& ld) {
+  const unsigned ad = cur + (unsigned)w * 32u;
+  asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(lc) : "v"(ad));      // l10
+  asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(la) : "v"(ad));     // l20 l21
+  asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(lb) : "v"(ad));     // l30 l31
+  asm volatile("ds_read_b64 %0, %1 offset:112" : "=v"(ld) : "v"(ad));     // l32
+}
+__device__ __forceinline__ double g4_pick(int hi, const double (&y)[4]) {
+  return hi == 0 ? y[0] : (hi == 1 ? y[1] : (hi == 2 ? y[2] : y[3]));
+}
 
 // One group of four pivots, forward: Q = tile of the pivots, GQ = their block inside it, `cur` = LDS
 // byte address of the group's record.
@@ -168,21 +196,8 @@ __device__ __forceinline__ void g4_fwd_group(double (&T)[NT], unsigned cur, int 
   // (opaque copy: without it the compiler keeps the clamped index of every (tile offset, group) pair
   // of the unrolled sweeps alive in registers and spills)
   asm volatile("" : "+v"(ln.cX));
-  int plo, phi;
-  // T[Q] was last written by the previous group's matrix instruction, and the DS instruction below is
-  // inline assembly: the compiler's hazard recogniser does not see that it READS that register pair
-  // (a DGEMM 4x4x4 result needs 9 wait states before a memory instruction may read it;
-  // GCNHazardRecognizer: DMFMA4x4WriteVgprMemExpReadWaitStates).  Without the wait the last tile of a
-  // block -- one matrix instruction per group, nothing behind it -- handed stale rows on.
-  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-  g4_bperm_issue(ln.bsrc | (GQ << 4), T[Q], plo, phi);          // the group's quad into every quad
-  double c0, c1, c2;
-  {
-    const unsigned ad = cur + (unsigned)w * 32u + ln.cg;           // row hi of the corner: columns 0, 1, 2
-    asm volatile("ds_read_b64 %0, %1" : "=v"(c0) : "v"(ad));
-    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(c1) : "v"(ad));
-    asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(c2) : "v"(ad));
-  }
+  g4_d2 la, lb; double lc, ld;
+  g4_corner_issue(cur, w, la, lb, lc, ld);
   double cf[DQ];
 #pragma unroll
   for (int dq = 0; dq < DQ; ++dq) {
@@ -193,31 +208,28 @@ __device__ __forceinline__ void g4_fwd_group(double (&T)[NT], unsigned cur, int 
       asm volatile("ds_read_b64 %0, %1" : "=v"(cf[dq]) : "v"(ad));
     }
   }
-  g4_wait_cf<DQ>(cf, c0, c1, c2, plo, phi);
-  double y = __hiloint2double(phi, plo);
-  // y_g = Lt(g, g)^-1 x_g: row k, once final, goes to the rows below it (c_k = 0 on the others)
-  y = fma(-c0, g4_bperm(ln.b16, y), y);
-  y = fma(-c1, g4_bperm(ln.b16 | (1 << 6), y), y);
-  y = fma(-c2, g4_bperm(ln.b16 | (2 << 6), y), y);
-  T[Q] = (ln.blk == GQ) ? y : T[Q];
+  // the group's four rows (quad GQ of the four 16-lane rows of T[Q]) in every quad, then each of
+  // them in every row: all lanes hold x_0 .. x_3 of their column and run the substitution
+  double x[4], y[4];
+  g4_row_bcast(g4_quad_bcast<GQ>(T[Q]), x);
+  g4_wait_cf<DQ>(cf, la, lb, lc, ld);
+  y[0] = x[0];
+  y[1] = fma(-lc, y[0], x[1]);
+  y[2] = fma(-la.y, y[1], fma(-la.x, y[0], x[2]));
+  y[3] = fma(-ld, y[2], fma(-lb.y, y[1], fma(-lb.x, y[0], x[3])));
+  const double yg = g4_pick(ln.hi, y);                  // B operand: row hi of the group in lane (hi, blk, lo)
+  T[Q] = (ln.blk == GQ) ? yg : T[Q];
 #pragma unroll
   for (int dq = 0; dq < DQ; ++dq)
-    if (Q + dq < NT) T[Q + dq] = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], y, T[Q + dq], 0, 0, 0);
+    if (Q + dq < NT) T[Q + dq] = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], yg, T[Q + dq], 0, 0, 0);
 }
 
 // The same group, backward: r = y_g - Lt(below, g)^T z(below), then z_g = Lt(g, g)^-T r.
 template <int NT, int DQ, int Q, int GQ>
 __device__ __forceinline__ void g4_bwd_group(double (&T)[NT], unsigned cur, int w, g4_lane ln) {
   asm volatile("" : "+v"(ln.cX));
-  int plo, phi;
-  g4_bperm_issue(ln.bsrc | (GQ << 4), T[Q], plo, phi);
-  double c3, c2, c1;
-  {
-    const unsigned ad = cur + (unsigned)w * 32u + ln.cg;           // column hi of the corner: rows 3, 2, 1
-    asm volatile("ds_read_b64 %0, %1 offset:96" : "=v"(c3) : "v"(ad));
-    asm volatile("ds_read_b64 %0, %1 offset:64" : "=v"(c2) : "v"(ad));
-    asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(c1) : "v"(ad));
-  }
+  g4_d2 la, lb; double lc, ld;
+  g4_corner_issue(cur, w, la, lb, lc, ld);
   double cf[DQ];
 #pragma unroll
   for (int dq = 0; dq < DQ; ++dq) {
@@ -228,7 +240,8 @@ __device__ __forceinline__ void g4_bwd_group(double (&T)[NT], unsigned cur, int 
       asm volatile("ds_read_b64 %0, %1" : "=v"(cf[dq]) : "v"(ad));
     }
   }
-  g4_wait_cf<DQ>(cf, c3, c2, c1, plo, phi);
+  const double yq = g4_quad_bcast<GQ>(T[Q]);
+  g4_wait_cf<DQ>(cf, la, lb, lc, ld);
   double acc = 0.0;
 #pragma unroll
   for (int dq = 0; dq < DQ; ++dq)
@@ -237,30 +250,32 @@ __device__ __forceinline__ void g4_bwd_group(double (&T)[NT], unsigned cur, int 
   // blocks (rotations by 4 and 8 lanes inside the 16-lane rows)
   acc += row_ror<4>(acc);
   acc += row_ror<8>(acc);
-  double r = __hiloint2double(phi, plo) + acc;
-  r = fma(-c3, g4_bperm(ln.b16 | (3 << 6), r), r);
-  r = fma(-c2, g4_bperm(ln.b16 | (2 << 6), r), r);
-  r = fma(-c1, g4_bperm(ln.b16 | (1 << 6), r), r);
-  T[Q] = (ln.blk == GQ) ? r : T[Q];
+  double r[4], z[4];
+  g4_row_bcast(yq + acc, r);
+  z[3] = r[3];
+  z[2] = fma(-ld, z[3], r[2]);
+  z[1] = fma(-la.y, z[2], fma(-lb.y, z[3], r[1]));
+  z[0] = fma(-lc, z[1], fma(-la.x, z[2], fma(-lb.x, z[3], r[0])));
+  const double zg = g4_pick(ln.hi, z);
+  T[Q] = (ln.blk == GQ) ? zg : T[Q];
 }
 
-// Chunk c (two groups) is in LDS buffer c & 1.  Entering it, the other buffer is free (its chunk was
-// consumed before): the next chunk of the sweep is requested FIRST, then the wave waits for everything
-// but that request -- two chunks are in flight while it waits, which halves the time a lone block
-// spends on memory latency (the blocks of the last, partly filled round run at that speed).
+// The chunks of a sweep (two groups each) go through a ring of `ring` LDS buffers (a power of two, lstride
+// doubles apart), chunk c in buffer c mod ring.  Entering chunk c, the buffer of chunk c - 1 is free: the
+// chunk ring - 1 further on is requested FIRST, then the wave waits for everything but the requests made
+// after chunk c's own -- ring - 1 chunks are in flight while it computes.  What a lone block pays per
+// chunk is then its arithmetic, not the memory latency: it decides how long the blocks of the last,
+// partly filled round take, and everything when a GPU holds fewer blocks than it has SIMDs.
 template <int NT, int DQ, int Q, int H>
 __device__ __forceinline__ void g4_fwd_chunk(double (&T)[NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                             int early) {
+                                             int ring) {
   constexpr int C = 2 * Q + H;
-  if (8 * (C + 1) < b) {
-    if (!(early & 1)) g4_wait_vm(0);
-    g4_issue_chunk(rec, chunk_doubles, C + 1, lds0 + ((C + 1) & 1) * lstride, lane);
-    if (early & 1) g4_wait_vm((chunk_doubles + 127) >> 7);
-  } else {
-    g4_wait_vm(0);
-  }
-  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & 1) * lstride);
+  const int nch = (b + 7) >> 3, nld = (chunk_doubles + 127) >> 7;
+  const int cn = C + ring - 1;
+  if (cn < nch) g4_issue_chunk(rec, chunk_doubles, cn, lds0 + (cn & (ring - 1)) * lstride, lane);
+  g4_wait_vm(min(ring - 1, nch - 1 - C) * nld);
+  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (ring - 1)) * lstride);
   g4_fwd_group<NT, DQ, Q, 2 * H>(T, cur, w, ln);
   g4_fwd_group<NT, DQ, Q, 2 * H + 1>(T, cur + (unsigned)(w + 4) * 32u, w, ln);
   asm volatile("" ::: "memory");
@@ -268,29 +283,32 @@ __device__ __forceinline__ void g4_fwd_chunk(double (&T)[NT], int b, int w, cons
 template <int NT, int DQ, int Q>
 __device__ __forceinline__ void g4_fwd_tiles(double (&T)[NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                             int early) {
+                                             int ring) {
   if constexpr (Q < NT) {
     if (16 * Q < b) {
-      g4_fwd_chunk<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
-      if (16 * Q + 8 < b) g4_fwd_chunk<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
-      g4_fwd_tiles<NT, DQ, Q + 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
+      g4_fwd_chunk<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+      if (16 * Q + 8 < b) g4_fwd_chunk<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+      g4_fwd_tiles<NT, DQ, Q + 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
     }
   }
 }
 
+// Backward: the last `ring` chunks are still where the forward sweep left them; chunk c requests chunk
+// c - (ring - 1) unless that one is among them.
 template <int NT, int DQ, int Q, int H>
 __device__ __forceinline__ void g4_bwd_chunk(double (&T)[NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                             int early) {
+                                             int ring) {
   constexpr int C = 2 * Q + H;
-  if (C > 0 && 8 * (C + 1) < b) {      // (the last two chunks are still where the forward sweep left them)
-    if (!(early & 1)) g4_wait_vm(0);
-    g4_issue_chunk(rec, chunk_doubles, C - 1, lds0 + ((C - 1) & 1) * lstride, lane);
-    if (early & 1) g4_wait_vm((chunk_doubles + 127) >> 7);
-  } else {
-    g4_wait_vm(0);
+  const int nch = (b + 7) >> 3, nld = (chunk_doubles + 127) >> 7;
+  const int cn = C - (ring - 1);
+  if (cn >= 0 && C < nch - 1) g4_issue_chunk(rec, chunk_doubles, cn, lds0 + (cn & (ring - 1)) * lstride, lane);
+  {
+    // chunks requested by this sweep that lie below c: indices max(0, c - ring + 1) .. min(c - 1, nch - ring - 1)
+    const int lo = max(0, C - ring + 1), hi = min(C - 1, nch - ring - 1);
+    g4_wait_vm(max(0, hi - lo + 1) * nld);
   }
-  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & 1) * lstride);
+  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (ring - 1)) * lstride);
   g4_bwd_group<NT, DQ, Q, 2 * H + 1>(T, cur + (unsigned)(w + 4) * 32u, w, ln);
   g4_bwd_group<NT, DQ, Q, 2 * H>(T, cur, w, ln);
   asm volatile("" ::: "memory");
@@ -298,13 +316,13 @@ __device__ __forceinline__ void g4_bwd_chunk(double (&T)[NT], int b, int w, cons
 template <int NT, int DQ, int Q>
 __device__ __forceinline__ void g4_bwd_tiles(double (&T)[NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                             int early) {
+                                             int ring) {
   if constexpr (Q >= 0) {
     if (16 * Q < b) {
-      if (16 * Q + 8 < b) g4_bwd_chunk<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
-      g4_bwd_chunk<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
+      if (16 * Q + 8 < b) g4_bwd_chunk<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+      g4_bwd_chunk<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
     }
-    g4_bwd_tiles<NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, early);
+    g4_bwd_tiles<NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
   }
 }
 
@@ -315,7 +333,7 @@ template <int NT, int DQ, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     const int* __restrict__ list, int count, const int* __restrict__ row0, const int* __restrict__ nrows,
     const int* __restrict__ bw, const long long* __restrict__ off2, const int* __restrict__ map_f,
-    const double* __restrict__ Lg4, const double* __restrict__ invd_f, int lds_per_wave, int xs, int ncol, int early,
+    const double* __restrict__ Lg4, const double* __restrict__ invd_f, int lds_per_wave, int ring, int xs, int ncol,
     const double* __restrict__ in, double* __restrict__ out) {
   extern __shared__ double smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -330,7 +348,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
                    (unsigned)__builtin_amdgcn_readfirstlane((int)o64);
   const double* __restrict__ rec = Lg4 + o;
   double* lds0 = smem + (size_t)wave * lds_per_wave;
-  const int lstride = lds_per_wave >> 1;
+  const int lstride = lds_per_wave / ring;
   const int chunk_doubles = 8 * (w + 4);
   const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
   // tile layout (D / B operand): row 4 blk + hi of the tile, column lo
@@ -339,9 +357,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
   g4_lane lf;
   lf.cX = w + 3 - (4 * blk + lo);
   lf.aX = (unsigned)hi * 8u;
-  lf.cg = (unsigned)hi * 32u;
-  lf.bsrc = (lane & ~12) << 2;                    // byte address of lane (hi, block 0, lo) for ds_bpermute
-  lf.b16 = (lane & 15) << 2;
+  lf.hi = hi;
   lf.blk = blk;
 
   g4_issue_chunk(rec, chunk_doubles, 0, lds0, lane);
@@ -357,8 +373,10 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
 #pragma unroll
     for (int q = 0; q < NT; ++q) T[q] = (16 * q + trow < b && lo < ncol) ? in[rowoff[q]] : 0.0;
   }
+  // the rest of the ring behind the panel loads, so that the newest requests are all chunks
+  for (int c = 1; c < ring - 1 && 8 * c < b; ++c) g4_issue_chunk(rec, chunk_doubles, c, lds0 + c * lstride, lane);
 
-  g4_fwd_tiles<NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, early);
+  g4_fwd_tiles<NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring);
 
   // y = D^-2 a
   {
@@ -371,7 +389,6 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
   }
   // (the last chunk of the forward sweep is the first of the backward one: it is still in its buffer,
   // and so is the one before it -- g4_bwd_chunk does not fetch that one again)
-  if (!(early & 2))      // (PREALPS_BJ_G4_EARLY & 2: debugging aid -- stop after the forward sweep and the scaling)
   {
     int l2 = lane;
     asm volatile("" : "+v"(l2));                   // (recomputed here rather than kept across the forward sweep)
@@ -379,11 +396,9 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     g4_lane lb;
     lb.cX = w + 3 - (4 * blk2 + hi2);
     lb.aX = (unsigned)lo2 * 8u;
-    lb.cg = (unsigned)hi2 * 8u;
-    lb.bsrc = (l2 & ~12) << 2;
-    lb.b16 = (l2 & 15) << 2;
+    lb.hi = hi2;
     lb.blk = blk2;
-    g4_bwd_tiles<NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, early);
+    g4_bwd_tiles<NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring);
   }
 
   {
@@ -413,8 +428,18 @@ int kfail(const char* what) {
 
 template <int NT, int DQ, int OCC>
 int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int xs, int ncol, const double* in, double* out) {
-  const int cbuf = (8 * (wmax + 4) + 127) & ~127;        // doubles, a multiple of 1 KiB
-  const int per_wave = 2 * cbuf;
+  const int cbuf = (8 * (wmax + 4) + 127) & ~127;        // doubles per ring buffer, a multiple of 1 KiB
+  const int nld = cbuf >> 7;
+  // Ring depth.  Many blocks (the chip is filled several wavefronts deep): two buffers, the LDS then
+  // allows six wavefronts per SIMD.  Few blocks (fewer than two per SIMD: a shard of a multi-GPU run):
+  // a lone wavefront cannot hide the memory latency behind other wavefronts, so up to eight chunks in
+  // flight.  PREALPS_BJ_G4_RING overrides (2, 4, 8).
+  static int ring_env = -1;
+  if (ring_env < 0) { const char* e = getenv("PREALPS_BJ_G4_RING"); ring_env = e ? atoi(e) : 0; }
+  const int simds = 4 * (pa_rt_num_cus() > 0 ? pa_rt_num_cus() : 256);
+  int ring = ring_env == 2 || ring_env == 4 || ring_env == 8 ? ring_env : (count < 2 * simds ? 8 : 2);
+  while (ring > 2 && ((ring - 1) * nld > 15 || (size_t)ring * cbuf * 8 > 40 * 1024)) ring >>= 1;
+  const int per_wave = ring * cbuf;
   int waves = (160 * 1024) / (per_wave * 8);
   if (waves > 4) waves = 4;
   if (waves < 1) return 1;
@@ -427,10 +452,8 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
     configured = lds;
   }
   const int blocks = (count + waves - 1) / waves;
-  static int early = -1;
-  if (early < 0) { const char* e = getenv("PREALPS_BJ_G4_EARLY"); early = e ? atoi(e) : 1; }
   PA_LAUNCH((k_bj_g4<NT, DQ, OCC>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
-                     pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, xs, ncol, early, in, out);
+                     pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out);
   return kfail("k_bj_g4");
 }
 

@@ -2420,7 +2420,25 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
                        const double* Xh, double* Y) {
   if (nlist <= 0) return 0;
   if (pl->runs) {
-    // a plan cut for half the panel stride: two workgroups per block, 8 of the 16 columns each
+    // a plan cut for half the panel stride: two workgroups per block, 8 of the 16 columns each;
+    // for the whole stride (pl->runs_cols == TS): one workgroup, the matrix is streamed once
+    if constexpr (TS >= 16) {
+      if (pl->runs_cols == TS) {
+        const size_t lds = (size_t)pl->stage_cap * TS * 8;
+        static size_t configured = 0;
+        if (lds > 64 * 1024 && lds > configured) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TS, TS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return kfail("hipFuncSetAttribute(k_spmm_runs)");
+          configured = lds;
+        }
+        const int cpx = (nlist + 7) / 8;
+        PA_LAUNCH((k_spmm_runs<TS, TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                  pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
+                  pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
+        return kfail("k_spmm_runs");
+      }
+    }
     constexpr int TC = TS >= 16 ? TS / 2 : TS;
     const int ns = TS / TC;
     const size_t lds = (size_t)pl->stage_cap * TC * 8;

@@ -77,6 +77,19 @@ static void* big_alloc(size_t bytes) {
   return p;
 }
 
+/* Rows per SpMM workgroup.  The measured optimum on a full GPU is 256 (192 at 8 columns); a process that
+ * owns few rows (one shard of a multi-GPU run: 130 k rows are 519 such blocks on 256 CUs) gets smaller
+ * blocks, so that every CU has at least four workgroups to hide the staging and streaming latencies. */
+static int env_int(const char* name, int dflt);
+static int spmm_block_rows(int m, int dflt) {
+  const char* e = getenv("PREALPS_SPMM_BLOCK_ROWS");
+  if (e && *e) return atoi(e);
+  int cus = pa_rt_num_cus() > 0 ? pa_rt_num_cus() : 256;
+  int rows = dflt;
+  while (rows > 64 && (long long)m / rows < 4LL * cus) rows -= 64;
+  return rows;
+}
+
 static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return (s && *s) ? atoi(s) : dflt;
@@ -169,7 +182,7 @@ static int build_plan(pa_operator_t* o, int ts) {
     free_plan(o); /* too many rows to stage, or not worth it: use the general kernel */
   }
   int win_cap = env_int("PREALPS_SPMM_WIN_CAP", 256);
-  int blk_rows = env_int("PREALPS_SPMM_BLOCK_ROWS", 256);
+  int blk_rows = spmm_block_rows(m, 256);
   if (blk_rows < 64) blk_rows = 64;
   blk_rows &= ~63;
   int nslices = 0;
@@ -288,7 +301,7 @@ static int build_plan_staged(pa_operator_t* o, int ts) {
   int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", ts <= 4 ? 32768 : 49152) / (ts * 8);
   if (cap_rows > 65535) cap_rows = 65535;
   /* 8-column panels: 192 rows and 48 KiB of staging (three workgroups per CU) measured 7 % faster */
-  int blk_rows = env_int("PREALPS_SPMM_BLOCK_ROWS", ts <= 4 ? 256 : 192);
+  int blk_rows = spmm_block_rows(m, ts <= 4 ? 256 : 192);
   if (blk_rows < 64) blk_rows = 64;
   blk_rows &= ~63;
   if (blk_rows > cap_rows) blk_rows = cap_rows & ~63;
@@ -767,6 +780,7 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
   (void)madvise((void*)map, (size_t)fsize, MADV_SEQUENTIAL);
   const char* beg = map + body;
   const char* end = map + fsize;
+  TRACE_DECL;
   int T = pa_host_threads();
   if ((long long)T > nz / 4096 + 1) T = (int)(nz / 4096 + 1);
   if (T < 1) T = 1;
@@ -800,6 +814,7 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
     first[t + 1] = n;
   }
   for (int t = 0; t < T; ++t) first[t + 1] += first[t];
+  TRACE("  mtx: count lines");
   int bad = first[T] < nz;     /* (extra lines behind the nz announced are ignored, like fscanf would) */
   long long bad_line = -1;
   if (!bad) {
@@ -824,6 +839,7 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
   }
   munmap((void*)map, (size_t)fsize);
   free(cut);
+  TRACE("  mtx: parse");
   if (bad || bad_line >= 0) {
     long long k = bad ? first[T] : bad_line;
     free(first); free(I); free(J); free(V);
@@ -870,6 +886,7 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
     }
   }
   free(hist); free(I); free(J); free(V);
+  TRACE("  mtx: rows (histograms, scatter)");
   /* sort every row by column (stable), sum repeated entries, compact */
   int* len = (int*)malloc((size_t)M * sizeof(int));
   if (!len) { free(ent); free(rp); return PA_FAIL("out of host memory"); }
@@ -904,6 +921,7 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
   for (int i = 0; i < M; ++i)
     for (int k = 0; k < len[i]; ++k) { ci[rp2[i] + k] = ent[rp[i] + k].c; vv[rp2[i] + k] = ent[rp[i] + k].v; }
   free(len); free(ent); free(rp);
+  TRACE("  mtx: sort + compact");
   *N_out = M; *rp_out = rp2; *ci_out = ci; *v_out = vv;
   return 0;
 }
@@ -1078,8 +1096,10 @@ int preAlps_OperatorBuild(const char* matrixFilename, MPI_Comm comm) {
     return build_distributed(matrixFilename, mrank, msize);
   }
   int N = 0; int* rp = NULL; int* ci = NULL; double* v = NULL;
+  TRACE_DECL;
   int rc = load_mtx(matrixFilename, &N, &rp, &ci, &v);
   if (rc) return rc;
+  TRACE("read the matrix");
   int nparts = env_int("PREALPS_NPARTS", pa_world_size());
   int* part = NULL;
   if (choose_partition(N, rp, ci, nparts, &part)) { free(rp); free(ci); free(v); return 1; }
@@ -1280,13 +1300,14 @@ static int build_plan_runs(pa_operator_t* o, int ts) {
   const int* colind = o->lcol;
   const double* val = in->A.val;
   int m = in->m, ncols = m + in->halo;
-  /* panels of 16 columns are handled as two halves of 8 (two workgroups per block, kernels.hip),
-   * so the staging area and the pay-off test are those of stride 8 */
-  if (ts >= 16) ts /= 2;
+  /* panels of 16 columns: one workgroup stages all 16 (PREALPS_SPMM_WIDE16=1, the matrix is then
+   * streamed once), or two workgroups per block take 8 columns each (kernels.hip; staging area and
+   * pay-off test of stride 8) */
+  if (ts >= 16 && !env_int("PREALPS_SPMM_WIDE16", 0)) ts /= 2;
   int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", ts <= 4 ? 32768 : 49152) / (ts * 8) - 2;
   if (cap_rows > 65533) cap_rows = 65533;
   /* 8-column panels: 192 rows and 48 KiB of staging (three workgroups per CU) measured 7 % faster */
-  int blk_rows = env_int("PREALPS_SPMM_BLOCK_ROWS", ts <= 4 ? 256 : 192);
+  int blk_rows = spmm_block_rows(m, ts <= 4 ? 256 : 192);
   if (blk_rows < 64) blk_rows = 64;
   blk_rows &= ~63;
   if (blk_rows > cap_rows) blk_rows = cap_rows & ~63;
@@ -1449,7 +1470,7 @@ static int build_plan_runs(pa_operator_t* o, int ts) {
       pl->m = m; pl->nslices = nslices; pl->sl_off = o->d_sl_off; pl->sl_len = o->d_sl_len;
       pl->sl_row0 = o->d_sl_row0; pl->sl_nrows = o->d_sl_nrows; pl->val = o->d_val;
       pl->nblk = nblk; pl->blk_slice = o->d_blk_slice; pl->order = o->d_order; pl->n_interior = ni;
-      pl->staged = 1; pl->runs = 1; pl->col16 = o->d_col16; pl->blk_ext_off = o->d_blk_ext_off;
+      pl->staged = 1; pl->runs = 1; pl->runs_cols = ts; pl->col16 = o->d_col16; pl->blk_ext_off = o->d_blk_ext_off;
       pl->blk_nlow = o->d_blk_nlow; pl->ext_rows = o->d_ext_rows;
       pl->stage_cap = max_stage;
       o->sell_entries = 3.0 * (double)nruns;

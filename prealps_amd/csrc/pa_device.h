@@ -91,6 +91,8 @@ typedef struct {
    * two zero rows], blk_nlow = how many of a block's external rows lie below its own range. */
   int runs;
   const int* blk_nlow;
+  int runs_cols;            /* columns a workgroup of the run plan stages and computes (= the panel stride, or 8
+                             * when a 16-column panel is split between two workgroups) */
 } pa_spmm_plan_t;
 /* phase 0: interior blocks, 1: halo-reading blocks, 2: all */
 int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo,

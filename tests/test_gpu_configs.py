@@ -284,6 +284,57 @@ def test_block_solve_dispatch_by_band(n, t, lo, hi, wide_from, monkeypatch):
         prob.close()
 
 
+# ---- the one-copy matrix-core band solve (bj_g4.hip) and the kernels it replaced ---------------------------
+def _boxes_problem(n, box, t, seed):
+    from prealps_amd import gen
+    rp, ci, v = gen.poisson3d_csr(n)
+    part, P = gen.box_partition(n, box)
+    A = sp.csr_matrix((v, ci, rp), shape=(n ** 3, n ** 3))
+    prob, B, rowpos = _problem(A, P, part)
+    X = np.random.default_rng(seed).standard_normal((n ** 3, t))
+    return prob, B, rowpos, X
+
+
+@pytest.mark.parametrize("g4", ["1", "0"])
+@pytest.mark.parametrize("n,box,t", [(20, (5, 5, 10), 4), (24, (4, 4, 12), 4), (12, (6, 6, 6), 4), (24, (6, 4, 8), 3),
+                                     (24, (8, 3, 8), 2), (24, (8, 8, 3), 1), (21, (7, 7, 3), 4), (20, (5, 5, 2), 4),
+                                     (18, (9, 9, 3), 4), (20, (10, 10, 2), 4)])
+def test_band_solve_for_up_to_four_columns(n, box, t, g4, monkeypatch):
+    """Panels of up to 4 columns on blocks of up to 256 rows with bands up to 112: ONE copy of the band for
+    both sweeps on the f64 matrix cores (bj_g4.hip: 12 / 14 / 16 register tiles, 3 .. 8 tiles under a group's
+    record; blocks that fill their last tile, rows that are no multiple of 4 or 8, panel strides 2 and 4,
+    fewer columns than the stride) -- and, with PREALPS_BJ_G4=0, the register recurrence on two copies that
+    it replaced (k_bj_apply_pairs / k_bj_apply).  Both against the oracle's exact block solve."""
+    monkeypatch.setenv("PREALPS_BJ_G4", g4)
+    monkeypatch.setenv("PREALPS_BJ_WIDE_FROM", "448")
+    from oracle import oracle as O
+    prob, B, rowpos, X = _boxes_problem(n, box, t, n + t)
+    try:
+        zr = O.BlockJacobi(B, rowpos).apply(X)
+        got = prob.block_jacobi_apply(X, t)
+        np.testing.assert_allclose(got, zr, rtol=1e-11, atol=1e-12 * np.abs(zr).max())
+        assert (prob.stat("bj_g4_bytes") > 0) == (g4 == "1")
+        # several applies in a row give the same bits (no race between the prefetch ring and the sweeps)
+        again = prob.block_jacobi_apply(X, t)
+        np.testing.assert_array_equal(got, again)
+    finally:
+        prob.close()
+
+
+@pytest.mark.parametrize("ring", ["2", "4", "8"])
+def test_band_solve_prefetch_ring_depths(ring, monkeypatch):
+    """The prefetch ring of bj_g4.hip at every depth (few blocks get 8 buffers by default, many get 2)."""
+    monkeypatch.setenv("PREALPS_BJ_G4_RING", ring)
+    from oracle import oracle as O
+    for n, box in ((20, (5, 5, 10)), (24, (4, 4, 12)), (16, (4, 4, 8))):
+        prob, B, rowpos, X = _boxes_problem(n, box, 4, 7)
+        try:
+            zr = O.BlockJacobi(B, rowpos).apply(X)
+            np.testing.assert_allclose(prob.block_jacobi_apply(X, 4), zr, rtol=1e-11, atol=1e-12 * np.abs(zr).max())
+        finally:
+            prob.close()
+
+
 # ---- large blocks: sparse (nested dissection) factor against the band factor and the oracle -----------
 @pytest.mark.parametrize("variant", ["device", "host", "chains"])
 @pytest.mark.parametrize("t", [1, 4, 8, 16])

@@ -29,7 +29,7 @@ def find(d, pattern):
 
 # 1. kernel statistics: copy the rocprofv3 summary as it is (names shortened)
 rows = list(csv.reader(open(find("prof_stats", "*kernel_stats.csv"))))
-dst = os.path.join(root, "profiles", "r02_bench_%s_kernel_stats.csv" % workload)
+dst = os.path.join(root, "profiles", "r03_bench_%s_kernel_stats.csv" % workload)
 with open(dst, "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(rows[0])
@@ -68,11 +68,12 @@ doc = {
                    "compare their rows below with those byte counts",
     "k_spmm": summary[spmm[0]] if spmm else None,
     "k_spmm_name": spmm[0] if spmm else None,
+    "k_bj": next((dict(summary[k], name=k) for k in summary if k.startswith("k_bj_g4<") or k.startswith("k_bj_apply")), None),
     "per_kernel": summary,
     "raw": raw,
     "bench_line_of_the_profiled_run": bench,
 }
-dst = os.path.join(root, "profiles", "r02_pmc_hbm_traffic_%s.json" % workload)
+dst = os.path.join(root, "profiles", "r03_pmc_hbm_traffic_%s.json" % workload)
 with open(dst, "w") as f:
     json.dump(doc, f, indent=1)
 print("wrote", dst)
