@@ -307,7 +307,7 @@ def main():
     # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/): the
     # counters cannot be read from inside the process, so the committed summary is quoted when
     # the workload is the one it was collected on.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, bj_traffic = None, None, None
     profiled = {("elasticity", 70, 4, "2,4,8"): "pmc_hbm_traffic_elasticity.json",
                 ("poisson", 100, 4, "5,5,10"): "pmc_hbm_traffic_poisson.json"}
     pmc = profiled.get((a.workload, a.n, a.t, a.box)) if a.nparts == 0 else None
@@ -316,7 +316,9 @@ def main():
             path = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, pmc))
             if os.path.exists(path):
                 with open(path) as f:
-                    traffic = json.load(f)["k_spmm"]["traffic_bytes_per_launch"]
+                    pmc_doc = json.load(f)
+                traffic = pmc_doc["k_spmm"]["traffic_bytes_per_launch"]
+                bj_traffic = (pmc_doc.get("k_bj") or {}).get("traffic_bytes_per_launch")
                 traffic_src = "profiles/%s_%s (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)" % (rnd, pmc)
                 break
     halo_rows = [halo]
@@ -347,13 +349,16 @@ def main():
                      "frac_of_measured_read_ceiling": spmm_gbs / read_gbs.value,
                      "note": "each timed launch follows one preconditioner apply (cache state of the solver loop)"},
         "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "factor_bytes": prob.stat("bj_factor_bytes"),
+                         "traffic": bj_traffic, "frac": bj_bytes / bj_s / 1e9 / HBM_PEAK_GBS,
                          "achieved_GBs": bj_bytes / bj_s / 1e9,
-                         # panels of up to 4 columns read ONE copy of the band for both sweeps (bj_g4.hip), or the
-                         # paired copy of both sweeps' records where that kernel does not apply
-                         "streamed_record_bytes": (prob.stat("bj_g4_bytes") if a.t <= 4 and prob.stat("bj_g4_bytes") > 0 else
+                         # panels of up to 4 columns: ONE stored copy of the band (bj_g4.hip), streamed once by each of
+                         # the two sweeps; else the paired copy of both sweeps' records, or the plain two copies
+                         "streamed_record_bytes": (2.0 * prob.stat("bj_g4_bytes") if a.t <= 4 and prob.stat("bj_g4_bytes") > 0 else
                                                    prob.stat("bj_pairs_bytes") if a.t <= 4 and prob.stat("bj_pairs_bytes") > 0
                                                    else prob.stat("bj_factor_bytes")),
-                         "streamed_GBs": ((prob.stat("bj_g4_bytes") if a.t <= 4 and prob.stat("bj_g4_bytes") > 0 else
+                         "stored_record_bytes": (prob.stat("bj_g4_bytes") if a.t <= 4 and prob.stat("bj_g4_bytes") > 0 else
+                                                 prob.stat("bj_factor_bytes")),
+                         "streamed_GBs": ((2.0 * prob.stat("bj_g4_bytes") if a.t <= 4 and prob.stat("bj_g4_bytes") > 0 else
                                            prob.stat("bj_factor_bytes")) + 16.0 * m_loc * a.t) / bj_s / 1e9,
                          "note": "achieved_GBs counts the plain two-sweep factor of SURVEY 8(d) (algorithmic bytes) + the "
                                  "panels; streamed_GBs what the kernel really reads and writes"},

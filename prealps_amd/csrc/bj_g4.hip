@@ -11,7 +11,7 @@
 //     below it, Lt(4g+4 .. 4g+3+w, g): the plain band entries, (w + 4) rows x 4 pivots.
 //     Forward:  y_g = Lt(g, g)^-1 x_g by substitution (three steps), then x(below) -= Lt(below, g) y_g;
 //     backward: r = y_g - Lt(below, g)^T z(below), then z_g = Lt(g, g)^-T r by substitution:
-//     the exact transpose, from the same record -- 8 N (w + 4) bytes for BOTH sweeps instead of
+//     the exact transpose, from the same record -- 8 N (w + 4) bytes stored for BOTH sweeps instead of
 //     16 N (w + 1).  Same arithmetic as the classic sweeps, other summation order.
 //     (A first version stored the group in selective-inversion form, [Lt(g,g)^-1 - I ; -Lt(below,g)
 //     Lt(g,g)^-1], which needs no substitution at all; on the elasticity matrix, whose scaled factors
@@ -32,7 +32,8 @@
 //     forward in ascending and backward in descending order; a lane fetches its A-operand entry with
 //     one ds_read_b64 (rows outside the record are clamped onto its all-zero row).
 //
-// HBM bytes per apply: 8 N (w + 4) + 16 N t.
+// Stored: 8 N (w + 4) bytes.  HBM bytes per apply: each sweep streams them once, 16 N (w + 4) + 16 N t
+// (measured: 705.6 MB on the headline problem, 5.85 TB/s = 0.93 of the device's read ceiling).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -185,8 +186,12 @@ __device__ __forceinline__ void g4_corner_issue(unsigned cur, int w, g4_d2& la, 
   asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(lb) : "v"(ad));     // l30 l31
   asm volatile("ds_read_b64 %0, %1 offset:112" : "=v"(ld) : "v"(ad));     // l32
 }
-__device__ __forceinline__ double g4_pick(int hi, const double (&y)[4]) {
-  return hi == 0 ? y[0] : (hi == 1 ? y[1] : (hi == 2 ? y[2] : y[3]));
+// the row this lane stands for.  (The values are made opaque first: otherwise the compiler sinks the
+// substitution chains into divergent branches, one per row, instead of four selects.)
+__device__ __forceinline__ double g4_pick(int hi, double (&y)[4]) {
+  asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+  const double a = hi == 0 ? y[0] : y[1], b = hi == 2 ? y[2] : y[3];
+  return hi < 2 ? a : b;
 }
 
 // One group of four pivots, forward: Q = tile of the pivots, GQ = their block inside it, `cur` = LDS
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
                    (unsigned)__builtin_amdgcn_readfirstlane((int)o64);
   const double* __restrict__ rec = Lg4 + o;
   double* lds0 = smem + (size_t)wave * lds_per_wave;
-  const int lstride = lds_per_wave / ring;
+  const int lstride = ((lds_per_wave / ring) >> 7) << 7;      // (whole KiB: the launcher may pad lds_per_wave)
   const int chunk_doubles = 8 * (w + 4);
   const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
   // tile layout (D / B operand): row 4 blk + hi of the tile, column lo
@@ -439,7 +444,11 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
   const int simds = 4 * (pa_rt_num_cus() > 0 ? pa_rt_num_cus() : 256);
   int ring = ring_env == 2 || ring_env == 4 || ring_env == 8 ? ring_env : (count < 2 * simds ? 8 : 2);
   while (ring > 2 && ((ring - 1) * nld > 15 || (size_t)ring * cbuf * 8 > 40 * 1024)) ring >>= 1;
-  const int per_wave = ring * cbuf;
+  // PREALPS_BJ_G4_LDSPAD = extra KiB of LDS per wavefront: lowers the number of resident blocks (an
+  // experiment: fewer blocks in flight keep the records of a block in the Infinity Cache between its sweeps)
+  static int pad_kib = -1;
+  if (pad_kib < 0) { const char* e = getenv("PREALPS_BJ_G4_LDSPAD"); pad_kib = e ? atoi(e) : 0; }
+  const int per_wave = ring * cbuf + pad_kib * 128;
   int waves = (160 * 1024) / (per_wave * 8);
   if (waves > 4) waves = 4;
   if (waves < 1) return 1;

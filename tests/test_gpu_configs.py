@@ -228,6 +228,36 @@ def test_config4_elasticity_t16_odir():
         prob.close()
 
 
+def test_unstructured_matrix_at_sixteen_columns():
+    """BASELINE configs[4]'s class (Queen_4147: unstructured, t = 16) at a size the oracle solves: the
+    unstructured 3-dof SPD matrix of the configs[2] test through the library's partitioner with 16 search
+    directions -- the 16-column SpMM (two 8-column halves of the run plan, or L2 gathers where rows do not
+    come in runs), the matrix-core Gram / update / trsm kernels and the 16-column block solve."""
+    import prealps_amd as pa
+    from prealps_amd.solver import partition_kway
+    from oracle import oracle as O
+    A = _unstructured_spd(3000, 9)
+    N, P, t = A.shape[0], 48, 16
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    part = partition_kway(A.indptr.astype(np.int32), A.indices.astype(np.int32), P)
+    prob, B, rowpos = _problem(A, P, part)
+    try:
+        X = np.random.default_rng(16).standard_normal((N, t))
+        ref = O.spmm(B, X)
+        np.testing.assert_allclose(prob.block_operator(X, t), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+        zr = O.BlockJacobi(B, rowpos).apply(X)
+        np.testing.assert_allclose(prob.block_jacobi_apply(X, t), zr, rtol=1e-9, atol=1e-10 * np.abs(zr).max())
+        rhs = prob.reference_rhs()
+        got = prob.solve(rhs, t, max_iter=1000)
+        refs = O.ECG(B, rowpos, t, max_iter=1000).solve(rhs)
+        assert got.iters == refs["iters"] and got.iters < 1000
+        np.testing.assert_allclose(got.res, refs["res"], rtol=1e-7)
+        np.testing.assert_allclose(got.x, refs["x"], rtol=1e-6, atol=1e-8 * np.abs(refs["x"]).max())
+    finally:
+        prob.close()
+
+
 # ---- the headline workload at full size: first iterations against the oracle -----------------------------
 @pytest.mark.parametrize("factor", ["device", "host"])
 def test_full_size_first_residuals_vs_oracle(factor, monkeypatch):

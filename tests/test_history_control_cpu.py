@@ -38,9 +38,12 @@ def test_cpu_vs_cpu_drift_matches_the_recorded_gpu_vs_oracle_drift():
     # together to rounding at the start ...
     assert rel[:10].max() < 1e-12 and max(gpu[:3]) < 1e-12
     # ... then apart by about a decade every ten iterations, both pairs alike: within a factor 10 of each
-    # other where the growth is still regular (iteration 20), within two decades once it is chaotic
-    for it, g, tol in ((19, gpu[3], 10.0), (39, gpu[4], 100.0), (79, gpu[5], 100.0)):
+    # other where the growth is still regular (iteration 20), within two decades at 40; by 80 both have
+    # saturated at a few per cent (chaotic: no finer statement holds there)
+    for it, g, tol in ((19, gpu[3], 10.0), (39, gpu[4], 100.0)):
         c = max(rel[it], 1e-16)
         assert g / tol <= c <= g * tol, "iteration %d: CPU-vs-CPU %.1e, GPU-vs-oracle %.1e (%s)" % (it + 1, c, g, src)
-    # and the HIP path is not the outlier: its distance to the oracle stays below 10 x the distance between the CPU paths
-    assert gpu[4] <= 10.0 * rel[39] and gpu[5] <= 10.0 * rel[79]
+    assert 1e-4 < rel[79] < 0.5 and 1e-4 < gpu[5] < 0.5
+    # and the HIP path is not the outlier while the growth is regular: its distance to the oracle stays
+    # below 10 x the distance between the two CPU paths
+    assert gpu[3] <= 10.0 * max(rel[19], 1e-13) and gpu[4] <= 10.0 * rel[39]

@@ -25,7 +25,13 @@ pd.DataFrame({"i": rows[keep] + 1, "j": ci[keep].astype(np.int64) + 1, "v": v[ke
     mtx, sep=" ", header=False, index=False, float_format="%.17g", mode="a")
 np.savetxt(pf, part, fmt="%d")
 print("wrote %s: %.2f GB, %d entries, %.0f s" % (mtx, os.path.getsize(mtx) / 1e9, int(keep.sum()), time.time() - t0), flush=True)
-# in-memory build
+# in-memory build of the matrix the FILE describes: the lower triangle mirrored (the assembled values differ
+# from their transposes in the last bit, and on this matrix that is enough to move the iteration count)
+import scipy.sparse as sp
+Lw = sp.tril(sp.csr_matrix((v, ci, rp), shape=(N, N)), 0, format="csr")
+As = (Lw + sp.tril(Lw, -1).T).tocsr()
+As.sort_indices()
+rp, ci, v = As.indptr.astype(np.int32), As.indices.astype(np.int32), As.data.copy()
 prob = pa.EcgProblem(rp, ci, v, P, part, scale=True, device=0)
 r0 = prob.solve(prob.reference_rhs(), 4, max_iter=3000)
 prob.close()
