@@ -80,8 +80,10 @@ def parse():
     ap.add_argument("--nparts", type=int, default=0,
                     help="number of subdomains from the library's own graph partitioner instead of --box")
     ap.add_argument("--alg", type=str, default="auto", choices=["auto", "odir", "omin", "fused"],
-                    help="auto: Orthodir on one GPU; with several, the one-collective fused Orthodir of "
-                         "examples/test_ecg_bench_fused.c (one all-reduce per iteration instead of two)")
+                    help="auto = odir for any number of GPUs.  (The one-collective fused Orthodir of "
+                         "examples/test_ecg_bench_fused.c saves an all-reduce per iteration but costs 42-48 us more "
+                         "device time per iteration on a 1/8 shard -- profiles/r03_shard8_*.json -- which is more than "
+                         "a small all-reduce takes.)")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="rehearse ONE rank of a G-GPU run on this one GPU (with --shard r): the rank's rows, plan, "
                          "kernels and stream choreography; sums are local, halo rows arrive as zeros")
@@ -149,7 +151,7 @@ def main():
     if a.shard_of and (a.gpus != 1 or not (0 <= a.shard < a.shard_of)):
         raise SystemExit("--shard-of G needs --gpus 1 and 0 <= --shard < G")
     if a.alg == "auto":
-        a.alg = "fused" if (a.gpus > 1 or a.shard_of > 1) else "odir"
+        a.alg = "odir"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

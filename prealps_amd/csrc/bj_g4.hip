@@ -195,9 +195,10 @@ __device__ __forceinline__ double g4_pick(int hi, double (&y)[4]) {
 }
 
 // One group of four pivots, forward: Q = tile of the pivots, GQ = their block inside it, `cur` = LDS
-// byte address of the group's record.
-template <int NT, int DQ, int Q, int GQ>
-__device__ __forceinline__ void g4_fwd_group(double (&T)[NT], unsigned cur, int w, g4_lane ln) {
+// byte address of the group's record.  NC = sets of four panel columns the wavefront carries (1, or 2
+// for 8-column panels: the record is read once for both), set c in T[c * NT ..].
+template <int NC, int NT, int DQ, int Q, int GQ>
+__device__ __forceinline__ void g4_fwd_group(double (&T)[NC * NT], unsigned cur, int w, g4_lane ln) {
   // (opaque copy: without it the compiler keeps the clamped index of every (tile offset, group) pair
   // of the unrolled sweeps alive in registers and spills)
   asm volatile("" : "+v"(ln.cX));
@@ -215,23 +216,28 @@ __device__ __forceinline__ void g4_fwd_group(double (&T)[NT], unsigned cur, int 
   }
   // the group's four rows (quad GQ of the four 16-lane rows of T[Q]) in every quad, then each of
   // them in every row: all lanes hold x_0 .. x_3 of their column and run the substitution
-  double x[4], y[4];
-  g4_row_bcast(g4_quad_bcast<GQ>(T[Q]), x);
-  g4_wait_cf<DQ>(cf, la, lb, lc, ld);
-  y[0] = x[0];
-  y[1] = fma(-lc, y[0], x[1]);
-  y[2] = fma(-la.y, y[1], fma(-la.x, y[0], x[2]));
-  y[3] = fma(-ld, y[2], fma(-lb.y, y[1], fma(-lb.x, y[0], x[3])));
-  const double yg = g4_pick(ln.hi, y);                  // B operand: row hi of the group in lane (hi, blk, lo)
-  T[Q] = (ln.blk == GQ) ? yg : T[Q];
+  double x[NC][4];
 #pragma unroll
-  for (int dq = 0; dq < DQ; ++dq)
-    if (Q + dq < NT) T[Q + dq] = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], yg, T[Q + dq], 0, 0, 0);
+  for (int c = 0; c < NC; ++c) g4_row_bcast(g4_quad_bcast<GQ>(T[c * NT + Q]), x[c]);
+  g4_wait_cf<DQ>(cf, la, lb, lc, ld);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    double y[4];
+    y[0] = x[c][0];
+    y[1] = fma(-lc, y[0], x[c][1]);
+    y[2] = fma(-la.y, y[1], fma(-la.x, y[0], x[c][2]));
+    y[3] = fma(-ld, y[2], fma(-lb.y, y[1], fma(-lb.x, y[0], x[c][3])));
+    const double yg = g4_pick(ln.hi, y);                // B operand: row hi of the group in lane (hi, blk, lo)
+    T[c * NT + Q] = (ln.blk == GQ) ? yg : T[c * NT + Q];
+#pragma unroll
+    for (int dq = 0; dq < DQ; ++dq)
+      if (Q + dq < NT) T[c * NT + Q + dq] = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], yg, T[c * NT + Q + dq], 0, 0, 0);
+  }
 }
 
 // The same group, backward: r = y_g - Lt(below, g)^T z(below), then z_g = Lt(g, g)^-T r.
-template <int NT, int DQ, int Q, int GQ>
-__device__ __forceinline__ void g4_bwd_group(double (&T)[NT], unsigned cur, int w, g4_lane ln) {
+template <int NC, int NT, int DQ, int Q, int GQ>
+__device__ __forceinline__ void g4_bwd_group(double (&T)[NC * NT], unsigned cur, int w, g4_lane ln) {
   asm volatile("" : "+v"(ln.cX));
   g4_d2 la, lb; double lc, ld;
   g4_corner_issue(cur, w, la, lb, lc, ld);
@@ -245,24 +251,29 @@ __device__ __forceinline__ void g4_bwd_group(double (&T)[NT], unsigned cur, int 
       asm volatile("ds_read_b64 %0, %1" : "=v"(cf[dq]) : "v"(ad));
     }
   }
-  const double yq = g4_quad_bcast<GQ>(T[Q]);
-  g4_wait_cf<DQ>(cf, la, lb, lc, ld);
-  double acc = 0.0;
+  double yq[NC];
 #pragma unroll
-  for (int dq = 0; dq < DQ; ++dq)
-    if (Q + dq < NT) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], T[Q + dq], acc, 0, 0, 0);
-  // every block of the accumulator holds the sum over ITS four rows of each tile: add the four
-  // blocks (rotations by 4 and 8 lanes inside the 16-lane rows)
-  acc += row_ror<4>(acc);
-  acc += row_ror<8>(acc);
-  double r[4], z[4];
-  g4_row_bcast(yq + acc, r);
-  z[3] = r[3];
-  z[2] = fma(-ld, z[3], r[2]);
-  z[1] = fma(-la.y, z[2], fma(-lb.y, z[3], r[1]));
-  z[0] = fma(-lc, z[1], fma(-la.x, z[2], fma(-lb.x, z[3], r[0])));
-  const double zg = g4_pick(ln.hi, z);
-  T[Q] = (ln.blk == GQ) ? zg : T[Q];
+  for (int c = 0; c < NC; ++c) yq[c] = g4_quad_bcast<GQ>(T[c * NT + Q]);
+  g4_wait_cf<DQ>(cf, la, lb, lc, ld);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    double acc = 0.0;
+#pragma unroll
+    for (int dq = 0; dq < DQ; ++dq)
+      if (Q + dq < NT) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], T[c * NT + Q + dq], acc, 0, 0, 0);
+    // every block of the accumulator holds the sum over ITS four rows of each tile: add the four
+    // blocks (rotations by 4 and 8 lanes inside the 16-lane rows)
+    acc += row_ror<4>(acc);
+    acc += row_ror<8>(acc);
+    double r[4], z[4];
+    g4_row_bcast(yq[c] + acc, r);
+    z[3] = r[3];
+    z[2] = fma(-ld, z[3], r[2]);
+    z[1] = fma(-la.y, z[2], fma(-lb.y, z[3], r[1]));
+    z[0] = fma(-lc, z[1], fma(-la.x, z[2], fma(-lb.x, z[3], r[0])));
+    const double zg = g4_pick(ln.hi, z);
+    T[c * NT + Q] = (ln.blk == GQ) ? zg : T[c * NT + Q];
+  }
 }
 
 // The chunks of a sweep (two groups each) go through a ring of `ring` LDS buffers (a power of two, lstride
@@ -271,8 +282,8 @@ __device__ __forceinline__ void g4_bwd_group(double (&T)[NT], unsigned cur, int 
 // after chunk c's own -- ring - 1 chunks are in flight while it computes.  What a lone block pays per
 // chunk is then its arithmetic, not the memory latency: it decides how long the blocks of the last,
 // partly filled round take, and everything when a GPU holds fewer blocks than it has SIMDs.
-template <int NT, int DQ, int Q, int H>
-__device__ __forceinline__ void g4_fwd_chunk(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+template <int NC, int NT, int DQ, int Q, int H>
+__device__ __forceinline__ void g4_fwd_chunk(double (&T)[NC * NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
                                              int ring) {
   constexpr int C = 2 * Q + H;
@@ -281,27 +292,27 @@ __device__ __forceinline__ void g4_fwd_chunk(double (&T)[NT], int b, int w, cons
   if (cn < nch) g4_issue_chunk(rec, chunk_doubles, cn, lds0 + (cn & (ring - 1)) * lstride, lane);
   g4_wait_vm(min(ring - 1, nch - 1 - C) * nld);
   const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (ring - 1)) * lstride);
-  g4_fwd_group<NT, DQ, Q, 2 * H>(T, cur, w, ln);
-  g4_fwd_group<NT, DQ, Q, 2 * H + 1>(T, cur + (unsigned)(w + 4) * 32u, w, ln);
+  g4_fwd_group<NC, NT, DQ, Q, 2 * H>(T, cur, w, ln);
+  g4_fwd_group<NC, NT, DQ, Q, 2 * H + 1>(T, cur + (unsigned)(w + 4) * 32u, w, ln);
   asm volatile("" ::: "memory");
 }
-template <int NT, int DQ, int Q>
-__device__ __forceinline__ void g4_fwd_tiles(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+template <int NC, int NT, int DQ, int Q>
+__device__ __forceinline__ void g4_fwd_tiles(double (&T)[NC * NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
                                              int ring) {
   if constexpr (Q < NT) {
     if (16 * Q < b) {
-      g4_fwd_chunk<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
-      if (16 * Q + 8 < b) g4_fwd_chunk<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
-      g4_fwd_tiles<NT, DQ, Q + 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+      g4_fwd_chunk<NC, NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+      if (16 * Q + 8 < b) g4_fwd_chunk<NC, NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+      g4_fwd_tiles<NC, NT, DQ, Q + 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
     }
   }
 }
 
 // Backward: the last `ring` chunks are still where the forward sweep left them; chunk c requests chunk
 // c - (ring - 1) unless that one is among them.
-template <int NT, int DQ, int Q, int H>
-__device__ __forceinline__ void g4_bwd_chunk(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+template <int NC, int NT, int DQ, int Q, int H>
+__device__ __forceinline__ void g4_bwd_chunk(double (&T)[NC * NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
                                              int ring) {
   constexpr int C = 2 * Q + H;
@@ -314,27 +325,27 @@ __device__ __forceinline__ void g4_bwd_chunk(double (&T)[NT], int b, int w, cons
     g4_wait_vm(max(0, hi - lo + 1) * nld);
   }
   const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (ring - 1)) * lstride);
-  g4_bwd_group<NT, DQ, Q, 2 * H + 1>(T, cur + (unsigned)(w + 4) * 32u, w, ln);
-  g4_bwd_group<NT, DQ, Q, 2 * H>(T, cur, w, ln);
+  g4_bwd_group<NC, NT, DQ, Q, 2 * H + 1>(T, cur + (unsigned)(w + 4) * 32u, w, ln);
+  g4_bwd_group<NC, NT, DQ, Q, 2 * H>(T, cur, w, ln);
   asm volatile("" ::: "memory");
 }
-template <int NT, int DQ, int Q>
-__device__ __forceinline__ void g4_bwd_tiles(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+template <int NC, int NT, int DQ, int Q>
+__device__ __forceinline__ void g4_bwd_tiles(double (&T)[NC * NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
                                              int ring) {
   if constexpr (Q >= 0) {
     if (16 * Q < b) {
-      if (16 * Q + 8 < b) g4_bwd_chunk<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
-      g4_bwd_chunk<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+      if (16 * Q + 8 < b) g4_bwd_chunk<NC, NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+      g4_bwd_chunk<NC, NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
     }
-    g4_bwd_tiles<NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+    g4_bwd_tiles<NC, NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
   }
 }
 
 // One wavefront per block.  NT tiles of 16 rows (b <= 16 NT), DQ = tiles a group's record reaches
 // (w + 15 < 16 DQ).  `xs` = row stride of the panels in doubles (2, 4; 8 / 16 when the kernel is
 // launched on a 4-column slice of a wider panel), `ncol` <= 4 columns starting at `in` / `out`.
-template <int NT, int DQ, int OCC>
+template <int NC, int NT, int DQ, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     const int* __restrict__ list, int count, const int* __restrict__ row0, const int* __restrict__ nrows,
     const int* __restrict__ bw, const long long* __restrict__ off2, const int* __restrict__ map_f,
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
   lf.blk = blk;
 
   g4_issue_chunk(rec, chunk_doubles, 0, lds0, lane);
-  double T[NT];
+  double T[NC * NT];
   const int* __restrict__ mp = map_f + r0;
   {
     unsigned rowoff[NT];        // (the host checks that m * xs fits 31 bits)
@@ -376,12 +387,14 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
       rowoff[q] = ((unsigned)r0 + (unsigned)mp[j < b ? j : 0]) * (unsigned)xs + lo;
     }
 #pragma unroll
-    for (int q = 0; q < NT; ++q) T[q] = (16 * q + trow < b && lo < ncol) ? in[rowoff[q]] : 0.0;
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int q = 0; q < NT; ++q) T[c * NT + q] = (16 * q + trow < b && 4 * c + lo < ncol) ? in[rowoff[q] + 4 * c] : 0.0;
   }
   // the rest of the ring behind the panel loads, so that the newest requests are all chunks
   for (int c = 1; c < ring - 1 && 8 * c < b; ++c) g4_issue_chunk(rec, chunk_doubles, c, lds0 + c * lstride, lane);
 
-  g4_fwd_tiles<NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring);
+  g4_fwd_tiles<NC, NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring);
 
   // y = D^-2 a
   {
@@ -390,7 +403,9 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
 #pragma unroll
     for (int q = 0; q < NT; ++q) { const int j = 16 * q + trow; d[q] = dv[j < b ? j : 0]; }
 #pragma unroll
-    for (int q = 0; q < NT; ++q) T[q] *= d[q] * d[q];
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int q = 0; q < NT; ++q) T[c * NT + q] *= d[q] * d[q];
   }
   // (the last chunk of the forward sweep is the first of the backward one: it is still in its buffer,
   // and so is the one before it -- g4_bwd_chunk does not fetch that one again)
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     lb.aX = (unsigned)lo2 * 8u;
     lb.hi = hi2;
     lb.blk = blk2;
-    g4_bwd_tiles<NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring);
+    g4_bwd_tiles<NC, NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring);
   }
 
   {
@@ -417,8 +432,10 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
       rowoff[q] = ((unsigned)r0 + (unsigned)mp[j < b ? j : 0]) * (unsigned)xs + lo3;
     }
 #pragma unroll
-    for (int q = 0; q < NT; ++q)
-      if (16 * q + trow3 < b && lo3 < ncol) out[rowoff[q]] = T[q];
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+        if (16 * q + trow3 < b && 4 * c + lo3 < ncol) out[rowoff[q] + 4 * c] = T[c * NT + q];
   }
 }
 
@@ -431,7 +448,7 @@ int kfail(const char* what) {
   return 1;
 }
 
-template <int NT, int DQ, int OCC>
+template <int NC, int NT, int DQ, int OCC>
 int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int xs, int ncol, const double* in, double* out) {
   const int cbuf = (8 * (wmax + 4) + 127) & ~127;        // doubles per ring buffer, a multiple of 1 KiB
   const int nld = cbuf >> 7;
@@ -455,32 +472,32 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
   const size_t lds = (size_t)waves * per_wave * 8;
   static size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NT, DQ, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NC, NT, DQ, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return kfail("hipFuncSetAttribute(k_bj_g4)");
     configured = lds;
   }
   const int blocks = (count + waves - 1) / waves;
-  PA_LAUNCH((k_bj_g4<NT, DQ, OCC>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
+  PA_LAUNCH((k_bj_g4<NC, NT, DQ, OCC>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
                      pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out);
   return kfail("k_bj_g4");
 }
 
-template <int NT, int DQ>
+template <int NC, int NT, int DQ>
 int launch(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int xs, int ncol, const double* in, double* out) {
-  return launch_occ<NT, DQ, (NT <= 12 && DQ <= 5) ? 5 : 4>(list, count, pl, wmax, xs, ncol, in, out);
+  return launch_occ<NC, NT, DQ, (NC == 1 && NT <= 12 && DQ <= 5) ? 5 : (NC == 1 ? 4 : 3)>(list, count, pl, wmax, xs, ncol, in, out);
 }
 
-template <int NT>
+template <int NC, int NT>
 int launch_dq(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int xs, int ncol, const double* in, double* out) {
   const int dq = ((wmax + 15) >> 4) + 1;
   switch (dq) {
-    case 1: case 2: case 3: return launch<NT, 3>(list, count, pl, wmax, xs, ncol, in, out);
-    case 4: return launch<NT, 4>(list, count, pl, wmax, xs, ncol, in, out);
-    case 5: return launch<NT, 5>(list, count, pl, wmax, xs, ncol, in, out);
-    case 6: return launch<NT, 6>(list, count, pl, wmax, xs, ncol, in, out);
-    case 7: return launch<NT, 7>(list, count, pl, wmax, xs, ncol, in, out);
-    case 8: return launch<NT, 8>(list, count, pl, wmax, xs, ncol, in, out);
+    case 1: case 2: case 3: return launch<NC, NT, 3>(list, count, pl, wmax, xs, ncol, in, out);
+    case 4: return launch<NC, NT, 4>(list, count, pl, wmax, xs, ncol, in, out);
+    case 5: return launch<NC, NT, 5>(list, count, pl, wmax, xs, ncol, in, out);
+    case 6: return launch<NC, NT, 6>(list, count, pl, wmax, xs, ncol, in, out);
+    case 7: if constexpr (NC == 1) return launch<NC, NT, 7>(list, count, pl, wmax, xs, ncol, in, out); else return 1;
+    case 8: if constexpr (NC == 1) return launch<NC, NT, 8>(list, count, pl, wmax, xs, ncol, in, out); else return 1;
     default: return 1;
   }
 }
@@ -491,6 +508,7 @@ extern "C" {
 
 int pa_bj_g4_max_rows(void) { return 256; }
 int pa_bj_g4_max_band(void) { return 112; }
+int pa_bj_g4_max_band8(void) { return 80; }     /* panels of 5 .. 8 columns (two column sets per wavefront) */
 
 int pa_k_bj_g4_setup(const int* list, int count, const int* nrows, const int* bw, const long long* off,
                       const long long* off2, const double* L, double* Lg4) {
@@ -500,13 +518,18 @@ int pa_k_bj_g4_setup(const int* list, int count, const int* nrows, const int* bw
 }
 
 /* One class of blocks (all with at most bmax rows and bands up to wmax) on a panel of row stride xs:
- * the four columns starting at `in` / `out`. */
+ * the ncol <= 8 columns starting at `in` / `out` (more than 4: bands up to pa_bj_g4_max_band8()). */
 int pa_k_bj_g4(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int bmax, int xs, int ncol,
                 const double* in, double* out) {
   if (count <= 0) return 0;
-  if (bmax <= 192) return launch_dq<12>(list, count, pl, wmax, xs, ncol, in, out);
-  if (bmax <= 224) return launch_dq<14>(list, count, pl, wmax, xs, ncol, in, out);
-  return launch_dq<16>(list, count, pl, wmax, xs, ncol, in, out);
+  if (ncol > 4) {
+    if (bmax <= 192) return launch_dq<2, 12>(list, count, pl, wmax, xs, ncol, in, out);
+    if (bmax <= 224) return launch_dq<2, 14>(list, count, pl, wmax, xs, ncol, in, out);
+    return launch_dq<2, 16>(list, count, pl, wmax, xs, ncol, in, out);
+  }
+  if (bmax <= 192) return launch_dq<1, 12>(list, count, pl, wmax, xs, ncol, in, out);
+  if (bmax <= 224) return launch_dq<1, 14>(list, count, pl, wmax, xs, ncol, in, out);
+  return launch_dq<1, 16>(list, count, pl, wmax, xs, ncol, in, out);
 }
 
 }  // extern "C"

@@ -351,6 +351,24 @@ def test_band_solve_for_up_to_four_columns(n, box, t, g4, monkeypatch):
         prob.close()
 
 
+@pytest.mark.parametrize("wide", ["1", "0"])
+@pytest.mark.parametrize("n,box,t", [(20, (5, 5, 10), 8), (24, (4, 4, 12), 8), (12, (6, 6, 6), 7), (24, (8, 3, 8), 5), (24, (6, 4, 8), 6)])
+def test_band_solve_for_eight_columns(n, box, t, wide, monkeypatch):
+    """Panels of 5 .. 8 columns: two column sets per wavefront on the one-copy records (bj_g4.hip, bands up to
+    80) and, with PREALPS_BJ_G4_WIDE=0, the two-copy matrix-core kernel k_bj_mfma it stands in for."""
+    monkeypatch.setenv("PREALPS_BJ_G4_WIDE", wide)
+    monkeypatch.setenv("PREALPS_BJ_WIDE_FROM", "448")
+    from oracle import oracle as O
+    prob, B, rowpos, X = _boxes_problem(n, box, t, n + t)
+    try:
+        zr = O.BlockJacobi(B, rowpos).apply(X)
+        got = prob.block_jacobi_apply(X, t)
+        np.testing.assert_allclose(got, zr, rtol=1e-11, atol=1e-12 * np.abs(zr).max())
+        np.testing.assert_array_equal(got, prob.block_jacobi_apply(X, t))
+    finally:
+        prob.close()
+
+
 @pytest.mark.parametrize("ring", ["2", "4", "8"])
 def test_band_solve_prefetch_ring_depths(ring, monkeypatch):
     """The prefetch ring of bj_g4.hip at every depth (few blocks get 8 buffers by default, many get 2)."""
