@@ -24,10 +24,11 @@
 //     and the accumulator of the forward one.  The whole block (up to 16 tiles = 256 rows) lives in
 //     registers between the sweeps: the forward result is never written out.
 //   * The four rows of a group sit in the four 16-lane rows of their tile register (one quad of each).
-//     Vector-ALU lane moves (DPP row rotations, v_permlane16_swap / v_permlane32_swap) copy that quad into
-//     every quad and every one of the four rows into all rows; each lane then runs the whole 4 x 4
-//     substitution for its column and keeps the row it stands for: no LDS round trip on the chain from
-//     one group to the next.
+//     The 4 x 4 substitution runs on the matrix cores too, in place: three dependent 4 x 4 x 4 products
+//     whose A operand holds one column of the negated corner and whose B operand and accumulator are the
+//     tile itself (g4_corner_solve).  One DPP sequence then copies the group's quad into every quad (the
+//     B operand of the update of the rows below); no LDS round trip and no lane-by-lane selection on the
+//     chain from one group to the next.
 //   * Records are streamed HBM -> LDS by LDS-DMA in chunks of two groups, double buffered per wave,
 //     forward in ascending and backward in descending order; a lane fetches its A-operand entry with
 //     one ds_read_b64 (rows outside the record are clamped onto its all-zero row).
@@ -57,7 +58,7 @@ inline hipStream_t cur_stream() { return (hipStream_t)pa_rt_stream(); }
 //                          product adds them;
 //   position  w            zeros (where every row outside the record is sent);
 //   positions w+1 .. w+3   rows 1 .. 3 of the strictly lower corner Lt(g, g) (zero on and above the
-//                          diagonal), as they are.
+//                          diagonal), negated as well.
 // Chunks of two groups; the groups a block does not have are zero.
 __global__ __launch_bounds__(256) void k_bj_g4_setup(const int* __restrict__ list, const int* __restrict__ nrows,
                                                       const int* __restrict__ bw, const long long* __restrict__ off,
@@ -75,10 +76,7 @@ __global__ __launch_bounds__(256) void k_bj_g4_setup(const int* __restrict__ lis
     if (pos != w) {
       const int rho = pos < w ? w + 3 - pos : pos - w;     // row of the group
       const int row = 4 * g + rho, d = row - piv;
-      if (row < b && piv < b && d >= 1 && d <= w) {
-        v = rec[(size_t)piv * wr + d - 1];
-        if (pos < w) v = -v;
-      }
+      if (row < b && piv < b && d >= 1 && d <= w) v = -rec[(size_t)piv * wr + d - 1];
     }
     dst[e] = v;
   }
@@ -125,27 +123,22 @@ __device__ __forceinline__ double row_ror(double v) {
   return __hiloint2double(hi, lo);
 }
 
-typedef double g4_d2 __attribute__((ext_vector_type(2)));
-
 // s_waitcnt lgkmcnt(0) that the compiler sees as the producer of everything read before it
 template <int DQ>
-__device__ __forceinline__ void g4_wait_cf(double (&cf)[DQ], g4_d2& la, g4_d2& lb, double& lc, double& ld) {
-  if constexpr (DQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]));
-  else if constexpr (DQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]));
-  else if constexpr (DQ == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]));
-  else if constexpr (DQ == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]));
-  else if constexpr (DQ == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]));
-  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la), "+v"(lb), "+v"(lc), "+v"(ld), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]), "+v"(cf[7]));
+__device__ __forceinline__ void g4_wait_cf(double (&cf)[DQ], double& c0, double& c1, double& c2) {
+  if constexpr (DQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]));
+  else if constexpr (DQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]));
+  else if constexpr (DQ == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]));
+  else if constexpr (DQ == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]));
+  else if constexpr (DQ == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]), "+v"(cf[7]));
 }
 
-// Lane moves, all in the vector ALU (no LDS round trip on the chain from one group to the next, and all
-// compiler-visible: an earlier version issued ds_bpermute by hand and read stale registers -- the hazard
-// recogniser does not look into inline assembly, and a double-precision result needs wait states before a
-// DS instruction may read it).  Lane = 16 hi + 4 blk + lo (tools/probe/permlane_swap.hip):
-//   DPP row_ror:4n          quad q of every 16-lane row takes quad (q - n) mod 4; bank_mask picks the
-//                           quads that are written
-//   v_permlane16_swap a, b  a' = [a.r0, b.r0, a.r2, b.r2],  b' = [a.r1, b.r1, a.r3, b.r3]   (r = 16-lane rows)
-//   v_permlane32_swap a, b  a' = [a.r0, a.r1, b.r0, b.r1],  b' = [a.r2, a.r3, b.r2, b.r3]
+// Lane moves in the vector ALU, compiler-visible (an earlier version issued ds_bpermute by hand and read
+// stale registers: the hazard recogniser does not look into inline assembly, and a double-precision
+// result needs wait states before a DS instruction may read it).  Lane = 16 hi + 4 blk + lo
+// (tools/probe/permlane_swap.hip): DPP row_ror:4n gives quad q of every 16-lane row the quad (q - n) mod 4;
+// bank_mask picks the quads that are written.
 template <int GQ>
 __device__ __forceinline__ double g4_quad_bcast(double x) {      // quad GQ of every row into all four quads
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -158,40 +151,29 @@ __device__ __forceinline__ double g4_quad_bcast(double x) {      // quad GQ of e
   hi = __builtin_amdgcn_update_dpp(hi, shi, 0x12C, 0xF, 1 << ((GQ + 3) & 3), false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void g4_row_bcast(double x, double (&R)[4]) {   // R[k] = row k of x, in every row
-  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-  const auto pl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [r0 r0 r2 r2], [r1 r1 r3 r3]
-  const auto ph = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  const auto al = __builtin_amdgcn_permlane32_swap(pl[0], pl[0], false, false);   // r0 x 4, r2 x 4
-  const auto ah = __builtin_amdgcn_permlane32_swap(ph[0], ph[0], false, false);
-  const auto bl = __builtin_amdgcn_permlane32_swap(pl[1], pl[1], false, false);   // r1 x 4, r3 x 4
-  const auto bh = __builtin_amdgcn_permlane32_swap(ph[1], ph[1], false, false);
-  R[0] = __hiloint2double((int)ah[0], (int)al[0]);
-  R[2] = __hiloint2double((int)ah[1], (int)al[1]);
-  R[1] = __hiloint2double((int)bh[0], (int)bl[0]);
-  R[3] = __hiloint2double((int)bh[1], (int)bl[1]);
-}
 
 // Per-lane constants of a sweep (lane = 16 hi + 4 blk + lo):
 //   cX     w + 3 - (row of this lane inside a tile as the A operand of this sweep sees it)
 //   aX     byte offset of this lane's pivot column inside a record row
-struct g4_lane { int cX; unsigned aX; int hi, blk; };
+//   cg     byte offset, from position w of a record, of this lane's entry of the 4 x 4 corner as the A
+//          operand of the substitution: forward Lt(lo, hi) (row lo, column hi), backward Lt(hi, lo)
+struct g4_lane { int cX; unsigned aX; unsigned cg; int hi, blk; };
 
-// the six entries of the group's strictly lower 4 x 4 corner (the same for every lane): rows 1, 2, 3 at
-// positions w + 1 .. w + 3 of the record
-__device__ __forceinline__ void g4_corner_issue(unsigned cur, int w, g4_d2& la, g4_d2& lb, double& lc, double& ld) {
-  const unsigned ad = cur + (unsigned)w * 32u;
-  asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(lc) : "v"(ad));      // l10
-  asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(la) : "v"(ad));     // l20 l21
-  asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(lb) : "v"(ad));     // l30 l31
-  asm volatile("ds_read_b64 %0, %1 offset:112" : "=v"(ld) : "v"(ad));     // l32
-}
-// the row this lane stands for.  (The values are made opaque first: otherwise the compiler sinks the
-// substitution chains into divergent branches, one per row, instead of four selects.)
-__device__ __forceinline__ double g4_pick(int hi, double (&y)[4]) {
-  asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
-  const double a = hi == 0 ? y[0] : y[1], b = hi == 2 ? y[2] : y[3];
-  return hi < 2 ? a : b;
+// The 4 x 4 substitution on the matrix cores, in place in the pivot tile: step k adds (column k of the
+// negated strictly lower corner) x (row k of the group) to the group's rows -- a 4 x 4 x 4 product whose A
+// operand is zero but for that column, and zero altogether in the three blocks that do not hold the group,
+// whose B operand and accumulator are both the tile itself.  Three dependent matrix instructions, no lane
+// moves; the same operations in the same order as the scalar substitution (the other three terms of each
+// product are exact zeros).  A lane gets its A entries by reading either its corner entry or the record's
+// zero row: `ck` = LDS addresses chosen per step.
+template <int NC, int NT, int Q>
+__device__ __forceinline__ void g4_corner_solve(double (&T)[NC * NT], double a0, double a1, double a2) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    T[c * NT + Q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, T[c * NT + Q], T[c * NT + Q], 0, 0, 0);
+    T[c * NT + Q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, T[c * NT + Q], T[c * NT + Q], 0, 0, 0);
+    T[c * NT + Q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, T[c * NT + Q], T[c * NT + Q], 0, 0, 0);
+  }
 }
 
 // One group of four pivots, forward: Q = tile of the pivots, GQ = their block inside it, `cur` = LDS
@@ -202,8 +184,17 @@ __device__ __forceinline__ void g4_fwd_group(double (&T)[NC * NT], unsigned cur,
   // (opaque copy: without it the compiler keeps the clamped index of every (tile offset, group) pair
   // of the unrolled sweeps alive in registers and spills)
   asm volatile("" : "+v"(ln.cX));
-  g4_d2 la, lb; double lc, ld;
-  g4_corner_issue(cur, w, la, lb, lc, ld);
+  const unsigned zero_ad = cur + (unsigned)w * 32u, mine = zero_ad + ln.cg;
+  const bool here = ln.blk == GQ;
+  double a0, a1, a2;          // steps 0, 1, 2: column k of the corner lives in the lanes hi == k
+  {
+    const unsigned ad0 = (here && ln.hi == 0) ? mine : zero_ad;
+    const unsigned ad1 = (here && ln.hi == 1) ? mine : zero_ad;
+    const unsigned ad2 = (here && ln.hi == 2) ? mine : zero_ad;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(a0) : "v"(ad0));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(a1) : "v"(ad1));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(a2) : "v"(ad2));
+  }
   double cf[DQ];
 #pragma unroll
   for (int dq = 0; dq < DQ; ++dq) {
@@ -214,21 +205,11 @@ __device__ __forceinline__ void g4_fwd_group(double (&T)[NC * NT], unsigned cur,
       asm volatile("ds_read_b64 %0, %1" : "=v"(cf[dq]) : "v"(ad));
     }
   }
-  // the group's four rows (quad GQ of the four 16-lane rows of T[Q]) in every quad, then each of
-  // them in every row: all lanes hold x_0 .. x_3 of their column and run the substitution
-  double x[NC][4];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) g4_row_bcast(g4_quad_bcast<GQ>(T[c * NT + Q]), x[c]);
-  g4_wait_cf<DQ>(cf, la, lb, lc, ld);
+  g4_wait_cf<DQ>(cf, a0, a1, a2);
+  g4_corner_solve<NC, NT, Q>(T, a0, a1, a2);            // y_g = Lt(g, g)^-1 x_g, in place
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    double y[4];
-    y[0] = x[c][0];
-    y[1] = fma(-lc, y[0], x[c][1]);
-    y[2] = fma(-la.y, y[1], fma(-la.x, y[0], x[c][2]));
-    y[3] = fma(-ld, y[2], fma(-lb.y, y[1], fma(-lb.x, y[0], x[c][3])));
-    const double yg = g4_pick(ln.hi, y);                // B operand: row hi of the group in lane (hi, blk, lo)
-    T[c * NT + Q] = (ln.blk == GQ) ? yg : T[c * NT + Q];
+    const double yg = g4_quad_bcast<GQ>(T[c * NT + Q]);  // B operand: the group's rows in every block
 #pragma unroll
     for (int dq = 0; dq < DQ; ++dq)
       if (Q + dq < NT) T[c * NT + Q + dq] = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], yg, T[c * NT + Q + dq], 0, 0, 0);
@@ -239,8 +220,17 @@ __device__ __forceinline__ void g4_fwd_group(double (&T)[NC * NT], unsigned cur,
 template <int NC, int NT, int DQ, int Q, int GQ>
 __device__ __forceinline__ void g4_bwd_group(double (&T)[NC * NT], unsigned cur, int w, g4_lane ln) {
   asm volatile("" : "+v"(ln.cX));
-  g4_d2 la, lb; double lc, ld;
-  g4_corner_issue(cur, w, la, lb, lc, ld);
+  const unsigned zero_ad = cur + (unsigned)w * 32u, mine = zero_ad + ln.cg;
+  const bool here = ln.blk == GQ;
+  double a3, a2, a1;          // steps 3, 2, 1: row k of the corner, transposed, lives in the lanes hi == k
+  {
+    const unsigned ad3 = (here && ln.hi == 3) ? mine : zero_ad;
+    const unsigned ad2 = (here && ln.hi == 2) ? mine : zero_ad;
+    const unsigned ad1 = (here && ln.hi == 1) ? mine : zero_ad;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(a3) : "v"(ad3));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(a2) : "v"(ad2));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(a1) : "v"(ad1));
+  }
   double cf[DQ];
 #pragma unroll
   for (int dq = 0; dq < DQ; ++dq) {
@@ -251,10 +241,7 @@ __device__ __forceinline__ void g4_bwd_group(double (&T)[NC * NT], unsigned cur,
       asm volatile("ds_read_b64 %0, %1" : "=v"(cf[dq]) : "v"(ad));
     }
   }
-  double yq[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) yq[c] = g4_quad_bcast<GQ>(T[c * NT + Q]);
-  g4_wait_cf<DQ>(cf, la, lb, lc, ld);
+  g4_wait_cf<DQ>(cf, a3, a2, a1);
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     double acc = 0.0;
@@ -262,18 +249,12 @@ __device__ __forceinline__ void g4_bwd_group(double (&T)[NC * NT], unsigned cur,
     for (int dq = 0; dq < DQ; ++dq)
       if (Q + dq < NT) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(cf[dq], T[c * NT + Q + dq], acc, 0, 0, 0);
     // every block of the accumulator holds the sum over ITS four rows of each tile: add the four
-    // blocks (rotations by 4 and 8 lanes inside the 16-lane rows)
+    // blocks (rotations by 4 and 8 lanes inside the 16-lane rows); the group's lanes take the total
     acc += row_ror<4>(acc);
     acc += row_ror<8>(acc);
-    double r[4], z[4];
-    g4_row_bcast(yq[c] + acc, r);
-    z[3] = r[3];
-    z[2] = fma(-ld, z[3], r[2]);
-    z[1] = fma(-la.y, z[2], fma(-lb.y, z[3], r[1]));
-    z[0] = fma(-lc, z[1], fma(-la.x, z[2], fma(-lb.x, z[3], r[0])));
-    const double zg = g4_pick(ln.hi, z);
-    T[c * NT + Q] = (ln.blk == GQ) ? zg : T[c * NT + Q];
+    T[c * NT + Q] += here ? acc : 0.0;
   }
+  g4_corner_solve<NC, NT, Q>(T, a3, a2, a1);
 }
 
 // The chunks of a sweep (two groups each) go through a ring of `ring` LDS buffers (a power of two, lstride
@@ -373,6 +354,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
   g4_lane lf;
   lf.cX = w + 3 - (4 * blk + lo);
   lf.aX = (unsigned)hi * 8u;
+  lf.cg = (unsigned)lo * 32u + (unsigned)hi * 8u;      // Lt(lo, hi): row lo of the corner, column hi
   lf.hi = hi;
   lf.blk = blk;
 
@@ -416,6 +398,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     g4_lane lb;
     lb.cX = w + 3 - (4 * blk2 + hi2);
     lb.aX = (unsigned)lo2 * 8u;
+    lb.cg = (unsigned)hi2 * 32u + (unsigned)lo2 * 8u;    // Lt(hi, lo): the transposed corner
     lb.hi = hi2;
     lb.blk = blk2;
     g4_bwd_tiles<NC, NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring);

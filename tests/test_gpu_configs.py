@@ -608,7 +608,10 @@ rhs = prob.reference_rhs()
 got = prob.solve(rhs, 8)
 ref = O.ECG(B, rowpos, 8).solve(rhs)
 assert got.iters == ref["iters"]
-np.testing.assert_allclose(got.res, ref["res"], rtol=1e-8)
+# (8 directions on 16 slabs: the t x t blocks lose rank as the solve converges, and the last residuals
+# amplify rounding differences -- 5e-9 with k_bj_mfma, 2e-8 with bj_g4 at the final iteration, 1e-11 before)
+np.testing.assert_allclose(got.res[:-2], ref["res"][:-2], rtol=1e-8)
+np.testing.assert_allclose(got.res, ref["res"], rtol=1e-6)
 prob.close()
 # narrow bands (register-set class 2): 27 boxes of 4 x 4 x 4 points
 from prealps_amd import gen
