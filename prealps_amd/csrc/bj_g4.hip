@@ -468,7 +468,7 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
 
 template <int NC, int NT, int DQ>
 int launch(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int xs, int ncol, const double* in, double* out) {
-  return launch_occ<NC, NT, DQ, (NC == 1 && NT <= 12 && DQ <= 5) ? 5 : (NC == 1 ? 4 : 3)>(list, count, pl, wmax, xs, ncol, in, out);
+  return launch_occ<NC, NT, DQ, (NC == 1 && NT <= 12 && DQ <= 5) ? 5 : (NC == 1 ? 4 : (NC == 2 ? 3 : 2))>(list, count, pl, wmax, xs, ncol, in, out);
 }
 
 template <int NC, int NT>
@@ -478,7 +478,7 @@ int launch_dq(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int 
     case 1: case 2: case 3: return launch<NC, NT, 3>(list, count, pl, wmax, xs, ncol, in, out);
     case 4: return launch<NC, NT, 4>(list, count, pl, wmax, xs, ncol, in, out);
     case 5: return launch<NC, NT, 5>(list, count, pl, wmax, xs, ncol, in, out);
-    case 6: return launch<NC, NT, 6>(list, count, pl, wmax, xs, ncol, in, out);
+    case 6: if constexpr (NC <= 2) return launch<NC, NT, 6>(list, count, pl, wmax, xs, ncol, in, out); else return 1;
     case 7: if constexpr (NC == 1) return launch<NC, NT, 7>(list, count, pl, wmax, xs, ncol, in, out); else return 1;
     case 8: if constexpr (NC == 1) return launch<NC, NT, 8>(list, count, pl, wmax, xs, ncol, in, out); else return 1;
     default: return 1;
@@ -492,6 +492,7 @@ extern "C" {
 int pa_bj_g4_max_rows(void) { return 256; }
 int pa_bj_g4_max_band(void) { return 112; }
 int pa_bj_g4_max_band8(void) { return 80; }     /* panels of 5 .. 8 columns (two column sets per wavefront) */
+int pa_bj_g4_max_band16(void) { return 64; }    /* panels of 9 .. 16 columns (four column sets) */
 
 int pa_k_bj_g4_setup(const int* list, int count, const int* nrows, const int* bw, const long long* off,
                       const long long* off2, const double* L, double* Lg4) {
@@ -501,10 +502,15 @@ int pa_k_bj_g4_setup(const int* list, int count, const int* nrows, const int* bw
 }
 
 /* One class of blocks (all with at most bmax rows and bands up to wmax) on a panel of row stride xs:
- * the ncol <= 8 columns starting at `in` / `out` (more than 4: bands up to pa_bj_g4_max_band8()). */
+ * the ncol <= 16 columns starting at `in` / `out` (more than 4 / 8: bands up to pa_bj_g4_max_band8() / 16()). */
 int pa_k_bj_g4(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int bmax, int xs, int ncol,
                 const double* in, double* out) {
   if (count <= 0) return 0;
+  if (ncol > 8) {
+    if (bmax <= 192) return launch_dq<4, 12>(list, count, pl, wmax, xs, ncol, in, out);
+    if (bmax <= 224) return launch_dq<4, 14>(list, count, pl, wmax, xs, ncol, in, out);
+    return launch_dq<4, 16>(list, count, pl, wmax, xs, ncol, in, out);
+  }
   if (ncol > 4) {
     if (bmax <= 192) return launch_dq<2, 12>(list, count, pl, wmax, xs, ncol, in, out);
     if (bmax <= 224) return launch_dq<2, 14>(list, count, pl, wmax, xs, ncol, in, out);
