@@ -75,6 +75,41 @@ def test_mpi_driver_two_ranks_one_gpu_matches_oracle(tmp_path, alg, t):
     np.testing.assert_allclose(x, ref["x"], rtol=1e-7, atol=1e-10 * np.abs(ref["x"]).max())
 
 
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(not have_mpi, reason="no MPI launcher in this image")
+def test_mpi_driver_two_ranks_two_gpus_native_rccl(tmp_path):
+    """The same driver with one device per rank: the library must pick RCCL by itself (unique id broadcast
+    over MPI_COMM_WORLD, ncclSend / ncclRecv / ncclAllReduce on the library stream).  Needs two devices."""
+    if _device_count() < 2:
+        pytest.skip("one device: RCCL refuses two ranks on it (the host-staged hooks are tested above)")
+    from oracle import oracle as O
+    n, nparts, world, t = 16, 16, 2, 4
+    (rp, ci, v), B, perm, rowpos = _problem(n, nparts)
+    mtx = str(tmp_path / "a.mtx")
+    _write_mtx(mtx, rp, ci, v)
+    prealps_amd.load()
+    exe = str(tmp_path / "ecg_driver_mpi")
+    subprocess.check_call(["gcc", "-std=gnu11", "-DPREALPS_USE_SYSTEM_MPI", "-I" + MPI_INC, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "ecg_driver.c"), "-L" + os.path.join(ROOT, "prealps_amd"),
+                           "-lprealps_hip", os.path.join(MPI_LIB, "libmpi.so.12"), "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu",
+                           "-Wl,-rpath," + os.path.join(ROOT, "prealps_amd"), "-Wl,-rpath," + MPI_LIB, "-lm", "-o", exe])
+    env = dict(os.environ, PREALPS_NPARTS=str(nparts), PREALPS_SETUP_TRACE="1", OMP_NUM_THREADS="4",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([MPIEXEC, "-n", str(world), exe, "-m", mtx, "-e", str(t), "-o", "0", "-x", str(tmp_path / "sol")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "hooks: rccl" in r.stderr
+    it = int(re.search(r"iter: (\d+)", r.stdout).group(1))
+    ref = O.ECG(B, rowpos, t).solve(O.reference_rhs(rowpos))
+    assert it == ref["iters"], (it, ref["iters"])
+    x = np.concatenate([np.fromfile(str(tmp_path / "sol") + ".%d" % k) for k in range(world)])
+    np.testing.assert_allclose(x, ref["x"], rtol=1e-7, atol=1e-10 * np.abs(ref["x"]).max())
+
+
 @pytest.mark.skipif(not (have_mpi and os.path.exists(REF_BIN)), reason="needs MPI and the prebuilt reference driver (oracle/Makefile)")
 def test_unmodified_reference_driver_two_ranks_one_gpu(tmp_path):
     """The reference's examples/test_ecg_prealps_op.c, compiled unchanged where the reference tree
