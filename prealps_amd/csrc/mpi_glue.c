@@ -105,6 +105,17 @@ static int is_mpich_comm(int c) {
  * and size from the communicator, as the reference does (utils/operator.c:42-43). */
 int pa_mpi_attach(MPI_Comm comm, int* rank, int* size) {
   if (g_active && (mp_comm)comm == g_comm) { *rank = g_mrank; *size = g_msize; return 1; }
+  {
+    /* an Open MPI launcher: its communicators are pointers, this library speaks the MPICH ABI only.
+     * Going on would make every rank solve the whole problem on its own: refuse loudly. */
+    const char* os = getenv("OMPI_COMM_WORLD_SIZE");
+    if (os && atoi(os) > 1 && pa_world_size() == 1) {
+      PA_FAIL("started by Open MPI with %s ranks: this library resolves MPI at run time with the MPICH ABI (MPICH, Intel MPI, "
+              "MVAPICH, Cray MPI); with Open MPI describe the process group yourself (preAlps_hip_set_world / "
+              "preAlps_hip_set_comm or preAlps_hip_rccl_init, INTEGRATION.md section 2)", os);
+      return 0;
+    }
+  }
   if (!resolve()) return 0;
   int flag = 0;
   if (M.Initialized(&flag) || !flag) return 0;
