@@ -41,6 +41,10 @@
 #include <cstdlib>
 #include "pa_device.h"
 
+#ifndef G4_NT
+#define G4_NT 12      /* this translation unit: 12 register tiles; bj_g4_nt14.hip / bj_g4_nt16.hip set 14 / 16 */
+#endif
+
 // a launch that a replayed graph segment makes in its place is skipped (runtime.hip: pa_rt_skip)
 #define PA_LAUNCH(...) do { if (!pa_rt_skipping()) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
@@ -468,7 +472,7 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
 
 template <int NC, int NT, int DQ>
 int launch(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int xs, int ncol, const double* in, double* out) {
-  return launch_occ<NC, NT, DQ, (NC == 1 && NT <= 12 && DQ <= 5) ? 5 : (NC == 1 ? 4 : (NC == 2 ? 3 : 2))>(list, count, pl, wmax, xs, ncol, in, out);
+  return launch_occ<NC, NT, DQ, (NC == 1 && NT <= 12 && DQ <= 5) ? 5 : (NC == 1 ? 4 : 3)>(list, count, pl, wmax, xs, ncol, in, out);
 }
 
 template <int NC, int NT>
@@ -489,10 +493,10 @@ int launch_dq(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int 
 
 extern "C" {
 
+#if G4_NT == 12
 int pa_bj_g4_max_rows(void) { return 256; }
 int pa_bj_g4_max_band(void) { return 112; }
 int pa_bj_g4_max_band8(void) { return 80; }     /* panels of 5 .. 8 columns (two column sets per wavefront) */
-int pa_bj_g4_max_band16(void) { return 64; }    /* panels of 9 .. 16 columns (four column sets) */
 
 int pa_k_bj_g4_setup(const int* list, int count, const int* nrows, const int* bw, const long long* off,
                       const long long* off2, const double* L, double* Lg4) {
@@ -501,24 +505,31 @@ int pa_k_bj_g4_setup(const int* list, int count, const int* nrows, const int* bw
   return kfail("k_bj_g4_setup");
 }
 
+int pa_k_bj_g4_nt14(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int xs, int ncol, const double* in, double* out);
+int pa_k_bj_g4_nt16(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int xs, int ncol, const double* in, double* out);
+
 /* One class of blocks (all with at most bmax rows and bands up to wmax) on a panel of row stride xs:
- * the ncol <= 16 columns starting at `in` / `out` (more than 4 / 8: bands up to pa_bj_g4_max_band8() / 16()). */
+ * the ncol <= 8 columns starting at `in` / `out` (more than 4: bands up to pa_bj_g4_max_band8()).  The
+ * kernels for 12 / 14 / 16 register tiles are compiled in three translation units (bj_g4.hip,
+ * bj_g4_nt14.hip, bj_g4_nt16.hip: the same source, G4_NT set) so that they build in parallel. */
 int pa_k_bj_g4(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int bmax, int xs, int ncol,
-                const double* in, double* out) {
+               const double* in, double* out) {
   if (count <= 0) return 0;
-  if (ncol > 8) {
-    if (bmax <= 192) return launch_dq<4, 12>(list, count, pl, wmax, xs, ncol, in, out);
-    if (bmax <= 224) return launch_dq<4, 14>(list, count, pl, wmax, xs, ncol, in, out);
-    return launch_dq<4, 16>(list, count, pl, wmax, xs, ncol, in, out);
-  }
-  if (ncol > 4) {
-    if (bmax <= 192) return launch_dq<2, 12>(list, count, pl, wmax, xs, ncol, in, out);
-    if (bmax <= 224) return launch_dq<2, 14>(list, count, pl, wmax, xs, ncol, in, out);
-    return launch_dq<2, 16>(list, count, pl, wmax, xs, ncol, in, out);
-  }
-  if (bmax <= 192) return launch_dq<1, 12>(list, count, pl, wmax, xs, ncol, in, out);
-  if (bmax <= 224) return launch_dq<1, 14>(list, count, pl, wmax, xs, ncol, in, out);
-  return launch_dq<1, 16>(list, count, pl, wmax, xs, ncol, in, out);
+  if (bmax > 224) return pa_k_bj_g4_nt16(pl, list, count, wmax, xs, ncol, in, out);
+  if (bmax > 192) return pa_k_bj_g4_nt14(pl, list, count, wmax, xs, ncol, in, out);
+  return ncol > 4 ? launch_dq<2, 12>(list, count, pl, wmax, xs, ncol, in, out)
+                  : launch_dq<1, 12>(list, count, pl, wmax, xs, ncol, in, out);
 }
+#elif G4_NT == 14
+int pa_k_bj_g4_nt14(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int xs, int ncol, const double* in, double* out) {
+  return ncol > 4 ? launch_dq<2, 14>(list, count, pl, wmax, xs, ncol, in, out)
+                  : launch_dq<1, 14>(list, count, pl, wmax, xs, ncol, in, out);
+}
+#else
+int pa_k_bj_g4_nt16(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int xs, int ncol, const double* in, double* out) {
+  return ncol > 4 ? launch_dq<2, 16>(list, count, pl, wmax, xs, ncol, in, out)
+                  : launch_dq<1, 16>(list, count, pl, wmax, xs, ncol, in, out);
+}
+#endif
 
 }  // extern "C"

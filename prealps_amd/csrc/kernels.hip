@@ -2991,10 +2991,9 @@ int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out)
   for (int c = 0; c < pl->nclass; ++c) {
     if (pl->class_count[c] <= 0) continue;
     int rc = 1;
-    static int g4_wide = -1;      /* PREALPS_BJ_G4_WIDE=0: 8-column panels stay with k_bj_mfma; 2: 16-column panels leave it too */
+    static int g4_wide = -1;      /* PREALPS_BJ_G4_WIDE=0: 8-column panels stay with k_bj_mfma */
     if (g4_wide < 0) { const char* e = getenv("PREALPS_BJ_G4_WIDE"); g4_wide = e ? atoi(e) : 1; }
-    if (pl->Lg4 && pl->class_g4[c] && (ts <= 4 || (ts == 8 && g4_wide && pl->class_wmax[c] <= pa_bj_g4_max_band8()) ||
-                                       (ts == 16 && g4_wide >= 2 && pl->class_wmax[c] <= pa_bj_g4_max_band16()))) {   /* one copy of the factor, matrix cores (bj_g4.hip) */
+    if (pl->Lg4 && pl->class_g4[c] && (ts <= 4 || (ts == 8 && g4_wide && pl->class_wmax[c] <= pa_bj_g4_max_band8()))) {   /* one copy of the factor, matrix cores (bj_g4.hip) */
       rc = pa_k_bj_g4(pl, pl->class_list[c], pl->class_count[c], pl->class_wmax[c], pl->class_bmax[c], ts, ts, in, out);
       if (rc) return rc;
       continue;

@@ -207,7 +207,6 @@ int pa_k_bj_pairs(const int* list, int count, const int* nrows, const int* bw, c
 int pa_bj_g4_max_rows(void);
 int pa_bj_g4_max_band(void);
 int pa_bj_g4_max_band8(void);
-int pa_bj_g4_max_band16(void);
 int pa_k_bj_g4_setup(const int* list, int count, const int* nrows, const int* bw, const long long* off,
                       const long long* off2, const double* L, double* Lg4);
 /* Band Cholesky on the device for blocks with bandwidth <= pa_bj_factor_wmax(): `band` holds
