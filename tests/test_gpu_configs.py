@@ -641,3 +641,75 @@ def test_opt_in_kernel_variants(env):
     r = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET % ROOT], capture_output=True, text=True,
                        env=dict(os.environ, **env), timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+# ---- opt-in: HIP-graph replay of the iteration halves; the one-shard rehearsal ----------------------------
+_GRAPH_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import prealps_amd as pa
+from prealps_amd import gen
+from oracle import oracle as O
+import scipy.sparse as sp
+rp, ci, v = gen.elasticity3d_csr(9)
+part, P = gen.box_partition_nodes(9, (3, 3, 3))
+A = sp.csr_matrix((v, ci, rp), shape=(len(rp) - 1, len(rp) - 1))
+B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, P)
+prob = pa.EcgProblem(rp, ci, v, P, part, scale=True, device=0)
+prob.L.preAlps_hip_graphs(1)
+rhs = prob.reference_rhs()
+for alg_g, alg_o, t in ((pa.ORTHODIR, O.ORTHODIR, 4), (pa.ORTHOMIN, O.ORTHOMIN, 4), (pa.ORTHODIR, O.ORTHODIR, 8)):
+    got = prob.solve(rhs, t, ortho_alg=alg_g, max_iter=400)
+    ref = O.ECG(B, rowpos, t, alg_o, O.NO_BS_RED, 1e-5, 400).solve(rhs)
+    assert got.iters == ref["iters"] and got.iters > 14, (got.iters, ref["iters"])      # (> 12 iterations: every phase replayed)
+    np.testing.assert_allclose(got.res[:20], ref["res"][:20], rtol=1e-8)
+    np.testing.assert_allclose(got.x, ref["x"], rtol=1e-5, atol=1e-7 * np.abs(ref["x"]).max())
+prob.close()
+print("graphs ok")
+"""
+
+_SHARD_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import prealps_amd as pa
+from prealps_amd import gen
+from oracle import oracle as O
+import scipy.sparse as sp
+n, box, G, r, t = 12, (3, 3, 3), 4, 1, 4
+rp, ci, v = gen.poisson3d_csr(n)
+part, P = gen.box_partition(n, box)
+A = sp.csr_matrix((v, ci, rp), shape=(n ** 3, n ** 3))
+B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, P)
+p0, p1 = r * P // G, (r + 1) * P // G
+lo, hi = int(rowpos[p0]), int(rowpos[p1])
+prob = pa.EcgProblem(rp, ci, v, P, part, scale=True, device=0, shard=(r, G))
+assert prob.m == hi - lo and prob.stat("halo_rows") > 0
+rhs = prob.reference_rhs()
+got = prob.solve(rhs, t, max_iter=400)
+# what the rehearsal iterates on: the rank's own diagonal block (halo rows arrive as zeros, sums are local),
+# split into the rank's own subdomains
+Brr = sp.csr_matrix(B[lo:hi][:, lo:hi])
+ref = O.ECG(Brr, (rowpos[p0:p1 + 1] - lo).astype(np.int32), t, O.ORTHODIR, O.NO_BS_RED, 1e-5, 400).solve(rhs)
+# (the enlarging columns of the rank's subdomains are p mod t in both: same splitting when p0 is a multiple of t)
+assert p0 %% t == 0
+assert got.iters == ref["iters"], (got.iters, ref["iters"])
+np.testing.assert_allclose(got.res, ref["res"], rtol=1e-7)
+np.testing.assert_allclose(got.x, ref["x"], rtol=1e-6, atol=1e-9 * np.abs(ref["x"]).max())
+prob.close()
+print("shard ok")
+"""
+
+
+def test_hip_graph_replay_matches_the_oracle():
+    """PREALPS_ECG_GRAPH / preAlps_hip_graphs(1): the two halves of an iteration captured on their second pass
+    and replayed afterwards (six pointer-rotation phases), Orthodir and Orthomin, 4 and 8 columns."""
+    r = subprocess.run([sys.executable, "-c", _GRAPH_SNIPPET % ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "graphs ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+
+
+def test_one_shard_rehearsal_solves_its_diagonal_block():
+    """preAlps_hip_loopback (bench.py --shard-of): rank 1 of 4 in one process runs the real multi-process
+    choreography (pack, side-stream exchange, interior / halo-reading SpMM halves) with zero halo rows and
+    local sums: it must solve exactly the system of its own diagonal block."""
+    r = subprocess.run([sys.executable, "-c", _SHARD_SNIPPET % ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "shard ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
