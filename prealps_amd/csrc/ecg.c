@@ -58,6 +58,7 @@ typedef struct {
   double* d_F; double* d_alpha; double* d_beta; double* d_mu; double* d_rtr;
   double* d_res2; double* d_q;
   double* d_partials; double* d_rtr_part;
+  double* d_spmm_parts; int spmm_cap;   /* Gram blocks left behind by the SpMM (pa_k_spmm_gram_arm), 32 doubles each */
   int rtr_nblk, rtr_valid;
   int* d_info; int* d_piv;
   double* h_pin;      /* pinned: [0] res2, [1..] scratch */
@@ -125,6 +126,9 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
   int nv = (ecg->ortho_alg == ORTHOMIN) ? 1 : 2;
   size_t small = 5 * (size_t)T * T + 2 * (size_t)T * T /* q, scratch */ + 8;
   size_t parts = (size_t)pa_gram_max_blocks() * (2 * (size_t)ts * ts + ts);
+  /* T = 4: the library's SpMM can form [AP | R]^T P while it computes AP (one block per workgroup) */
+  pv->spmm_cap = (T == 4 && ts == 4) ? pa_operator_gram_blocks(ts) : 0;
+  if (pv->spmm_cap) parts += ((size_t)pv->spmm_cap + pa_finish32_scratch_blocks()) * 32;
   pv->pool_doubles = (2 * nv + 3) * panel + small + parts;
   ecg->work = (double*)pa_rt_malloc(pv->pool_doubles * sizeof(double));
   if (!ecg->work) return PA_FAIL("device pool of %zu doubles: %s", pv->pool_doubles, pa_rt_error());
@@ -141,7 +145,8 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
   pv->d_q = w; w += 2 * (size_t)T * T;
   pv->d_res2 = w; w += 8;
   pv->d_partials = w; w += (size_t)pa_gram_max_blocks() * 2 * ts * ts;
-  pv->d_rtr_part = w;
+  pv->d_rtr_part = w; w += (size_t)pa_gram_max_blocks() * ts;
+  pv->d_spmm_parts = pv->spmm_cap ? w : NULL;
   pv->d_info = (int*)pa_rt_malloc((8 + T) * sizeof(int));
   if (!pv->d_info) return PA_FAIL("device allocation failed: %s", pa_rt_error());
   pv->d_piv = pv->d_info + 8;
@@ -152,6 +157,17 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
   if (!pv->ev_res) return PA_FAIL("hipEventCreate failed");
   publish_pointers(ecg, pv);
   return 0;
+}
+
+/* The first half of the next iteration starts with [AP | R]^T P (fused_first_half): when the
+ * product P -> AP is the library's SpMM on 4-column panels, ask it to leave that block behind.
+ * Called whenever the P / AP pointers have been published; anything else ends the request. */
+static void request_gram_from_spmm(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
+  if (pv->spmm_cap > 0 && pv->fuse && ecg->bs_red == NO_BS_RED && ecg->ortho_alg != ORTHODIR_FUSED &&
+      ecg->enlFac == 4 && ecg->P->info.n == 4)
+    pa_k_spmm_gram_arm(ecg->P->val, ecg->AP->val, pv->d_R, pv->d_spmm_parts, pv->spmm_cap);
+  else
+    pa_k_spmm_gram_disarm();
 }
 
 /* ------------------------------------------------------------- reset ---- */
@@ -243,6 +259,7 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
   ecg->res = 1.0; ecg->iter = 0; ecg->bs = t; ecg->kbs = ecg->V->info.n;
   pv->rtr_valid = 0;
   *rci_request = 0;
+  request_gram_from_spmm(ecg, pv);
   return 0;
 }
 
@@ -410,16 +427,22 @@ static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
   int single = pa_world_size() == 1;
   double* buf = pv->d_q; /* (t+T) x t */
   double t0;
+  /* blocks the SpMM left behind while it formed AP (request_gram_from_spmm): only their sum is left to do */
+  int from_spmm = pv->spmm_cap > 0 ? pa_k_spmm_gram_take(ecg->P->val, ecg->AP->val) : 0;
   TIC(PA_T_GRAM);
   if (single) {
-    /* nothing to reduce across processes: the Gram kernel's last workgroup sums the partial
-     * blocks and factors them right away */
-    PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, t, T, t, buf, t + T,
-                              t, T, pv->d_mu, pv->d_alpha, pv->d_info));
+    /* nothing to reduce across processes: the launch that sums the partial blocks factors them
+     * right away */
+    if (from_spmm) PA_CHECK(pa_k_finish32(pv->d_spmm_parts, from_spmm, pv->d_spmm_parts + (size_t)pv->spmm_cap * 32, t, T, buf,
+                                         pv->d_mu, pv->d_alpha, pv->d_info));
+    else PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, t, T, t, buf, t + T,
+                                   t, T, pv->d_mu, pv->d_alpha, pv->d_info));
     TAC(PA_T_GRAM, gemm_t);
   } else {
-    PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, t, T, t, buf, t + T,
-                              0, 0, NULL, NULL, NULL));
+    if (from_spmm) PA_CHECK(pa_k_finish32(pv->d_spmm_parts, from_spmm, pv->d_spmm_parts + (size_t)pv->spmm_cap * 32, 0, 0, buf,
+                                         NULL, NULL, NULL));
+    else PA_CHECK(pa_k_gram_finish(m, ts, ecg->AP->val, pv->d_R, ecg->P->val, pv->d_partials, t, T, t, buf, t + T,
+                                   0, 0, NULL, NULL, NULL));
     TAC(PA_T_GRAM, gemm_t);
     TIC(PA_T_COMM);
     if (pa_allreduce(buf, (t + T) * t)) return 1;
@@ -578,6 +601,7 @@ int _preAlps_ECGIterateOdir(preAlps_ECG_t* ecg, int* rci_request) {
   } else if (*rci_request == 1) {
     if (orthogonalise_z(ecg, pv)) return 1;
     if (shift_directions(ecg, pv, t)) return 1;
+    request_gram_from_spmm(ecg, pv);
     *rci_request = 0;
   }
   return 0;
@@ -637,6 +661,7 @@ int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
       CPLM_MatDenseSetInfo(ecg->beta, t, nrhs, t, nrhs, COL_MAJOR);
       ecg->bs = t;
     }
+    request_gram_from_spmm(ecg, pv);
     *rci_request = 0;
   }
   return 0;
@@ -725,6 +750,7 @@ int _preAlps_ECGWrapUp(preAlps_ECG_t* ecg, double* solution) {
 void _preAlps_ECGFree(preAlps_ECG_t* ecg) {
   ecg_priv_t* pv = priv_of(ecg);
   if (pv) {
+    pa_k_spmm_gram_disarm();
     pa_rt_sync();
     pa_rt_free(pv->d_info);
     pa_rt_host_free(pv->h_pin);

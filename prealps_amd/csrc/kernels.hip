@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WG) void k_spmm(
     for (int i = tid; i < nx2; i += WG) reinterpret_cast<double2*>(sx)[i] = xsrc[i];
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   for (int s = s0 + wave; s < s1; s += WG / 64) {
     const long long off = sl_off[s];
     const int len = sl_len[s];
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WG) void k_spmm_staged(
     }
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   for (int s = s0 + wave; s < s1; s += WG / 64) {
     const long long off = sl_off[s];
     const int len = sl_len[s];
@@ -208,15 +208,49 @@ __global__ __launch_bounds__(WG) void k_spmm_staged(
 // XS = panel stride in doubles.  XS = 2 TS splits a wide panel by columns: two workgroups per
 // block (neighbours in the dispatch order of one XCD, so the second one finds the matrix slice
 // in that XCD's L2), each staging and computing TS of the XS columns.
-template <int TS, int XS>
-__global__ __launch_bounds__(WG) void k_spmm_runs(
+//
+// GRAM (4-column panels): the workgroup also leaves the block's share of [Y | R]^T X -- the
+// Gram block the ECG iteration forms right after A P (ecg.c:425-436: W = AP^T P, G^T = R^T P)
+// -- in gpart[gbase + logical] (8 x 4, column major, the layout of k_gram<4, 2>), so that the
+// panels are not read a second time.  Y rows sit one per lane in registers and X rows in the
+// staging area: a 4 x 4 transpose inside each quad of lanes puts 16 rows x 4 columns into the
+// operand layout of v_mfma_f64_4x4x4 (lane 4g + c = column c of row g), four of which cover the
+// 64 rows of a slice; R is read in that layout directly.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// a[s] of lane c  <-  a[c] of lane s, within each quad of lanes (c = lane & 3)
+__device__ __forceinline__ void quad_transpose4(double (&a)[4], int c) {
+  const bool b0 = c & 1, b1 = c & 2;
+#pragma unroll
+  for (int p = 0; p < 4; p += 2) {          // partner lane ^ 1 (quad_perm [1,0,3,2]), registers (p, p+1)
+    const double recv = dpp_mov_f64<0xB1>(b0 ? a[p] : a[p + 1]);
+    a[p] = b0 ? recv : a[p];
+    a[p + 1] = b0 ? a[p + 1] : recv;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {             // partner lane ^ 2 (quad_perm [2,3,0,1]), registers (p, p+2)
+    const double recv = dpp_mov_f64<0x4E>(b1 ? a[p] : a[p + 2]);
+    a[p] = b1 ? recv : a[p];
+    a[p + 2] = b1 ? a[p + 2] : recv;
+  }
+}
+
+template <int TS, int XS, bool GRAM>
+__device__ __forceinline__ void spmm_runs_body(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
     const unsigned short* __restrict__ slot16, const double* __restrict__ val,
     const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
     const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
     const int* __restrict__ order, int nlist, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y) {
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
+  static_assert(!GRAM || (TS == 4 && XS == 4), "the fused Gram block is built for 4-column panels");
   extern __shared__ double sx[];
   constexpr int NS = XS / TS;
   const int cpx = (nlist + 7) >> 3;
@@ -247,7 +281,9 @@ __global__ __launch_bounds__(WG) void k_spmm_runs(
     if (tid < 2 * H) dst[(size_t)(nown + next) * H + tid] = make_double2(0.0, 0.0);
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
+  // (the wavefront's number as a scalar: the slice loop and everything indexed by it stay in SGPRs)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  double gw = 0.0, gg = 0.0;      // GRAM: D[i][j] of the lane's 4 x 4 block (lane = 16 i + 4 q + j)
   for (int s = s0 + wave; s < s1; s += WG / 64) {
     const long long off = sl_off[s];
     const int len = sl_len[s];
@@ -256,6 +292,9 @@ __global__ __launch_bounds__(WG) void k_spmm_runs(
     double acc[TS];
 #pragma unroll
     for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+    int touch = 0;
+    if constexpr (GRAM)       // the slice's rows of R on their way into the L2 while the matrix streams
+      touch = reinterpret_cast<const int*>(Rg)[((size_t)sl_row0[s] + min(lane, sl_nrows[s] - 1)) * 8];
 #pragma unroll 4
     for (int k = 0; k < len; ++k) {
       const int slot = cp[(size_t)k * 64];
@@ -267,12 +306,74 @@ __global__ __launch_bounds__(WG) void k_spmm_runs(
       spmm_fma_row<TS>(acc, v1, xr + TS);
       spmm_fma_row<TS>(acc, v2, xr + 2 * TS);
     }
-    if (lane < sl_nrows[s]) {
-      double2* q = reinterpret_cast<double2*>(Y + (size_t)(sl_row0[s] + lane) * XS + coff);
+    const int nr = sl_nrows[s], row_s = sl_row0[s];
+    if (lane < nr) {
+      double2* q = reinterpret_cast<double2*>(Y + (size_t)(row_s + lane) * XS + coff);
 #pragma unroll
       for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
     }
+    if constexpr (GRAM) {
+      const int g4 = lane & ~3, c = lane & 3;
+      asm volatile("" ::"v"(touch));
+      double rv[4], xv[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {         // step st: the quad stands for row g4 + st of the slice
+        const int rr = g4 + st;
+        const bool on = rr < nr;
+        rv[st] = on ? Rg[(size_t)(row_s + rr) * 4 + c] : 0.0;
+        xv[st] = on ? sx[(size_t)(nlow + row_s - r0 + rr) * 4 + c] : 0.0;
+      }
+      double ty[4] = {acc[0], acc[1], acc[2], acc[3]};
+      quad_transpose4(ty, c);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        gw = __builtin_amdgcn_mfma_f64_4x4x4f64(ty[st], xv[st], gw, 0, 0, 0);
+        gg = __builtin_amdgcn_mfma_f64_4x4x4f64(rv[st], xv[st], gg, 0, 0, 0);
+      }
+    }
   }
+  if constexpr (GRAM) {
+    // the four blocks of the lane's row of 16 lanes (row_ror 4 / 8), then the four wavefronts
+    // through the staging area, which no wavefront reads any more after the barrier
+    gw += dpp_mov_f64<0x124>(gw); gw += dpp_mov_f64<0x128>(gw);
+    gg += dpp_mov_f64<0x124>(gg); gg += dpp_mov_f64<0x128>(gg);
+    __syncthreads();
+    if ((lane & 12) == 0) {
+      const int i = lane >> 4, j = lane & 3;
+      sx[wave * 32 + i + 8 * j] = gw;
+      sx[wave * 32 + 4 + i + 8 * j] = gg;
+    }
+    __syncthreads();
+    if (tid < 32)
+      gpart[(size_t)(gbase + logical) * 32 + tid] = ((sx[tid] + sx[32 + tid]) + sx[64 + tid]) + sx[96 + tid];
+  }
+}
+
+template <int TS, int XS>
+__global__ __launch_bounds__(WG) void k_spmm_runs(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, int nlist, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y) {
+  spmm_runs_body<TS, XS, false>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+                                ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
+}
+
+// 4 columns with the Gram block; five wavefronts per SIMD as k_spmm_runs<4, 4> (32 KiB of staging each)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_spmm_runs_gram(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, int nlist, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
+  spmm_runs_body<4, 4, true>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+                             ext_rows, order, nlist, X, Xh, Y, Rg, gpart, gbase);
 }
 
 template <int TS>
@@ -368,7 +469,7 @@ __global__ __launch_bounds__(1024) void k_bj_factor_big(
   double* panel = sm;                        // [row][NB]
   double* D = sm + (size_t)w * NB;           // [NB][NB], lower triangle of the diagonal block
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
   for (int J = 0; J < b; J += NB) {
     const int nbk = (b - J) < NB ? (b - J) : NB;
     for (int e = tid; e < NB * NB; e += nt) {
@@ -510,7 +611,7 @@ __global__ __launch_bounds__(WG) void k_gram_mfma16(int m, const double* __restr
                                                     const double* __restrict__ B,
                                                     double* __restrict__ partials) {
   constexpr int TS = 16, LDP = NPAN * TS;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int col = lane & 15, rsub = lane >> 4;
   mfma_d4 acc[NPAN];
 #pragma unroll
@@ -554,7 +655,7 @@ __global__ __launch_bounds__(WG) void k_gram_mfma8(int m, const double* __restri
                                                    const double* __restrict__ B,
                                                    double* __restrict__ partials) {
   constexpr int TS = 8, LDP = NPAN * TS;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int col = lane & 15, rsub = lane >> 4;
   const double* __restrict__ Ap = (col < TS) ? A0 : A1;      // panel this lane's A column lives in
   const bool a_on = col < LDP, b_on = col < TS;
@@ -779,7 +880,7 @@ __global__ __launch_bounds__(WG) void k_gram(int m, const double* __restrict__ A
 #pragma unroll
       for (int j = 0; j < TI; ++j) acc[i][j] += __shfl_xor(acc[i][j], off);
   __shared__ double red[WG / 64][LDP * TS];
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   if (lane < LPR) {
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -817,6 +918,76 @@ __global__ __launch_bounds__(1024) void k_finish_potrf_alpha(const double* __res
   __threadfence_block();
   __syncthreads();
   potrf_alpha_wg(out, t, T, mu, alpha, info, red, red + 256);
+}
+
+// The [W ; G^T] block of 4-column panels (8 x 4) from many partial blocks (one per workgroup of
+// the SpMM that formed them; 1 MB on the headline problem, which one workgroup needs 24 us to
+// read): FIN32_WG workgroups sum a contiguous share each (32-byte loads, 32 blocks side by
+// side, fixed order) into scratch; the last one to finish (ticket counter) adds
+// the shares in order and, t > 0, factors and forms alpha as k_finish_potrf_alpha does.
+constexpr int FIN32_WG = 64;
+__device__ unsigned g_fin32_ticket = 0;
+__global__ __launch_bounds__(WG) void k_finish32(const double* __restrict__ partials, int nblk,
+                                                 double* scratch, int t, int T, double* out,
+                                                 double* __restrict__ mu, double* __restrict__ alpha,
+                                                 int* __restrict__ info) {
+  __shared__ double red[32 * 32];
+  __shared__ int s_last;
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, e4 = tid & 7, sl = tid >> 3;
+  const int per = (nblk + FIN32_WG - 1) / FIN32_WG;
+  const int b0 = blockIdx.x * per, b1 = min(nblk, b0 + per);
+  const d4* __restrict__ q = reinterpret_cast<const d4*>(partials) + e4;
+  d4 sum = {0.0, 0.0, 0.0, 0.0};
+  int b = b0 + sl;
+  for (; b + 3 * 32 < b1; b += 4 * 32) {
+    d4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = q[(size_t)(b + u * 32) * 8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sum += v[u];
+  }
+  for (; b < b1; b += 32) sum += q[(size_t)b * 8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) red[sl * 32 + e4 * 4 + u] = sum[u];
+  __syncthreads();
+  for (int half = 16; half >= 1; half >>= 1) {       // tree over the 32 slices
+    for (int e = tid; e < half * 32; e += WG) red[e] += red[half * 32 + e];
+    __syncthreads();
+  }
+  // the share goes out with device-scope (write-through) stores, the ticket is taken once they have
+  // completed, and the last workgroup reads the shares with device-scope loads: no fence, which
+  // costs 10 us on gfx950 even when the L2 holds nothing dirty
+  if (tid < 32) __hip_atomic_store(scratch + blockIdx.x * 32 + tid, red[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) s_last = (__hip_atomic_fetch_add(&g_fin32_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
+  __syncthreads();
+  if (!s_last) return;
+  {
+    // eight shares per thread, all loads in flight at once (one after the other they cost 0.3 us each)
+    const int e = tid & 31, g8 = tid >> 5;
+    double v[FIN32_WG / 8];
+#pragma unroll
+    for (int u = 0; u < FIN32_WG / 8; ++u)
+      v[u] = __hip_atomic_load(scratch + (g8 * (FIN32_WG / 8) + u) * 32 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double tot = 0.0;
+#pragma unroll
+    for (int u = 0; u < FIN32_WG / 8; ++u) tot += v[u];
+    red[g8 * 32 + e] = tot;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    double tot = red[tid];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) tot += red[g * 32 + tid];
+    out[tid] = tot;
+  }
+  if (tid == 0) __hip_atomic_store(&g_fin32_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t > 0) {
+    __threadfence_block();
+    __syncthreads();
+    potrf_alpha_wg(out, t, T, mu, alpha, info, red, red + 256);
+  }
 }
 
 // t x t upper Cholesky, one lane (t <= 16).  LAPACK dpotf2 'U': on failure
@@ -920,7 +1091,7 @@ __device__ __forceinline__ void block_sum_cols(double (&v)[TS], double* __restri
   for (int off = 1; off < 64; off <<= 1)
 #pragma unroll
     for (int c = 0; c < TS; ++c) v[c] += __shfl_xor(v[c], off);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (lane == 0)
 #pragma unroll
     for (int c = 0; c < TS; ++c) red[wave][c] = v[c];
@@ -1064,7 +1235,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, c
   __shared__ double su[16 * 16];    // U (column major, leading dimension 16, identity beyond t)
   __shared__ double si[16 * 16];    // Ui = U^-1
   __shared__ double sb[16 * 16];    // B = Ui alpha (16 x 16, zero beyond t x nc)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lo = lane & 15, hi = lane >> 4;
   for (int e = tid; e < 256; e += WG) {
     const int i = e & 15, j = e >> 4;
@@ -1261,7 +1432,7 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_h
                                                         const double* __restrict__ V1,
                                                         double* __restrict__ Z) {
   constexpr int TS = 16;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lo = lane & 15, hi = lane >> 4;
   // B[k][j] = -beta(k, j), k = 4s + hi (s < 4: rows of beta that meet V0, s >= 4: V1), j = lo
   double bneg[8];
@@ -1312,7 +1483,7 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma8(int m, int a_lo, int a_hi
                                                        const double* __restrict__ V1,
                                                        double* __restrict__ Z) {
   constexpr int TS = 8;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lo = lane & 15, hi = lane >> 4;
   double bneg[4];
   bool von[4];
@@ -2268,7 +2439,7 @@ __global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_forward(nd_args a, const in
   const int* __restrict__ rows = a.rows + a.rows_off[s];
   const int* __restrict__ src = a.src + 2 * (size_t)a.rows_off[s];
   const int cc0 = a.ccoff[2 * s], cc1 = a.ccoff[2 * s + 1];
-  const int tid = threadIdx.x, rl = tid % ND_CHUNK, q = tid / ND_CHUNK;
+  const int tid = threadIdx.x, rl = tid % ND_CHUNK, q = __builtin_amdgcn_readfirstlane(tid / ND_CHUNK);
   const int r = r0 + rl;
   const bool on = r < f;
   const int hi = min(r, n);                   // columns 0 .. hi - 1 of front row r
@@ -2340,7 +2511,7 @@ __global__ __launch_bounds__(64 * W) void k_nd_backward(nd_args a, const int* __
   const int n = a.n[s], f = n + a.m[s], ldb = PA_ND_LD(n);
   const double* __restrict__ U = a.B + a.offB[s];
   const int* __restrict__ rows = a.rows + a.rows_off[s];
-  const int tid = threadIdx.x, kk = tid & 63, q = tid >> 6;
+  const int tid = threadIdx.x, kk = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = k0 + kk;
   const bool on = k < n;
   const int gtot = (f + 15) >> 4;
@@ -2415,10 +2586,33 @@ inline int grid_rows(int m, int per_thread_rows = 1) {
     default: snprintf(g_kerr, sizeof(g_kerr), "unsupported panel stride %d", ts); return 1; \
   }
 
+// A Gram block requested from the next SpMM that reads X and writes Y (pa_k_spmm_gram_arm):
+// k_spmm_runs_gram leaves one partial block per workgroup, `count` of them so far.
+static struct {
+  const double* X; const double* Y; const double* R;
+  double* partials; int cap, count, armed;
+} g_sg;
+
+static long long g_sg_launches = 0;
+
 template <int TS>
 static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, const double* X,
                        const double* Xh, double* Y) {
   if (nlist <= 0) return 0;
+  if constexpr (TS == 4) {
+    const size_t lds = (size_t)pl->stage_cap * TS * 8;
+    if (g_sg.armed && pl->runs && lds <= 64 * 1024 && X == g_sg.X && Y == g_sg.Y && g_sg.count >= 0 &&
+        g_sg.count + nlist <= g_sg.cap) {
+      const int cpx = (nlist + 7) / 8;
+      PA_LAUNCH(k_spmm_runs_gram, dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice, pl->blk_ext_off,
+                pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y, g_sg.R, g_sg.partials, g_sg.count);
+      g_sg.count += nlist;
+      ++g_sg_launches;
+      return kfail("k_spmm_runs");
+    }
+    if (g_sg.armed && X == g_sg.X && Y == g_sg.Y) g_sg.count = -1;    // this product leaves no Gram block
+  }
   if (pl->runs) {
     // a plan cut for half the panel stride: two workgroups per block, 8 of the 16 columns each;
     // for the whole stride (pl->runs_cols == TS): one workgroup, the matrix is streamed once
@@ -2712,10 +2906,38 @@ extern "C" {
 int pa_bj_max_R(void) { return 8; }
 int pa_gram_max_blocks(void) { return GRAM_MAX_BLOCKS; }
 
+void pa_k_spmm_gram_arm(const double* X, const double* Y, const double* R, double* partials, int cap) {
+  g_sg.X = X; g_sg.Y = Y; g_sg.R = R; g_sg.partials = partials; g_sg.cap = cap; g_sg.count = 0;
+  g_sg.armed = (X && Y && R && partials && cap > 0);
+}
+
+long long pa_k_spmm_gram_launches(void) { return g_sg_launches; }
+
+void pa_k_spmm_gram_disarm(void) { g_sg.armed = 0; g_sg.count = 0; }
+
+/* The number of partial blocks the armed products X -> Y have left since the request (0: none,
+ * or the operator was applied with another kernel); the request stays armed for the same pointers. */
+int pa_k_spmm_gram_take(const double* X, const double* Y) {
+  if (!g_sg.armed || X != g_sg.X || Y != g_sg.Y) return 0;
+  const int n = g_sg.count > 0 ? g_sg.count : 0;
+  g_sg.armed = 0; g_sg.count = 0;
+  return n;
+}
+
+int pa_finish32_scratch_blocks(void) { return FIN32_WG; }
+
+int pa_k_finish32(const double* partials, int nblk, double* scratch, int t, int T, double* out, double* mu,
+                  double* alpha, int* info) {
+  PA_LAUNCH(k_finish32, dim3(FIN32_WG), dim3(WG), 0, cur_stream(), partials, nblk, scratch, t, T, out, mu,
+            alpha, info);
+  return kfail("k_finish32");
+}
+
 int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo, double* Y,
               int phase) {
   const int* order = pl->order;
   int n = pl->nblk;
+  if (phase != 1 && g_sg.armed && X == g_sg.X && Y == g_sg.Y) g_sg.count = 0;   /* a new product starts */
   if (phase == 0) n = pl->n_interior;
   else if (phase == 1) { order += pl->n_interior; n = pl->nblk - pl->n_interior; }
   const double* Xh = Xhalo ? Xhalo : X;

@@ -1189,6 +1189,16 @@ int preAlps_hip_prepare_operator(int enlFac) {
   return 0;
 }
 
+int pa_operator_gram_blocks(int ts) {
+  pa_operator_t* o = &g_op;
+  /* opt-in: measured on the headline problem, the SpMM with the block takes 165.6 us instead of 148.9 us
+   * and the sum 8.7 us, against 19.8 + 8.3 us for k_gram + its sum -- 2.7 us per iteration, and the SpMM's
+   * own roofline figure drops */
+  if (!o->info.built || g_plan_only || ts != 4 || !env_int("PREALPS_SPMM_GRAM", 0)) return 0;
+  if (o->plan_ts != ts && build_plan(o, ts)) return 0;
+  return o->plan.runs ? o->plan.nblk : 0;
+}
+
 /* AX = A X for the X->info.n current columns (operator.c:334-351). */
 int preAlps_BlockOperator(CPLM_Mat_Dense_t* X, CPLM_Mat_Dense_t* AX) {
   pa_operator_t* o = &g_op;
@@ -1237,6 +1247,7 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "halo_rows")) *value = o->info.halo;
   else if (!strcmp(key, "send_rows")) *value = o->nsend;
   else if (!strcmp(key, "spmm_blocks")) *value = o->plan.nblk;
+  else if (!strcmp(key, "spmm_gram_launches")) *value = (double)pa_k_spmm_gram_launches();
   else if (!strcmp(key, "spmm_slices")) *value = o->plan.nslices;
   else if (!strcmp(key, "spmm_stored_entries")) *value = o->sell_entries;
   else if (!strcmp(key, "spmm_stream_bytes")) *value = o->stream_bytes;

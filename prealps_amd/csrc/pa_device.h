@@ -97,6 +97,18 @@ typedef struct {
 /* phase 0: interior blocks, 1: halo-reading blocks, 2: all */
 int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo,
               double* Y, int phase);
+/* Ask the next product X -> Y of pa_k_spmm (4-column panels, run plan) to leave the partial
+ * blocks of [Y | R]^T X (8 x 4 each, the layout of pa_k_gram with two panels) in `partials`
+ * (room for cap blocks); pa_k_spmm_gram_take returns how many there are (0: the product ran
+ * without them) and ends the request; pa_k_finish32 sums them (t > 0: and factors, as
+ * pa_k_gram_finish does). */
+void pa_k_spmm_gram_arm(const double* X, const double* Y, const double* R, double* partials, int cap);
+void pa_k_spmm_gram_disarm(void);
+long long pa_k_spmm_gram_launches(void);   /* launches of the SpMM with the Gram block so far */
+int pa_k_spmm_gram_take(const double* X, const double* Y);
+int pa_k_finish32(const double* partials, int nblk, double* scratch, int t, int T, double* out, double* mu,
+                  double* alpha, int* info);       /* scratch: pa_finish32_scratch_blocks() x 32 doubles */
+int pa_finish32_scratch_blocks(void);
 /* sendbuf[i*ts + c] = X[idx[i]*ts + c] */
 int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendbuf);
 

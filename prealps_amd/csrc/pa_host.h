@@ -70,6 +70,9 @@ typedef struct {
   int halo;         /* halo rows */
 } pa_operator_info_t;
 const pa_operator_info_t* pa_operator_info(void);
+/* Workgroups of the SpMM at panel stride ts when it can leave the ECG Gram block behind
+ * (pa_k_spmm_gram_arm: run plan, 4 columns); builds the plan if need be.  0: it cannot. */
+int pa_operator_gram_blocks(int ts);
 
 int pa_panel_stride(int enlFac);
 static inline int pa_desc_stride(const CPLM_Mat_Dense_t* A) { return A->info.lda; }

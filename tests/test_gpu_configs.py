@@ -700,6 +700,50 @@ print("shard ok")
 """
 
 
+_SPMM_GRAM_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import prealps_amd as pa
+from prealps_amd import gen
+from oracle import oracle as O
+import scipy.sparse as sp
+rp, ci, v = gen.elasticity3d_csr(9)
+part, P = gen.box_partition_nodes(9, (3, 3, 3))
+A = sp.csr_matrix((v, ci, rp), shape=(len(rp) - 1, len(rp) - 1))
+B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, P)
+rhs = None
+for shard in (None, (0, 3)):
+    prob = pa.EcgProblem(rp, ci, v, P, part, scale=True, device=0, **({"shard": shard} if shard else {}))
+    rhs = prob.reference_rhs()
+    if shard:      # the rank's own diagonal block (test_one_shard_rehearsal_solves_its_diagonal_block)
+        p0, p1 = shard[0] * P // shard[1], (shard[0] + 1) * P // shard[1]
+        lo, hi = int(rowpos[p0]), int(rowpos[p1])
+        Bs, rps = sp.csr_matrix(B[lo:hi][:, lo:hi]), (rowpos[p0:p1 + 1] - lo).astype(np.int32)
+        assert p0 %% 4 == 0
+    else:
+        Bs, rps = B, rowpos
+    before = prob.stat("spmm_gram_launches")
+    for alg_g, alg_o in ((pa.ORTHODIR, O.ORTHODIR), (pa.ORTHOMIN, O.ORTHOMIN)):
+        got = prob.solve(rhs, 4, ortho_alg=alg_g, max_iter=400)
+        ref = O.ECG(Bs, rps, 4, alg_o, O.NO_BS_RED, 1e-5, 400).solve(rhs)
+        assert got.iters == ref["iters"] and got.iters >= 8, (got.iters, ref["iters"])
+        np.testing.assert_allclose(got.res[:20], ref["res"][:20], rtol=1e-8)
+        np.testing.assert_allclose(got.x, ref["x"], rtol=1e-5, atol=1e-7 * np.abs(ref["x"]).max())
+    assert prob.stat("spmm_runs") == 1.0 and prob.stat("spmm_gram_launches") - before >= 16, prob.stat("spmm_gram_launches") - before
+    prob.close()
+print("spmm gram ok")
+"""
+
+
+def test_spmm_leaves_the_gram_block_behind():
+    """PREALPS_SPMM_GRAM=1: k_spmm_runs_gram forms [AP | R]^T P while it computes AP (one partial block per
+    workgroup, k_finish32 sums them): Orthodir and Orthomin at 4 columns, in one process and in the one-shard
+    rehearsal, where the interior and the halo-reading halves of the SpMM each leave their share."""
+    r = subprocess.run([sys.executable, "-c", _SPMM_GRAM_SNIPPET % ROOT], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PREALPS_SPMM_GRAM="1"))
+    assert r.returncode == 0 and "spmm gram ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+
+
 def test_hip_graph_replay_matches_the_oracle():
     """PREALPS_ECG_GRAPH / preAlps_hip_graphs(1): the two halves of an iteration captured on their second pass
     and replayed afterwards (six pointer-rotation phases), Orthodir and Orthomin, 4 and 8 columns."""
