@@ -767,7 +767,7 @@ __device__ __forceinline__ void potrf_upper_wg(double* W, int t, int* info) {
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) *info = s_fail;
+    if (threadIdx.x == 0 && info) *info = s_fail;
   } else if (threadIdx.x == 0) {
     int fail = 0;
     for (int j = 0; j < t; ++j) {
@@ -782,7 +782,7 @@ __device__ __forceinline__ void potrf_upper_wg(double* W, int t, int* info) {
         W[j + t * i] = s / d;
       }
     }
-    *info = fail;
+    if (info) *info = fail;
   }
   __syncthreads();
 }
@@ -806,8 +806,9 @@ __device__ __forceinline__ void potrf_alpha_wg(const double* buf, int t, int T, 
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < t * t; e += nt) mu[e] = W[e];
-  for (int e = threadIdx.x; e < t * T; e += nt) alpha[e] = G[e];
+  // (mu / alpha / info may be null: the factor and alpha stay in W and G for the caller)
+  if (mu) for (int e = threadIdx.x; e < t * t; e += nt) mu[e] = W[e];
+  if (alpha) for (int e = threadIdx.x; e < t * T; e += nt) alpha[e] = G[e];
 }
 
 // Residual norm from the per-workgroup column sums: fixed-order tree over WG threads.
@@ -815,7 +816,7 @@ __device__ __forceinline__ void potrf_alpha_wg(const double* buf, int t, int T, 
 // (pinned, device-visible) receives the same two values when given.
 __device__ __forceinline__ void trace_finish_wg(const double* rtr, int nblk, int ts, int nc,
                                                 double* res2, const int* info, double* host,
-                                                double* red) {
+                                                double* red, double seq = 0.0) {
   double s = 0.0;
   for (int b = threadIdx.x; b < nblk; b += WG)
     for (int c = 0; c < nc; ++c) s += rtr[(size_t)b * ts + c];
@@ -828,7 +829,13 @@ __device__ __forceinline__ void trace_finish_wg(const double* rtr, int nblk, int
   if (threadIdx.x == 0) {
     const double r2 = red[0], st = info ? (double)info[0] : 0.0;
     res2[0] = r2; res2[1] = st;
-    if (host) { host[0] = r2; host[1] = st; __threadfence_system(); }
+    // host[2] = seq (when given) tells a polling host that the two words are there (pa_k_note_seq)
+    if (host) {
+      __hip_atomic_store(host, r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host + 1, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+      if (seq != 0.0) __hip_atomic_store(host + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -904,6 +911,32 @@ __global__ __launch_bounds__(1024) void k_finish(const double* __restrict__ part
   // several workgroups (large blocks, 16-column panels): 64 elements at a time each
   if (gridDim.x > 1) finish_sum<1024>(partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out, red, 64, blockIdx.x, gridDim.x);
   else finish_sum<1024>(partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out, red);
+}
+
+// k_finish and k_trace_finish in one launch: the Gram block that is about to be all-reduced and,
+// right behind it (res2), the squared residual norm from the column sums the update kernel left
+// (same order of additions as k_trace_finish), so that one collective carries both.
+__global__ __launch_bounds__(1024) void k_finish_trace(const double* __restrict__ partials, int nblk,
+                                                     int npan, int ts, int a_lo, int a_hi, int nb,
+                                                     double* __restrict__ out, int ld_out,
+                                                     const double* __restrict__ rtr, int rtr_nblk, int nc,
+                                                     double* __restrict__ res2, const int* __restrict__ info) {
+  __shared__ double red[1024];
+  finish_sum<1024>(partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out, red);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid < WG) {
+    double s = 0.0;
+    for (int b = tid; b < rtr_nblk; b += WG)
+      for (int c = 0; c < nc; ++c) s += rtr[(size_t)b * ts + c];
+    red[tid] = s;
+  }
+  __syncthreads();
+  for (int off = WG / 2; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) { res2[0] = red[0]; res2[1] = info ? (double)info[0] : 0.0; }
 }
 
 // k_finish followed by k_potrf_alpha on its output, one launch (single-process runs, where no
@@ -1157,17 +1190,24 @@ __global__ void k_potrf_alpha(const double* __restrict__ buf, int t, int T, doub
 
 // P <- P U^-1, AP <- AP U^-1, X += P alpha, R -= AP alpha and the column sums of
 // R^2 in one pass over the four panels (ecg.c:434-435 + :500-501 + :250).
+// gram != null (runs of several processes, where an all-reduce of [W ; G^T] sits between the Gram
+// kernel and this one): every workgroup factors W and forms alpha itself (k_potrf_alpha's
+// arithmetic, a microsecond), workgroup 0 stores them and the status -- one launch less.
 template <int TS>
-__global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, const double* __restrict__ U,
-                                                    const double* __restrict__ alpha,
+__global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, double* U, double* alpha,
                                                     double* __restrict__ P, double* __restrict__ AP,
                                                     double* __restrict__ X, double* __restrict__ R,
-                                                    double* __restrict__ rtr) {
+                                                    double* __restrict__ rtr, const double* gram, int* info) {
   __shared__ double su[TS * TS];
   __shared__ double sd[TS];
   __shared__ double sa[TS * TS];
-  for (int e = threadIdx.x; e < t * t; e += WG) su[e] = U[e];
-  for (int e = threadIdx.x; e < t * nc; e += WG) sa[e] = alpha[e];
+  if (gram) {
+    const bool first = blockIdx.x == 0;
+    potrf_alpha_wg(gram, t, nc, first ? U : nullptr, first ? alpha : nullptr, first ? info : nullptr, su, sa);
+  } else {
+    for (int e = threadIdx.x; e < t * t; e += WG) su[e] = U[e];
+    for (int e = threadIdx.x; e < t * nc; e += WG) sa[e] = alpha[e];
+  }
   __syncthreads();
   if (threadIdx.x < t) sd[threadIdx.x] = 1.0 / su[threadIdx.x + t * threadIdx.x];
   __syncthreads();
@@ -1226,17 +1266,26 @@ __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, const 
 // TS = 16: one tile per panel.  TS = 8: [P | AP] is one 16-wide A operand, blockdiag(Ui, Ui) and
 // [B 0; 0 -B] the B operands, [X | R] the accumulator.
 template <int TS>
-__global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, const double* __restrict__ U,
-                                                         const double* __restrict__ alpha,
+__global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, double* Ug, double* alphag,
                                                          double* __restrict__ P, double* __restrict__ AP,
                                                          double* __restrict__ X, double* __restrict__ R,
-                                                         double* __restrict__ rtr) {
+                                                         double* __restrict__ rtr, const double* gram, int* info) {
   static_assert(TS == 8 || TS == 16, "matrix-core variant: panels of 8 or 16 columns");
   __shared__ double su[16 * 16];    // U (column major, leading dimension 16, identity beyond t)
   __shared__ double si[16 * 16];    // Ui = U^-1
   __shared__ double sb[16 * 16];    // B = Ui alpha (16 x 16, zero beyond t x nc)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lo = lane & 15, hi = lane >> 4;
+  __shared__ double sw[16 * 16];    // gram != null: U and alpha as this workgroup computes them (k_trsm_update)
+  __shared__ double sg[16 * 16];
+  const double* U = Ug;
+  const double* alpha = alphag;
+  if (gram) {
+    const bool first = blockIdx.x == 0;
+    potrf_alpha_wg(gram, t, nc, first ? Ug : nullptr, first ? alphag : nullptr, first ? info : nullptr, sw, sg);
+    __syncthreads();
+    U = sw; alpha = sg;
+  }
   for (int e = tid; e < 256; e += WG) {
     const int i = e & 15, j = e >> 4;
     su[e] = (i < t && j < t) ? U[i + t * j] : (i == j ? 1.0 : 0.0);
@@ -1381,9 +1430,9 @@ __global__ __launch_bounds__(WG) void k_colnorm2(int m, const double* __restrict
 
 __global__ __launch_bounds__(WG) void k_trace_finish(const double* __restrict__ rtr, int nblk,
                                                      int ts, int nc, double* __restrict__ res2,
-                                                     const int* __restrict__ info, double* host) {
+                                                     const int* __restrict__ info, double* host, double seq) {
   __shared__ double red[WG];
-  trace_finish_wg(rtr, nblk, ts, nc, res2, info, host, red);
+  trace_finish_wg(rtr, nblk, ts, nc, res2, info, host, red, seq);
 }
 
 // Z(:, :nc) -= [V0(:, :a_lo) | V1(:, :a_hi)] beta
@@ -1392,8 +1441,17 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
                                                  const double* __restrict__ beta, int ldb,
                                                  const double* __restrict__ V0,
                                                  const double* __restrict__ V1,
-                                                 double* __restrict__ Z) {
+                                                 double* __restrict__ Z,
+    const double* note_src, double* note_host, double note_seq) {
   __shared__ double sb[2 * TS * TS];
+  // (note_host: two words the host is waiting for -- the all-reduced residual norm and the
+  // factorisation status next to beta -- go out to pinned memory from here: no copy, no extra launch)
+  if (note_host && blockIdx.x == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(note_host, note_src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(note_host + 1, note_src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (note_seq != 0.0) __hip_atomic_store(note_host + 2, note_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int na = a_lo + a_hi;
   for (int e = threadIdx.x; e < na * nc; e += WG) sb[e] = beta[(e % na) + ldb * (e / na)];
   __syncthreads();
@@ -1430,8 +1488,17 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_h
                                                         const double* __restrict__ beta, int ldb,
                                                         const double* __restrict__ V0,
                                                         const double* __restrict__ V1,
-                                                        double* __restrict__ Z) {
+                                                        double* __restrict__ Z,
+    const double* note_src, double* note_host, double note_seq) {
   constexpr int TS = 16;
+  // (note_host: two words the host is waiting for -- the all-reduced residual norm and the
+  // factorisation status next to beta -- go out to pinned memory from here: no copy, no extra launch)
+  if (note_host && blockIdx.x == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(note_host, note_src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(note_host + 1, note_src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (note_seq != 0.0) __hip_atomic_store(note_host + 2, note_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lo = lane & 15, hi = lane >> 4;
   // B[k][j] = -beta(k, j), k = 4s + hi (s < 4: rows of beta that meet V0, s >= 4: V1), j = lo
@@ -1481,8 +1548,17 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma8(int m, int a_lo, int a_hi
                                                        const double* __restrict__ beta, int ldb,
                                                        const double* __restrict__ V0,
                                                        const double* __restrict__ V1,
-                                                       double* __restrict__ Z) {
+                                                       double* __restrict__ Z,
+    const double* note_src, double* note_host, double note_seq) {
   constexpr int TS = 8;
+  // (note_host: two words the host is waiting for -- the all-reduced residual norm and the
+  // factorisation status next to beta -- go out to pinned memory from here: no copy, no extra launch)
+  if (note_host && blockIdx.x == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(note_host, note_src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(note_host + 1, note_src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (note_seq != 0.0) __hip_atomic_store(note_host + 2, note_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lo = lane & 15, hi = lane >> 4;
   double bneg[4];
@@ -2577,6 +2653,17 @@ inline int grid_rows(int m, int per_thread_rows = 1) {
 
 }  // namespace
 
+// Sequence number for the next launch that writes its two words to pinned host memory (host[2] =
+// seq behind them): the host then polls that word instead of waiting for an event, whose record
+// costs the stream 5-6 us of idle time.  One-shot: taken by that launch, 0 = no number.
+static double g_note_seq = 0.0;
+static inline double take_note_seq(const double* host) {
+  if (!host) return 0.0;
+  const double v = g_note_seq;
+  g_note_seq = 0.0;
+  return v;
+}
+
 #define TS_DISPATCH(ts, CALL)                      \
   switch (ts) {                                    \
     case 2: { constexpr int TS_ = 2; CALL; } break;   \
@@ -2906,6 +2993,8 @@ extern "C" {
 int pa_bj_max_R(void) { return 8; }
 int pa_gram_max_blocks(void) { return GRAM_MAX_BLOCKS; }
 
+void pa_k_note_seq(double seq) { g_note_seq = seq; }
+
 void pa_k_spmm_gram_arm(const double* X, const double* Y, const double* R, double* partials, int cap) {
   g_sg.X = X; g_sg.Y = Y; g_sg.R = R; g_sg.partials = partials; g_sg.cap = cap; g_sg.count = 0;
   g_sg.armed = (X && Y && R && partials && cap > 0);
@@ -3007,6 +3096,20 @@ int pa_k_gram_finish(int m, int ts, const double* A0, const double* A1, const do
   return pa_k_finish(partials, nblk, A1 ? 2 : 1, ts, a_lo, a_hi, nb, out, ld_out);
 }
 
+int pa_k_gram_finish_trace(int m, int ts, const double* A0, const double* A1, const double* B, double* partials,
+                           int a_lo, int a_hi, int nb, double* out, int ld_out, const double* rtr_partials,
+                           int rtr_nblk, int nc, double* res2, const int* info) {
+  int nblk = 0;
+  const int ne = (a_lo + a_hi) * nb;
+  if (ne <= 0 || ne > 128)     /* no Gram block, or one that several workgroups sum: the two launches */
+    return pa_k_trace_finish(rtr_partials, rtr_nblk, ts, nc, res2, info) ||
+           pa_k_gram_finish(m, ts, A0, A1, B, partials, a_lo, a_hi, nb, out, ld_out, 0, 0, NULL, NULL, NULL);
+  if (pa_k_gram(m, ts, A0, A1, B, partials, &nblk)) return 1;
+  PA_LAUNCH(k_finish_trace, dim3(1), dim3(1024), 0, cur_stream(), partials, nblk, A1 ? 2 : 1, ts, a_lo, a_hi, nb,
+            out, ld_out, rtr_partials, rtr_nblk, nc, res2, info);
+  return kfail("k_finish_trace");
+}
+
 int pa_k_finish(const double* partials, int nblk, int npan, int ts, int a_lo, int a_hi, int nb,
                 double* out, int ld_out) {
   const int ne = (a_lo + a_hi) * nb;
@@ -3047,7 +3150,7 @@ int pa_k_update_xr(int m, int ts, int t, int nc, const double* alpha, const doub
   if (kfail("k_update_xr")) return 1;
   if (trace_nc <= 0) return 0;
   PA_LAUNCH(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, blocks, ts, trace_nc,
-                     res2, info, host);
+                     res2, info, host, take_note_seq(host));
   return kfail("k_trace_finish");
 }
 
@@ -3056,9 +3159,9 @@ int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha,
   return kfail("k_potrf_alpha");
 }
 
-int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double* alpha, double* P,
+int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, double* P,
                      double* AP, double* X, double* R, double* rtr_partials, int* nblk, int trace_nc,
-                     double* res2, const int* info, double* host) {
+                     double* res2, int* info, double* host, const double* gram) {
   int blocks = grid_rows(m, 2);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
@@ -3066,17 +3169,17 @@ int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double
   static int use_mfma = -1;
   if (use_mfma < 0) { const char* e = getenv("PREALPS_TRSM_MFMA"); use_mfma = e ? atoi(e) : 1; }
   if (ts == 16 && use_mfma)
-    PA_LAUNCH((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials);
+    PA_LAUNCH((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info);
   else if (ts == 8 && use_mfma)
-    PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials);
+    PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info);
   else {
     TS_DISPATCH(ts, PA_LAUNCH((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
-                                       t, nc, U, alpha, P, AP, X, R, rtr_partials));
+                                       t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info));
   }
   if (kfail("k_trsm_update")) return 1;
   if (trace_nc <= 0) return 0;
   PA_LAUNCH(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, blocks, ts, trace_nc,
-                     res2, info, host);
+                     res2, (const int*)info, host, take_note_seq(host));
   return kfail("k_trace_finish");
 }
 
@@ -3092,25 +3195,26 @@ int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nbl
 int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2,
                       const int* info) {
   PA_LAUNCH(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, nblk, ts, nc,
-                     res2, info, (double*)nullptr);
+                     res2, info, (double*)nullptr, 0.0);
   return kfail("k_trace_finish");
 }
 
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
-                  const double* V0, const double* V1, double* Z) {
+                  const double* V0, const double* V1, double* Z, const double* note_src, double* note_host) {
   if (nc <= 0) return 0;
+  const double seq_ = take_note_seq(note_host);
   if (ts == 16) {   // matrix cores (k_update_z_mfma16), one 16-row tile per wavefront and step
     PA_LAUNCH(k_update_z_mfma16, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
-                       beta, ldb, V0, V1, Z);
+                       beta, ldb, V0, V1, Z, note_src, note_host, seq_);
     return kfail("k_update_z_mfma16");
   }
   if (ts == 8) {
     PA_LAUNCH(k_update_z_mfma8, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
-                       beta, ldb, V0, V1, Z);
+                       beta, ldb, V0, V1, Z, note_src, note_host, seq_);
     return kfail("k_update_z_mfma8");
   }
   TS_DISPATCH(ts, PA_LAUNCH((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
-                                     cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z));
+                                     cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z, note_src, note_host, seq_));
   return kfail("k_update_z");
 }
 

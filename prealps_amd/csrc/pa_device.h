@@ -22,6 +22,8 @@ const char* pa_rt_error(void);
 void* pa_rt_malloc(size_t bytes);
 void pa_rt_free(void* d);
 void* pa_rt_host_alloc(size_t bytes);
+void* pa_rt_host_alloc_coherent(size_t bytes);   /* fine-grained: a kernel writes, the host polls */
+int pa_rt_stream_state(void);                     /* 0: work pending, 1: idle, -1: error */
 void pa_rt_host_free(void* h);
 int pa_rt_memset(void* d, int v, size_t bytes);
 int pa_rt_h2d(void* d, const void* h, size_t bytes);
@@ -126,6 +128,11 @@ int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B
 int pa_k_gram_finish(int m, int ts, const double* A0, const double* A1, const double* B,
                      double* partials, int a_lo, int a_hi, int nb, double* out, int ld_out, int t,
                      int T, double* mu, double* alpha, int* info);
+/* pa_k_gram + one launch that sums the block (as pa_k_finish) and the residual norm (as
+ * pa_k_trace_finish: res2[0] = norm^2, res2[1] = *info). */
+int pa_k_gram_finish_trace(int m, int ts, const double* A0, const double* A1, const double* B, double* partials,
+                           int a_lo, int a_hi, int nb, double* out, int ld_out, const double* rtr_partials,
+                           int rtr_nblk, int nc, double* res2, const int* info);
 int pa_gram_max_blocks(void);
 /* out[i + ld_out*j] = sum over blocks, for rows i < a_lo (panel 0) and
  * a_lo <= i < a_lo + a_hi (panel 1, column i - a_lo), j < nb. */
@@ -152,10 +159,12 @@ int pa_k_update_xr(int m, int ts, int t, int nc, const double* alpha, const doub
 /* buf = [W ; G^T] ((t+T) x t, leading dimension t+T) with W = AP^T P and G = P^T R of the
  * un-normalised P  ->  mu = chol(W) (upper, t x t), alpha = U^-T G (t x T, ld t). */
 int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha, int* info);
-/* pa_k_trsm followed by pa_k_update_xr in one pass over P, AP, X, R. */
-int pa_k_trsm_update(int m, int ts, int t, int nc, const double* U, const double* alpha, double* P,
+/* pa_k_trsm followed by pa_k_update_xr in one pass over P, AP, X, R.  gram != NULL: U and alpha
+ * are outputs -- every workgroup computes them from gram = [W ; G^T] as pa_k_potrf_alpha does
+ * (nc = T) and the first one stores them and *info. */
+int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, double* P,
                      double* AP, double* X, double* R, double* rtr_partials, int* nblk, int trace_nc,
-                     double* res2, const int* info, double* host);
+                     double* res2, int* info, double* host, const double* gram);
 /* Standalone sums of R(:,c)^2 (same layout as above). */
 int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk);
 /* res2[0] = sum over blocks and columns c < nc; res2[1] = *info (0 if info is NULL). */
@@ -164,7 +173,12 @@ int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, doub
 /* Z(:, :nc) -= [V0(:, :a_lo) | V1(:, :a_hi)] beta, beta is (a_lo+a_hi) x nc,
  * leading dimension ldb (ecg.c:354,517). */
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
-                  const double* V0, const double* V1, double* Z);
+                  const double* V0, const double* V1, double* Z, const double* note_src, double* note_host);
+/* note_host != NULL: note_src[0..1] (device) are also written to note_host[0..1] (pinned, device-visible) */
+/* The next launch that writes two words to pinned host memory (pa_k_trsm_update / pa_k_update_xr with
+ * `host`, pa_k_update_z with note_host) also writes host[2] = seq behind them (seq != 0; one-shot), for
+ * a host that polls that word instead of waiting for an event. */
+void pa_k_note_seq(double seq);
 /* dst(:, :nc) = src(:, :nc) (mkl_domatcopy, ecg.c:358,521-523). */
 int pa_k_copy_cols(int m, int ts, int nc, const double* src, double* dst);
 /* A(:, :t) <- A(:, :t) Q, Q is t x t column-major (the effect of LAPACKE_dormqr

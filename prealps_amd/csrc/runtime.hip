@@ -97,7 +97,22 @@ void* pa_rt_host_alloc(size_t bytes) {
   if (e != hipSuccess) { fail(e, "hipHostMalloc"); return nullptr; }
   return p;
 }
+/* fine-grained (host-coherent) pinned memory: words a kernel writes while the host polls them */
+void* pa_rt_host_alloc_coherent(size_t bytes) {
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocCoherent | hipHostMallocMapped);
+  if (e != hipSuccess) { (void)hipGetLastError(); return pa_rt_host_alloc(bytes); }
+  return p;
+}
 void pa_rt_host_free(void* h) { if (h) (void)hipHostFree(h); }
+/* 0: work pending, 1: the library stream is idle, -1: it reports an error */
+int pa_rt_stream_state(void) {
+  hipError_t e = hipStreamQuery(g_cur);
+  if (e == hipErrorNotReady) return 0;
+  if (e == hipSuccess) return 1;
+  fail(e, "hipStreamQuery");
+  return -1;
+}
 
 /* ---- graphs: one ECG iteration segment captured once, replayed afterwards -------------------------
  * While a segment is REPLAYED its host code still runs (pointer rotations, counters), but every

@@ -632,11 +632,13 @@ print("variant ok", prob.stat("spmm_staged"), prob.stat("bj_max_bandwidth"), pro
                                  {"PREALPS_BJ_SPLIT": "1", "PREALPS_BJ_MFMA": "0", "PREALPS_BJ_WIDE_FROM": "448"},
                                  {"PREALPS_BJ_MFMA": "2", "PREALPS_BJ_WIDE_FROM": "448", "PREALPS_TRSM_MFMA": "0"},
                                  {"PREALPS_BJ_SPLIT4": "0", "PREALPS_ECG_FUSE": "0"},
-                                 {"PREALPS_BJ_PAIRS": "0"}])
+                                 {"PREALPS_BJ_PAIRS": "0"},
+                                 {"PREALPS_ECG_POLL": "1", "PREALPS_SPMM_GRAM": "1"}])
 def test_opt_in_kernel_variants(env):
     """Non-temporal SpMM loads (k_spmm<TS,true>), the column-split block solve (PREALPS_BJ_SPLIT),
     the matrix-core block solve at every width, the unsplit 4-column sweep, the four-pass first
-    half, and the narrow-band sweep on plain instead of paired records: same answers as the oracle
+    half, the narrow-band sweep on plain instead of paired records, and the host polling for the residual norm
+    (the default of multi-process runs) in one process: same answers as the oracle
     (Poisson 16^3, 16 slabs, band 256 -> register-set class 5; Poisson 12^3 in 27 boxes, class 2)."""
     r = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET % ROOT], capture_output=True, text=True,
                        env=dict(os.environ, **env), timeout=600)
@@ -751,9 +753,12 @@ def test_hip_graph_replay_matches_the_oracle():
     assert r.returncode == 0 and "graphs ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
 
 
-def test_one_shard_rehearsal_solves_its_diagonal_block():
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_one_shard_rehearsal_solves_its_diagonal_block(overlap):
     """preAlps_hip_loopback (bench.py --shard-of): rank 1 of 4 in one process runs the real multi-process
-    choreography (pack, side-stream exchange, interior / halo-reading SpMM halves) with zero halo rows and
+    choreography (pack, exchange on the main stream and one SpMM launch -- or, PREALPS_HALO_OVERLAP=1,
+    side-stream exchange beside the interior blocks, then the halo-reading ones) with zero halo rows and
     local sums: it must solve exactly the system of its own diagonal block."""
-    r = subprocess.run([sys.executable, "-c", _SHARD_SNIPPET % ROOT], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", _SHARD_SNIPPET % ROOT], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PREALPS_HALO_OVERLAP=overlap))
     assert r.returncode == 0 and "shard ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])

@@ -31,6 +31,8 @@ def _worker(rank, world, port, alg, q):
         os.environ["LOCAL_RANK"] = "0"
         if alg == "fused":
             os.environ["PREALPS_SPMM_RUNS"] = "2"   # halo slots inside the run plan of the SpMM
+        if world == 4 or alg in ("omin", "odir_nd"):   # exchange on the side stream beside the interior blocks (the
+            os.environ["PREALPS_HALO_OVERLAP"] = "1"   # library's choice from 12 M interior nonzeros on); else: main stream
         big = alg == "odir_nd"
         if big:                                      # large blocks: every rank builds sparse (nested dissection) factors
             os.environ["PREALPS_BJ_ND"] = "2"
