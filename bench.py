@@ -376,10 +376,13 @@ def main():
                         "send_rows": int(prob.stat("send_rows")), "bj_blocks": int(prob.stat("bj_parts_local")),
                         "iteration_device_us": 1e6 * dev_s.value / a.steps,
                         "sum_of_phase_device_us": kern, "launch_gap_us": 1e6 * dev_s.value / a.steps - kern,
-                        "note": "one rank of a %d-GPU run on one GPU (preAlps_hip_loopback): its rows, SpMM plan (interior / "
-                                "halo-reading halves, pack, side-stream exchange), block solve and reductions with the "
-                                "collectives replaced by no-ops; value = iterations/s of THIS shard alone, not a "
-                                "multi-GPU measurement" % a.shard_of}
+                        "halo_overlap": os.environ.get("PREALPS_HALO_OVERLAP", "auto"),
+                        "note": "one rank of a %d-GPU run on one GPU (preAlps_hip_loopback): its rows, SpMM plan, pack, "
+                                "exchange (main stream in front of one SpMM launch for small interiors, else side stream "
+                                "beside the interior blocks), block solve and reductions with the collectives replaced "
+                                "by no-ops; sum_of_phase_device_us is measured with a sync after every phase and exceeds "
+                                "the iteration; value = iterations/s of THIS shard alone, not a multi-GPU measurement"
+                                % a.shard_of}
     if rank == 0 and phases:
         phase_table("%s on %d x MI355X (device time, %d iterations)" % ({"odir": "ODIR", "omin": "OMIN", "fused": "F-ODIR"}[a.alg], world, a.phase_iters),
                     world, a.phase_iters, phases, ecg_fields)
