@@ -2507,7 +2507,8 @@ template <int TS, int XS, int Q>
 __global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_forward(nd_args a, const int* __restrict__ cfront,
                                                              const int* __restrict__ crow0,
                                                              const double* __restrict__ in) {
-  __shared__ double ws[ND_STAGE][TS];
+  constexpr int STG = TS >= 16 ? ND_STAGE / 2 : ND_STAGE;   // entries of w staged per round (32 KiB at 8 and 16 columns)
+  __shared__ double ws[STG][TS];
   __shared__ double red[Q > 1 ? Q - 1 : 1][ND_CHUNK][TS];
   const int s = cfront[blockIdx.x], r0 = crow0[blockIdx.x], coff = blockIdx.y * TS;
   const int n = a.n[s], f = n + a.m[s], ld = a.ld[s];
@@ -2529,9 +2530,9 @@ __global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_forward(nd_args a, const in
 #pragma unroll
   for (int c = 0; c < TS; ++c) { acc[c] = 0.0; own[c] = 0.0; }
   if (q == 0 && on && r >= n) nd_gather_w<TS, XS>(a, rows, src, cc0, cc1, r, n, in, coff, own);
-  for (int c0 = 0; c0 < jwg; c0 += ND_STAGE) {
+  for (int c0 = 0; c0 < jwg; c0 += STG) {
     if (c0 > 0) __syncthreads();
-    for (int jj = tid; jj < ND_STAGE; jj += ND_CHUNK * Q) {
+    for (int jj = tid; jj < STG; jj += ND_CHUNK * Q) {
       double w[TS];
 #pragma unroll
       for (int c = 0; c < TS; ++c) w[c] = 0.0;
@@ -2541,11 +2542,11 @@ __global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_forward(nd_args a, const in
       for (int c = 0; c < TS / 2; ++c) wq[c] = make_double2(w[2 * c], w[2 * c + 1]);
     }
     __syncthreads();
-    if (q == 0 && on && r < n && r >= c0 && r < c0 + ND_STAGE) {
+    if (q == 0 && on && r < n && r >= c0 && r < c0 + STG) {
 #pragma unroll
       for (int c = 0; c < TS; ++c) own[c] = ws[r - c0][c];
     }
-    nd_dot<TS, Q, ND_STAGE>(acc, cf, p, (size_t)ld, g, min(gtot, (c0 + ND_STAGE) >> 4), gtot, 0, hi, on, ws, c0);
+    nd_dot<TS, Q, STG>(acc, cf, p, (size_t)ld, g, min(gtot, (c0 + STG) >> 4), gtot, 0, hi, on, ws, c0);
   }
   if constexpr (Q > 1) {
     if (q > 0) {
@@ -2580,7 +2581,7 @@ __global__ __launch_bounds__(ND_CHUNK * Q) void k_nd_forward(nd_args a, const in
 template <int TS, int XS, int W>
 __global__ __launch_bounds__(64 * W) void k_nd_backward(nd_args a, const int* __restrict__ cfront,
                                                         const int* __restrict__ ccol0, double* __restrict__ out) {
-  constexpr int NSTG = TS >= 8 ? 512 : 1024;  // rows of v staged per round
+  constexpr int NSTG = TS >= 16 ? 256 : TS >= 8 ? 512 : 1024;  // rows of v staged per round
   __shared__ double vs[NSTG][TS];
   __shared__ double red[W - 1][ND_COLS][TS];
   const int s = cfront[blockIdx.x], k0 = ccol0[blockIdx.x], coff = blockIdx.y * TS;
@@ -2961,12 +2962,28 @@ static int bj_factor_big_launch(const int* list, int count, int wmax, const int*
   return kfail("k_bj_factor_big");
 }
 
+// 16-column panels: all columns in one pass over the factor (172 VGPRs, two wavefronts per SIMD: 2.6 TB/s
+// of factor bytes) instead of two 8-column passes at 4.5 TB/s each: 4.37 against 5.09 ms per apply on the
+// 64-block elasticity problem.  PREALPS_ND_WIDE16=0: the two passes.
+static int nd_wide16() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PREALPS_ND_WIDE16"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 // one level of the tree; launches of few workgroups put more threads on each output
 template <int XS>
 static int nd_launch_fwd(const nd_args& a, const int* cfront, const int* crow0, int nwg, const double* in) {
   if (nwg <= 0) return 0;
   static int few = -1;
   if (few < 0) { const char* e = getenv("PREALPS_ND_FEW"); few = e ? atoi(e) : 1024; }
+  if constexpr (XS == 16) {                   // all 16 columns in one pass over the factor (nd_wide16)
+    if (nd_wide16()) {
+      if (nwg < few) PA_LAUNCH((k_nd_forward<16, 16, 2>), dim3(nwg), dim3(ND_CHUNK * 2), 0, cur_stream(), a, cfront, crow0, in);
+      else PA_LAUNCH((k_nd_forward<16, 16, 1>), dim3(nwg), dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, in);
+      return kfail("k_nd_forward");
+    }
+  }
   constexpr int TS = XS <= 8 ? XS : 8;        // 16-column panels in two column groups (LDS, registers)
   constexpr int QB = TS >= 8 ? 2 : 4;
   const dim3 grid(nwg, XS / TS);
@@ -2980,6 +2997,12 @@ static int nd_launch_bwd(const nd_args& a, const int* cfront, const int* ccol0, 
   if (nwg <= 0) return 0;
   static int few = -1;
   if (few < 0) { const char* e = getenv("PREALPS_ND_FEW_BWD"); few = e ? atoi(e) : 2048; }
+  if constexpr (XS == 16) {
+    if (nd_wide16()) {
+      PA_LAUNCH((k_nd_backward<16, 16, 4>), dim3(nwg), dim3(256), 0, cur_stream(), a, cfront, ccol0, out);
+      return kfail("k_nd_backward");
+    }
+  }
   constexpr int TS = XS <= 8 ? XS : 8;
   constexpr int WB = TS >= 8 ? 8 : 16;
   const dim3 grid(nwg, XS / TS);
