@@ -200,8 +200,8 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
    * iteration and decide one half-step later; the last half-step is then simply unused.  The
    * RCI entry preAlps_ECGStoppingCriterion keeps working (it reduces the norm by itself). */
   { const char* f = getenv("PREALPS_ECG_LAZY_STOP");
-    pv->lazy_stop = pa_world_size() > 1 && pv->fuse && ecg->bs_red == NO_BS_RED &&
-                    ecg->ortho_alg != ORTHODIR_FUSED && ecg->enlFac >= 2 && (f ? atoi(f) : 1);
+    pv->lazy_stop = pv->fuse && ecg->bs_red == NO_BS_RED && ecg->ortho_alg != ORTHODIR_FUSED && ecg->enlFac >= 2 &&
+                    (f ? atoi(f) : pa_world_size() > 1);
     pv->lazy_ptr = NULL; }
   /* graphs (opt-in: preAlps_hip_graphs(1) or PREALPS_ECG_GRAPH=1): one process, or the one-shard
    * rehearsal of preAlps_hip_loopback, whose sums are free, so the stopping test need not ride on one;

@@ -21,6 +21,7 @@
  */
 #include <ctype.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <sys/mman.h>
 #include <stdlib.h>
@@ -81,6 +82,7 @@ static void* big_alloc(size_t bytes) {
  * owns few rows (one shard of a multi-GPU run: 130 k rows are 519 such blocks on 256 CUs) gets smaller
  * blocks, so that every CU has at least four workgroups to hide the staging and streaming latencies. */
 static int env_int(const char* name, int dflt);
+static size_t g_dbg_val_bytes, g_dbg_slot_bytes;
 static int spmm_block_rows(int m, int dflt) {
   const char* e = getenv("PREALPS_SPMM_BLOCK_ROWS");
   if (e && *e) return atoi(e);
@@ -1189,6 +1191,26 @@ int preAlps_hip_prepare_operator(int enlFac) {
   return 0;
 }
 
+/* Run-to-run spread study: move the matrix values (which & 1) and / or the slot array
+ * (which & 2) of the run plan to freshly allocated device memory; the old arrays stay allocated, so the
+ * new ones land on other physical pages. */
+static size_t g_dbg_val_bytes = 0, g_dbg_slot_bytes = 0;
+int preAlps_hip_debug_move_plan(int which) {
+  pa_operator_t* o = &g_op;
+  if (!o->plan.runs || !g_dbg_val_bytes) return PA_FAIL("no run plan");
+  if (which & 1) {
+    double* nv = (double*)pa_rt_malloc(g_dbg_val_bytes);
+    if (!nv || pa_rt_d2d(nv, o->d_val, g_dbg_val_bytes) || pa_rt_sync()) return PA_FAIL("%s", pa_rt_error());
+    o->d_val = nv; o->plan.val = nv;
+  }
+  if (which & 2) {
+    unsigned short* nc = (unsigned short*)pa_rt_malloc(g_dbg_slot_bytes);
+    if (!nc || pa_rt_d2d(nc, o->d_col16, g_dbg_slot_bytes) || pa_rt_sync()) return PA_FAIL("%s", pa_rt_error());
+    o->d_col16 = nc; o->plan.col16 = nc;
+  }
+  return 0;
+}
+
 int pa_operator_gram_blocks(int ts) {
   pa_operator_t* o = &g_op;
   /* opt-in: measured on the headline problem, the SpMM with the block takes 165.6 us instead of 148.9 us
@@ -1267,6 +1289,8 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "spmm_slices")) *value = o->plan.nslices;
   else if (!strcmp(key, "spmm_stored_entries")) *value = o->sell_entries;
   else if (!strcmp(key, "spmm_stream_bytes")) *value = o->stream_bytes;
+  else if (!strcmp(key, "spmm_val_address")) *value = (double)(uintptr_t)o->d_val;      /* (for the run-to-run spread study) */
+  else if (!strcmp(key, "spmm_slot_address")) *value = (double)(uintptr_t)o->d_col16;
   else if (!strcmp(key, "spmm_staged")) *value = o->plan.staged;
   else if (!strcmp(key, "spmm_runs")) *value = o->plan.runs;
   else if (!strcmp(key, "spmm_stage_rows")) *value = o->plan.stage_cap;
@@ -1472,6 +1496,7 @@ static int build_plan_runs(pa_operator_t* o, int ts) {
     o->d_sl_nrows = (int*)pa_rt_malloc(ns1 * sizeof(int));
     o->d_col16 = (unsigned short*)pa_rt_malloc(nr1 * sizeof(unsigned short));
     o->d_val = (double*)pa_rt_malloc(nr1 * 3 * sizeof(double));
+    g_dbg_val_bytes = nr1 * 3 * sizeof(double); g_dbg_slot_bytes = nr1 * sizeof(unsigned short);
     o->d_blk_slice = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
     o->d_blk_ext_off = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
     o->d_blk_nlow = (int*)pa_rt_malloc((size_t)(nblk > 0 ? nblk : 1) * sizeof(int));
