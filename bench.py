@@ -280,6 +280,7 @@ def main():
     #     block-Jacobi factors and seven panels through the 256 MiB Infinity Cache, so each timed launch
     #     here is preceded by one (untimed) preconditioner apply; one event pair per launch.
     tot = 0.0
+    gram0 = prob.stat("spmm_gram_launches")
     for _ in range(a.spmm_reps):
         check(L.preAlps_BlockJacobiApply(e.AP, e.Z), "BlockJacobiApply")
         check(L.preAlps_hip_timer_start(), "timer_start")
@@ -287,6 +288,23 @@ def main():
         check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
         tot += sec.value
     spmm_s = tot / a.spmm_reps
+    # the product P -> AP of the solver also leaves the Gram block [AP | R]^T P behind (k_spmm_runs_gram, the
+    # default at t = 4): it reads the m x t rows of R on top of the product's bytes; the plain product
+    # (k_spmm_runs, other panels) is timed next to it for comparison
+    with_gram = prob.stat("spmm_gram_launches") > gram0
+    plain_s = None
+    if with_gram:
+        dx, dy = prob.panel(a.t, a.t), prob.panel(a.t, a.t)
+        prob.to_device(dx, np.random.default_rng(1).standard_normal((m_loc, a.t)), a.t)
+        tot = 0.0
+        for _ in range(a.spmm_reps):
+            check(L.preAlps_BlockJacobiApply(e.AP, e.Z), "BlockJacobiApply")
+            check(L.preAlps_hip_timer_start(), "timer_start")
+            check(L.preAlps_BlockOperator(C.byref(dx), C.byref(dy)), "BlockOperator")
+            check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
+            tot += sec.value
+        plain_s = tot / a.spmm_reps
+        prob.panel_free(dx); prob.panel_free(dy)
     # (b) back to back (matrix partly resident in the Infinity Cache): reported for comparison only
     check(L.preAlps_hip_timer_start(), "timer_start")
     for _ in range(a.spmm_reps):
@@ -295,6 +313,9 @@ def main():
     spmm_b2b_s = sec.value / a.spmm_reps
     # 12 B per nonzero + 4 B per row pointer + read X + write AX (8*t B per row each)
     spmm_bytes = 12.0 * nnz_loc + 4.0 * (m_loc + 1) + 8.0 * (m_loc + halo) * a.t + 8.0 * m_loc * a.t
+    plain_bytes = spmm_bytes
+    if with_gram:
+        spmm_bytes += 8.0 * m_loc * a.t + 256.0 * prob.stat("spmm_blocks")     # rows of R read, one 8 x 4 block per workgroup written
     spmm_gbs = spmm_bytes / spmm_s / 1e9
     # block-Jacobi apply, same stopwatch
     check(L.preAlps_hip_timer_start(), "timer_start")
@@ -343,13 +364,18 @@ def main():
                    "setup_breakdown_s": {k: prob.stat("setup_" + k + "_s") for k in ("build", "plan", "bj_factor", "bj_layout")},
                    "bj_max_bandwidth": int(prob.stat("bj_max_bandwidth")),
                    "spmm_blocks": int(prob.stat("spmm_blocks"))},
-        "roofline": {"kernel": "k_spmm_runs" if prob.stat("spmm_runs") else ("k_spmm_staged" if prob.stat("spmm_staged") else "k_spmm"), "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "k_spmm_runs_gram" if with_gram else ("k_spmm_runs" if prob.stat("spmm_runs") else ("k_spmm_staged" if prob.stat("spmm_staged") else "k_spmm")), "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": spmm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s,
                      "back_to_back_launch_us": 1e6 * spmm_b2b_s,
                      "measured_copy_ceiling_GBs": copy_gbs.value, "measured_read_ceiling_GBs": read_gbs.value,
                      "frac_of_measured_read_ceiling": spmm_gbs / read_gbs.value,
-                     "note": "each timed launch follows one preconditioner apply (cache state of the solver loop)"},
+                     "plain_product": None if plain_s is None else {
+                         "kernel": "k_spmm_runs", "avg_launch_us": 1e6 * plain_s, "algorithmic_bytes_per_launch": plain_bytes,
+                         "achieved": plain_bytes / plain_s / 1e9, "frac": plain_bytes / plain_s / 1e9 / HBM_PEAK_GBS,
+                         "note": "the same product on other panels, without the Gram block (what rounds 1-2 reported)"},
+                     "note": "each timed launch follows one preconditioner apply (cache state of the solver loop)"
+                             + ("; the solver's product also forms [AP | R]^T P (rows of R counted in the bytes)" if with_gram else "")},
         "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "factor_bytes": prob.stat("bj_factor_bytes"),
                          "traffic": bj_traffic, "frac": bj_bytes / bj_s / 1e9 / HBM_PEAK_GBS,
                          "achieved_GBs": bj_bytes / bj_s / 1e9,

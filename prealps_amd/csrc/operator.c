@@ -1213,10 +1213,11 @@ int preAlps_hip_debug_move_plan(int which) {
 
 int pa_operator_gram_blocks(int ts) {
   pa_operator_t* o = &g_op;
-  /* opt-in: measured on the headline problem, the SpMM with the block takes 165.6 us instead of 148.9 us
-   * and the sum 8.7 us, against 19.8 + 8.3 us for k_gram + its sum -- 2.7 us per iteration, and the SpMM's
-   * own roofline figure drops */
-  if (!o->info.built || g_plan_only || ts != 4 || !env_int("PREALPS_SPMM_GRAM", 0)) return 0;
+  /* measured inside one process with the two variants alternating (tools/probe/spmm_gram_ab.py,
+   * ecg_gram_ab.py): the SpMM with the block takes 9.5-11 us longer (159 against 149 us), the sum 8.7 us
+   * instead of 19.8 + 8.3 us for k_gram and its sum: 11-12 us per ECG iteration saved (409.5 -> 397.7 us).
+   * PREALPS_SPMM_GRAM=0: the separate Gram kernel */
+  if (!o->info.built || g_plan_only || ts != 4 || !env_int("PREALPS_SPMM_GRAM", 1)) return 0;
   if (o->plan_ts != ts && build_plan(o, ts)) return 0;
   return o->plan.runs ? o->plan.nblk : 0;
 }
