@@ -48,6 +48,12 @@
 // a launch that a replayed graph segment makes in its place is skipped (runtime.hip: pa_rt_skip)
 #define PA_LAUNCH(...) do { if (!pa_rt_skipping()) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+// One-shot request for the Gram block of the next launch (pa_k_bj_g4_gram; defined in the 12-tile unit)
+extern "C" {
+extern const double* pa_g4_gram_prev;
+extern double* pa_g4_gram_part;
+}
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -335,7 +341,8 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     const int* __restrict__ list, int count, const int* __restrict__ row0, const int* __restrict__ nrows,
     const int* __restrict__ bw, const long long* __restrict__ off2, const int* __restrict__ map_f,
     const double* __restrict__ Lg4, const double* __restrict__ invd_f, int lds_per_wave, int ring, int xs, int ncol,
-    const double* __restrict__ in, double* __restrict__ out) {
+    const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ gprev,
+    double* __restrict__ gpart) {
   extern __shared__ double smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int pi = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -423,6 +430,33 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
 #pragma unroll
       for (int q = 0; q < NT; ++q)
         if (16 * q + trow3 < b && 4 * c + lo3 < ncol) out[rowoff[q] + 4 * c] = T[c * NT + q];
+    // gpart != null (4-column panels, pa_k_bj_g4_gram): the block's share of [in | gprev]^T out -- the Gram
+    // block the ECG iteration forms right after the apply (beta = [AP | AP_prev]^T Z, ecg.c:510) -- while
+    // the result is still in registers.  A tile (lane = 16 hi + 4 blk + lo: row 4 blk + hi, column lo) is
+    // the B operand of v_mfma_f64_4x4x4 as it stands (k = hi); the A operand, row 4 blk + k of the other
+    // panel in column i = lo, sits at the tile's own address.  8 x 4 per block, the layout of k_gram<4, 2>.
+    if constexpr (NC == 1) {
+      if (gpart) {
+        double ga = 0.0, gp = 0.0;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          const bool on = 16 * q + trow3 < b;
+          const double a = on ? in[rowoff[q]] : 0.0;
+          const double ap = on ? gprev[rowoff[q]] : 0.0;
+          const double z = on ? T[q] : 0.0;
+          ga = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z, ga, 0, 0, 0);
+          gp = __builtin_amdgcn_mfma_f64_4x4x4f64(ap, z, gp, 0, 0, 0);
+        }
+        ga += row_ror<4>(ga); ga += row_ror<8>(ga);
+        gp += row_ror<4>(gp); gp += row_ror<8>(gp);
+        if (((l3 >> 2) & 3) == 0) {
+          const int i = l3 >> 4;
+          double* gq = gpart + (size_t)pi * 32;
+          gq[i + 8 * lo3] = ga;
+          gq[4 + i + 8 * lo3] = gp;
+        }
+      }
+    }
   }
 }
 
@@ -465,8 +499,10 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
     configured = lds;
   }
   const int blocks = (count + waves - 1) / waves;
+  const bool gram = NC == 1 && pa_g4_gram_part && xs == 4 && ncol == 4;
   PA_LAUNCH((k_bj_g4<NC, NT, DQ, OCC>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
-                     pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out);
+                     pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out,
+                     gram ? pa_g4_gram_prev : (const double*)nullptr, gram ? pa_g4_gram_part : (double*)nullptr);
   return kfail("k_bj_g4");
 }
 
@@ -494,6 +530,12 @@ int launch_dq(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int 
 extern "C" {
 
 #if G4_NT == 12
+const double* pa_g4_gram_prev = nullptr;
+double* pa_g4_gram_part = nullptr;
+/* The next pa_k_bj_g4 on a 4-column panel also leaves, per block (in the order of `list`), the 8 x 4 block
+ * [in | prev]^T out in part (32 doubles each).  Cleared by that call. */
+void pa_k_bj_g4_gram(const double* prev, double* part) { pa_g4_gram_prev = prev; pa_g4_gram_part = part; }
+
 int pa_bj_g4_max_rows(void) { return 256; }
 int pa_bj_g4_max_band(void) { return 112; }
 int pa_bj_g4_max_band8(void) { return 80; }     /* panels of 5 .. 8 columns (two column sets per wavefront) */
@@ -515,10 +557,13 @@ int pa_k_bj_g4_nt16(const pa_bj_plan_t* pl, const int* list, int count, int wmax
 int pa_k_bj_g4(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int bmax, int xs, int ncol,
                const double* in, double* out) {
   if (count <= 0) return 0;
-  if (bmax > 224) return pa_k_bj_g4_nt16(pl, list, count, wmax, xs, ncol, in, out);
-  if (bmax > 192) return pa_k_bj_g4_nt14(pl, list, count, wmax, xs, ncol, in, out);
-  return ncol > 4 ? launch_dq<2, 12>(list, count, pl, wmax, xs, ncol, in, out)
-                  : launch_dq<1, 12>(list, count, pl, wmax, xs, ncol, in, out);
+  int rc;
+  if (bmax > 224) rc = pa_k_bj_g4_nt16(pl, list, count, wmax, xs, ncol, in, out);
+  else if (bmax > 192) rc = pa_k_bj_g4_nt14(pl, list, count, wmax, xs, ncol, in, out);
+  else rc = ncol > 4 ? launch_dq<2, 12>(list, count, pl, wmax, xs, ncol, in, out)
+                     : launch_dq<1, 12>(list, count, pl, wmax, xs, ncol, in, out);
+  pa_g4_gram_prev = nullptr; pa_g4_gram_part = nullptr;
+  return rc;
 }
 #elif G4_NT == 14
 int pa_k_bj_g4_nt14(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int xs, int ncol, const double* in, double* out) {

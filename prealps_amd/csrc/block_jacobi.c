@@ -70,6 +70,13 @@ int pa_bj_nparts(void) { return g_bj.created ? g_bj.np : 0; }
 int pa_bj_nd_blocks(void) { return g_bj.created ? g_bj.nd_blocks : 0; }
 double pa_bj_pairs_bytes(void) { return g_bj.created ? g_bj.pairs_bytes : 0.0; }
 double pa_bj_g4_bytes(void) { return g_bj.created ? g_bj.g4_bytes : 0.0; }
+/* blocks of the apply when it can leave the ECG Gram block [in | prev]^T out behind (pa_k_bj_gram_arm): every
+ * local block in one class served by bj_g4.hip, no sparse-factored blocks; 0: it cannot */
+int pa_bj_gram_blocks(void) {
+  const pa_bj_t* s = &g_bj;
+  if (!s->created || s->nd_blocks > 0 || !s->d_Lg4 || s->nclass != 1 || !s->class_g4[0] || s->class_count[0] != s->np) return 0;
+  return s->np;
+}
 
 void preAlps_BlockJacobiFree(void) {
   pa_bj_t* s = &g_bj;

@@ -58,6 +58,7 @@ typedef struct {
   double* d_F; double* d_alpha; double* d_beta; double* d_mu; double* d_rtr;
   double* d_res2; double* d_q;
   double* d_partials; double* d_rtr_part;
+  double* d_bj_parts; int bj_cap;       /* Gram blocks left behind by the block solve (pa_k_bj_gram_arm), 32 doubles per block */
   double* d_spmm_parts; int spmm_cap;   /* Gram blocks left behind by the SpMM (pa_k_spmm_gram_arm), 32 doubles each */
   int rtr_nblk, rtr_valid;
   int* d_info; int* d_piv;
@@ -103,6 +104,8 @@ static void publish_pointers(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   ecg->Z_p = pv->buf_z;
 }
 
+static int pa_env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
 /* ------------------------------------------------------------- malloc ---- */
 int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
   PA_REQUIRE_GPU();
@@ -131,6 +134,9 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
   /* T = 4: the library's SpMM can form [AP | R]^T P while it computes AP (one block per workgroup) */
   pv->spmm_cap = (T == 4 && ts == 4) ? pa_operator_gram_blocks(ts) : 0;
   if (pv->spmm_cap) parts += ((size_t)pv->spmm_cap + pa_finish32_scratch_blocks()) * 32;
+  /* ... and the library's block solve beta = [AP | AP_prev]^T Z while Z is still in its registers (Orthodir) */
+  pv->bj_cap = (T == 4 && ts == 4 && ecg->ortho_alg == ORTHODIR && pa_env_flag("PREALPS_BJ_GRAM", 1)) ? pa_bj_gram_blocks() : 0;
+  if (pv->bj_cap) parts += ((size_t)pv->bj_cap + pa_finish32_scratch_blocks()) * 32;
   pv->pool_doubles = (2 * nv + 3) * panel + small + parts;
   ecg->work = (double*)pa_rt_malloc(pv->pool_doubles * sizeof(double));
   if (!ecg->work) return PA_FAIL("device pool of %zu doubles: %s", pv->pool_doubles, pa_rt_error());
@@ -149,6 +155,8 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
   pv->d_partials = w; w += (size_t)pa_gram_max_blocks() * 2 * ts * ts;
   pv->d_rtr_part = w; w += (size_t)pa_gram_max_blocks() * ts;
   pv->d_spmm_parts = pv->spmm_cap ? w : NULL;
+  if (pv->spmm_cap) w += ((size_t)pv->spmm_cap + pa_finish32_scratch_blocks()) * 32;
+  pv->d_bj_parts = pv->bj_cap ? w : NULL;
   pv->d_info = (int*)pa_rt_malloc((8 + T) * sizeof(int));
   if (!pv->d_info) return PA_FAIL("device allocation failed: %s", pa_rt_error());
   pv->d_piv = pv->d_info + 8;
@@ -549,7 +557,24 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   int cnt = ecg->beta->info.lda * ecg->beta->info.n;
   const double* note = NULL;     /* device words the update kernel copies to pinned memory */
   TIC(PA_T_GRAM);
-  if (pv->rtr_valid == 1 && pv->lazy_ptr && pv->lazy_ptr == pv->d_beta + cnt) {
+  int from_bj = pv->bj_cap > 0 ? pa_k_bj_gram_take(pv->buf_av[0], pv->buf_z) : 0;
+  if (from_bj > 0 && !(a_lo == T && a_hi == T && T == 4 && ecg->beta->info.n == 4 && ecg->beta->info.lda == 8)) from_bj = 0;
+  if (from_bj > 0) {
+    /* the block solve left one 8 x 4 block per subdomain behind: only their sum is left to do (and, with the
+     * lazy stopping test, the residual norm next to it) */
+    double* scratch = pv->d_bj_parts + (size_t)pv->bj_cap * 32;
+    if (pv->rtr_valid == 1 && pv->lazy_ptr && pv->lazy_ptr == pv->d_beta + cnt) {
+      PA_CHECK(pa_k_finish32_trace(pv->d_bj_parts, from_bj, scratch, pv->d_beta, pv->d_rtr_part, pv->rtr_nblk, pv->ts, T,
+                                   pv->lazy_ptr, pv->d_info));
+      pv->rtr_valid = 2;
+    } else {
+      if (pv->rtr_valid == 1 && pv->lazy_ptr) {
+        PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->lazy_ptr, pv->d_info));
+        pv->rtr_valid = 2;
+      }
+      PA_CHECK(pa_k_finish32(pv->d_bj_parts, from_bj, scratch, 0, 0, pv->d_beta, NULL, NULL, NULL));
+    }
+  } else if (pv->rtr_valid == 1 && pv->lazy_ptr && pv->lazy_ptr == pv->d_beta + cnt) {
     /* the column sums fused_first_half left: summed by the same launch, into the slot behind beta */
     PA_CHECK(pa_k_gram_finish_trace(pv->m, pv->ts, pv->buf_av[0], a_hi > 0 ? pv->buf_av[1] : NULL, pv->buf_z,
                                     pv->d_partials, a_lo, a_hi, ecg->beta->info.n, pv->d_beta, ecg->beta->info.lda,
@@ -651,6 +676,10 @@ int _preAlps_ECGIterateOdir(preAlps_ECG_t* ecg, int* rci_request) {
   if (*rci_request == 0) {
     if (ecg->bs_red == NO_BS_RED && pv->fuse) {
       if (fused_first_half(ecg, pv, t)) return 1;
+      /* next: Z = M^-1 AP by the caller, then beta = [AP | AP_prev]^T Z here: ask the block solve for it */
+      if (pv->bj_cap > 0 && t == 4 && ecg->beta->info.m == 8 && ecg->beta->info.lda == 8 && ecg->beta->info.n == 4)
+        pa_k_bj_gram_arm(pv->buf_av[0], pv->buf_z, pv->buf_av[1], pv->d_bj_parts, pv->bj_cap);
+      else pa_k_bj_gram_disarm();
     } else {
       if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
       if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0)) return 1;
@@ -811,6 +840,7 @@ void _preAlps_ECGFree(preAlps_ECG_t* ecg) {
   ecg_priv_t* pv = priv_of(ecg);
   if (pv) {
     pa_k_spmm_gram_disarm();
+    pa_k_bj_gram_disarm();
     pa_rt_sync();
     pa_rt_free(pv->d_info);
     pa_rt_host_free(pv->h_pin);

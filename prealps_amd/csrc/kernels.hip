@@ -963,7 +963,8 @@ __device__ unsigned g_fin32_ticket = 0;
 __global__ __launch_bounds__(WG) void k_finish32(const double* __restrict__ partials, int nblk,
                                                  double* scratch, int t, int T, double* out,
                                                  double* __restrict__ mu, double* __restrict__ alpha,
-                                                 int* __restrict__ info) {
+                                                 int* __restrict__ info, const double* __restrict__ rtr,
+                                                 int rtr_nblk, int rtr_ts, int rtr_nc, double* __restrict__ res2) {
   __shared__ double red[32 * 32];
   __shared__ int s_last;
   typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1020,6 +1021,10 @@ __global__ __launch_bounds__(WG) void k_finish32(const double* __restrict__ part
     __threadfence_block();
     __syncthreads();
     potrf_alpha_wg(out, t, T, mu, alpha, info, red, red + 256);
+  }
+  if (rtr) {      // the residual norm next to the block, as k_finish_trace (same order of additions as k_trace_finish)
+    __syncthreads();
+    trace_finish_wg(rtr, rtr_nblk, rtr_ts, rtr_nc, res2, info, nullptr, red);
   }
 }
 
@@ -3041,7 +3046,14 @@ int pa_finish32_scratch_blocks(void) { return FIN32_WG; }
 int pa_k_finish32(const double* partials, int nblk, double* scratch, int t, int T, double* out, double* mu,
                   double* alpha, int* info) {
   PA_LAUNCH(k_finish32, dim3(FIN32_WG), dim3(WG), 0, cur_stream(), partials, nblk, scratch, t, T, out, mu,
-            alpha, info);
+            alpha, info, (const double*)nullptr, 0, 0, 0, (double*)nullptr);
+  return kfail("k_finish32");
+}
+
+int pa_k_finish32_trace(const double* partials, int nblk, double* scratch, double* out, const double* rtr_partials,
+                        int rtr_nblk, int ts, int nc, double* res2, int* info) {
+  PA_LAUNCH(k_finish32, dim3(FIN32_WG), dim3(WG), 0, cur_stream(), partials, nblk, scratch, 0, 0, out,
+            (double*)nullptr, (double*)nullptr, info, rtr_partials, rtr_nblk, ts, nc, res2);
   return kfail("k_finish32");
 }
 
@@ -3336,6 +3348,23 @@ int pa_k_bj_pairs(const int* list, int count, const int* nrows, const int* bw, c
   return kfail("k_bj_pairs");
 }
 
+/* A Gram block requested from the next block solve in -> out (pa_k_bj_gram_arm), as g_sg for the SpMM */
+static struct { const double* in; const double* out; const double* prev; double* partials; int cap, count, armed; } g_bg;
+
+void pa_k_bj_gram_arm(const double* in, const double* out, const double* prev, double* partials, int cap) {
+  g_bg.in = in; g_bg.out = out; g_bg.prev = prev; g_bg.partials = partials; g_bg.cap = cap; g_bg.count = 0;
+  g_bg.armed = (in && out && prev && partials && cap > 0);
+}
+static long long g_bg_applies = 0;
+long long pa_k_bj_gram_applies(void) { return g_bg_applies; }
+void pa_k_bj_gram_disarm(void) { g_bg.armed = 0; g_bg.count = 0; }
+int pa_k_bj_gram_take(const double* in, const double* out) {
+  if (!g_bg.armed || in != g_bg.in || out != g_bg.out) return 0;
+  const int n = g_bg.count;
+  g_bg.armed = 0; g_bg.count = 0;
+  return n;
+}
+
 int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out) {
   for (int c = 0; c < pl->nclass; ++c) {
     if (pl->class_count[c] <= 0) continue;
@@ -3343,6 +3372,13 @@ int pa_k_bj_apply(const pa_bj_plan_t* pl, int ts, const double* in, double* out)
     static int g4_wide = -1;      /* PREALPS_BJ_G4_WIDE=0: 8-column panels stay with k_bj_mfma */
     if (g4_wide < 0) { const char* e = getenv("PREALPS_BJ_G4_WIDE"); g4_wide = e ? atoi(e) : 1; }
     if (pl->Lg4 && pl->class_g4[c] && (ts <= 4 || (ts == 8 && g4_wide && pl->class_wmax[c] <= pa_bj_g4_max_band8()))) {   /* one copy of the factor, matrix cores (bj_g4.hip) */
+      if (ts == 4 && g_bg.armed && pl->nclass == 1 && in == g_bg.in && out == g_bg.out && pl->class_count[c] <= g_bg.cap) {
+        pa_k_bj_g4_gram(g_bg.prev, g_bg.partials);      // this apply also leaves [in | prev]^T out (pa_k_bj_gram_arm)
+        g_bg.count = pl->class_count[c];
+        ++g_bg_applies;
+      } else if (g_bg.armed && in == g_bg.in && out == g_bg.out) {
+        g_bg.count = 0;
+      }
       rc = pa_k_bj_g4(pl, pl->class_list[c], pl->class_count[c], pl->class_wmax[c], pl->class_bmax[c], ts, ts, in, out);
       if (rc) return rc;
       continue;

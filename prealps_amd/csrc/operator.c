@@ -1287,6 +1287,7 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "send_rows")) *value = o->nsend;
   else if (!strcmp(key, "spmm_blocks")) *value = o->plan.nblk;
   else if (!strcmp(key, "spmm_gram_launches")) *value = (double)pa_k_spmm_gram_launches();
+  else if (!strcmp(key, "bj_gram_applies")) *value = (double)pa_k_bj_gram_applies();
   else if (!strcmp(key, "spmm_slices")) *value = o->plan.nslices;
   else if (!strcmp(key, "spmm_stored_entries")) *value = o->sell_entries;
   else if (!strcmp(key, "spmm_stream_bytes")) *value = o->stream_bytes;

@@ -111,6 +111,15 @@ int pa_k_spmm_gram_take(const double* X, const double* Y);
 int pa_k_finish32(const double* partials, int nblk, double* scratch, int t, int T, double* out, double* mu,
                   double* alpha, int* info);       /* scratch: pa_finish32_scratch_blocks() x 32 doubles */
 int pa_finish32_scratch_blocks(void);
+/* the same sum, followed by the residual norm from the update kernel's column sums (res2[0], res2[1] = *info) */
+int pa_k_finish32_trace(const double* partials, int nblk, double* scratch, double* out, const double* rtr_partials,
+                        int rtr_nblk, int ts, int nc, double* res2, int* info);
+/* Ask the next block solve in -> out on a 4-column panel (every block through bj_g4.hip) to leave the partial
+ * blocks of [in | prev]^T out behind, one per block; pa_k_bj_gram_take: how many there are (0: none). */
+void pa_k_bj_gram_arm(const double* in, const double* out, const double* prev, double* partials, int cap);
+void pa_k_bj_gram_disarm(void);
+long long pa_k_bj_gram_applies(void);        /* block solves that left the Gram block behind so far */
+int pa_k_bj_gram_take(const double* in, const double* out);
 /* sendbuf[i*ts + c] = X[idx[i]*ts + c] */
 int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendbuf);
 
@@ -224,6 +233,9 @@ typedef struct {
 } pa_bj_plan_t;
 int pa_k_bj_g4(const pa_bj_plan_t* pl, const int* list, int count, int wmax, int bmax, int xs, int ncol,
                 const double* in, double* out);
+/* One-shot: the next pa_k_bj_g4 on a 4-column panel also leaves the 8 x 4 block [in | prev]^T out of every
+ * block in part (32 doubles per block, in the order of its list; the layout of pa_k_gram with two panels). */
+void pa_k_bj_g4_gram(const double* prev, double* part);
 int pa_bj_max_R(void);
 int pa_k_bj_pairs(const int* list, int count, const int* nrows, const int* bw, const long long* off,
                   const long long* off2, const double* L, double* L2);

@@ -103,6 +103,7 @@ int pa_bj_max_bandwidth(void);
 double pa_bj_setup_seconds(int which);   /* 0: ordering + band Cholesky, 1: sweep layouts + upload */
 int pa_bj_nparts(void);
 int pa_bj_nd_blocks(void);
+int pa_bj_gram_blocks(void);       /* blocks of an apply that can leave [in | prev]^T out behind (0: cannot) */
 double pa_bj_g4_bytes(void);        /* bytes of the one-copy records of bj_g4.hip, 0 if absent */
 double pa_bj_pairs_bytes(void);     /* bytes of the paired sweep records (both sweeps), 0 if absent */
 

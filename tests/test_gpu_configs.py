@@ -703,7 +703,7 @@ print("shard ok")
 
 
 _SPMM_GRAM_SNIPPET = r"""
-import sys, numpy as np
+import os, sys, numpy as np
 sys.path.insert(0, %r)
 import prealps_amd as pa
 from prealps_amd import gen
@@ -724,25 +724,32 @@ for shard in (None, (0, 3)):
         assert p0 %% 4 == 0
     else:
         Bs, rps = B, rowpos
-    before = prob.stat("spmm_gram_launches")
+    before, before_bj = prob.stat("spmm_gram_launches"), prob.stat("bj_gram_applies")
     for alg_g, alg_o in ((pa.ORTHODIR, O.ORTHODIR), (pa.ORTHOMIN, O.ORTHOMIN)):
         got = prob.solve(rhs, 4, ortho_alg=alg_g, max_iter=400)
         ref = O.ECG(Bs, rps, 4, alg_o, O.NO_BS_RED, 1e-5, 400).solve(rhs)
         assert got.iters == ref["iters"] and got.iters >= 8, (got.iters, ref["iters"])
         np.testing.assert_allclose(got.res[:20], ref["res"][:20], rtol=1e-8)
         np.testing.assert_allclose(got.x, ref["x"], rtol=1e-5, atol=1e-7 * np.abs(ref["x"]).max())
-    assert prob.stat("spmm_runs") == 1.0 and prob.stat("spmm_gram_launches") - before >= 16, prob.stat("spmm_gram_launches") - before
+    on = os.environ["PREALPS_SPMM_GRAM"] == "1"
+    assert prob.stat("spmm_runs") == 1.0
+    assert (prob.stat("spmm_gram_launches") - before >= 16) if on else (prob.stat("spmm_gram_launches") == before)
+    # the block solve leaves beta = [AP | AP_prev]^T Z behind in the Orthodir solve (every block in one bj_g4 class)
+    assert (prob.stat("bj_gram_applies") - before_bj >= 8) if on else (prob.stat("bj_gram_applies") == before_bj)
     prob.close()
 print("spmm gram ok")
 """
 
 
-def test_spmm_leaves_the_gram_block_behind():
-    """PREALPS_SPMM_GRAM=1: k_spmm_runs_gram forms [AP | R]^T P while it computes AP (one partial block per
-    workgroup, k_finish32 sums them): Orthodir and Orthomin at 4 columns, in one process and in the one-shard
-    rehearsal, where the interior and the halo-reading halves of the SpMM each leave their share."""
+@pytest.mark.parametrize("on", ["1", "0"])
+def test_spmm_and_block_solve_leave_the_gram_blocks_behind(on):
+    """The defaults at 4 columns: k_spmm_runs_gram forms [AP | R]^T P while it computes AP (one partial block per
+    workgroup) and k_bj_g4 forms [AP | AP_prev]^T Z while Z is in its registers (one per subdomain), k_finish32
+    sums them: Orthodir and Orthomin, in one process and in the one-shard rehearsal, where the interior and the
+    halo-reading halves of the SpMM each leave their share.  "0": both switched off (PREALPS_SPMM_GRAM,
+    PREALPS_BJ_GRAM), the separate Gram kernels give the same answers."""
     r = subprocess.run([sys.executable, "-c", _SPMM_GRAM_SNIPPET % ROOT], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, PREALPS_SPMM_GRAM="1"))
+                       env=dict(os.environ, PREALPS_SPMM_GRAM=on, PREALPS_BJ_GRAM=on))
     assert r.returncode == 0 and "spmm gram ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
 
 
