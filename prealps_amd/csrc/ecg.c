@@ -206,10 +206,13 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
    * new residual is only needed for the stopping decision, so the driver loops of this library
    * (preAlps_ECGSolve / ECGAdvance) let it travel with the beta all-reduce of the same
    * iteration and decide one half-step later; the last half-step is then simply unused.  The
-   * RCI entry preAlps_ECGStoppingCriterion keeps working (it reduces the norm by itself). */
+   * RCI entry preAlps_ECGStoppingCriterion keeps working (it reduces the norm by itself).
+   * One process: the same order saves the launch that sums the norm (it is summed with beta):
+   * 2-3 us per iteration (in-process A/B), so it is the default there too; PREALPS_ECG_LAZY_STOP=0
+   * decides right after the update, as the reference does. */
   { const char* f = getenv("PREALPS_ECG_LAZY_STOP");
     pv->lazy_stop = pv->fuse && ecg->bs_red == NO_BS_RED && ecg->ortho_alg != ORTHODIR_FUSED && ecg->enlFac >= 2 &&
-                    (f ? atoi(f) : pa_world_size() > 1);
+                    (f ? atoi(f) : 1);
     pv->lazy_ptr = NULL; }
   /* graphs (opt-in: preAlps_hip_graphs(1) or PREALPS_ECG_GRAPH=1): one process, or the one-shard
    * rehearsal of preAlps_hip_loopback, whose sums are free, so the stopping test need not ride on one;
@@ -321,8 +324,17 @@ static int stopping_queue(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
     if (!pv->rtr_valid) {
       PA_CHECK(pa_k_colnorm2(pv->m, pv->ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
     }
-    PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2, pv->d_info));
-    pv->rtr_valid = 3;   /* summed, but not on the host yet */
+    if (single && pv->rtr_valid == 1) {
+      /* column sums left by the update kernel (lazy stopping test), one process: the sum goes straight to
+       * the pinned words, as it does from the update kernel's own launch without the lazy test */
+      pv->sent_seq = 0.0;
+      if (pv->poll) { pv->sent_seq = (pv->seq += 1.0); pa_k_note_seq(pv->sent_seq); }
+      PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2, pv->d_info, pv->h_pin));
+      pv->rtr_valid = 2;
+    } else {
+      PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->d_res2, pv->d_info, NULL));
+      pv->rtr_valid = 3;   /* summed, but not on the host yet */
+    }
   }
   /* rtr_valid == 2: the update kernel summed the norm itself and, in a single-process run,
    * already wrote it to the pinned words the host reads */
@@ -499,7 +511,7 @@ static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
    * (orthogonalise_z), next to which the norm travels: no launch of its own here */
   int defer = pv->lazy_ptr != NULL;
   pv->sent_seq = 0.0;
-  if (single && pv->poll) { pv->sent_seq = (pv->seq += 1.0); pa_k_note_seq(pv->sent_seq); }
+  if (single && pv->poll && !defer) { pv->sent_seq = (pv->seq += 1.0); pa_k_note_seq(pv->sent_seq); }
   PA_CHECK(pa_k_trsm_update(m, ts, t, ecg->X->info.n, pv->d_mu, pv->d_alpha, ecg->P->val, ecg->AP->val,
                             pv->d_X, pv->d_R, pv->d_rtr_part, &nb, defer ? 0 : T,
                             pv->lazy_ptr ? pv->lazy_ptr : pv->d_res2, pv->d_info, single ? pv->h_pin : NULL,
@@ -569,7 +581,7 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
       pv->rtr_valid = 2;
     } else {
       if (pv->rtr_valid == 1 && pv->lazy_ptr) {
-        PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->lazy_ptr, pv->d_info));
+        PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->lazy_ptr, pv->d_info, NULL));
         pv->rtr_valid = 2;
       }
       PA_CHECK(pa_k_finish32(pv->d_bj_parts, from_bj, scratch, 0, 0, pv->d_beta, NULL, NULL, NULL));
@@ -582,7 +594,7 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
     pv->rtr_valid = 2;
   } else {
     if (pv->rtr_valid == 1 && pv->lazy_ptr) {     /* (beta not where expected: the norm by itself) */
-      PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->lazy_ptr, pv->d_info));
+      PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, pv->ts, T, pv->lazy_ptr, pv->d_info, NULL));
       pv->rtr_valid = 2;
     }
     PA_CHECK(pa_k_gram_finish(pv->m, pv->ts, pv->buf_av[0], a_hi > 0 ? pv->buf_av[1] : NULL, pv->buf_z,
@@ -778,7 +790,7 @@ int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
   /* R has not changed since the previous call's update: its column norms are
    * already there, except on the first call */
   if (!pv->rtr_valid) PA_CHECK(pa_k_colnorm2(m, ts, pv->d_R, pv->d_rtr_part, &pv->rtr_nblk));
-  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, ts, nrhs, pv->d_rtr, NULL));
+  PA_CHECK(pa_k_trace_finish(pv->d_rtr_part, pv->rtr_nblk, ts, nrhs, pv->d_rtr, NULL, NULL));
   TAC(PA_T_GRAM, gemm_t);
   TIC(PA_T_COMM);
   if (pa_allreduce(pv->d_F, 5 * nrhs * nrhs)) return 1; /* the single reduction (ecg.c:563) */

@@ -3137,7 +3137,7 @@ int pa_k_gram_finish_trace(int m, int ts, const double* A0, const double* A1, co
   int nblk = 0;
   const int ne = (a_lo + a_hi) * nb;
   if (ne <= 0 || ne > 128)     /* no Gram block, or one that several workgroups sum: the two launches */
-    return pa_k_trace_finish(rtr_partials, rtr_nblk, ts, nc, res2, info) ||
+    return pa_k_trace_finish(rtr_partials, rtr_nblk, ts, nc, res2, info, NULL) ||
            pa_k_gram_finish(m, ts, A0, A1, B, partials, a_lo, a_hi, nb, out, ld_out, 0, 0, NULL, NULL, NULL);
   if (pa_k_gram(m, ts, A0, A1, B, partials, &nblk)) return 1;
   PA_LAUNCH(k_finish_trace, dim3(1), dim3(1024), 0, cur_stream(), partials, nblk, A1 ? 2 : 1, ts, a_lo, a_hi, nb,
@@ -3228,9 +3228,9 @@ int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nbl
 }
 
 int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2,
-                      const int* info) {
+                      const int* info, double* host) {
   PA_LAUNCH(k_trace_finish, dim3(1), dim3(WG), 0, cur_stream(), rtr_partials, nblk, ts, nc,
-                     res2, info, (double*)nullptr, 0.0);
+                     res2, info, host, take_note_seq(host));
   return kfail("k_trace_finish");
 }
 

@@ -178,7 +178,7 @@ int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, dou
 int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk);
 /* res2[0] = sum over blocks and columns c < nc; res2[1] = *info (0 if info is NULL). */
 int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, double* res2,
-                      const int* info);
+                      const int* info, double* host);    /* host: pinned words that receive the same two values (may be NULL) */
 /* Z(:, :nc) -= [V0(:, :a_lo) | V1(:, :a_hi)] beta, beta is (a_lo+a_hi) x nc,
  * leading dimension ldb (ecg.c:354,517). */
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,

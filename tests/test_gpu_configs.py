@@ -633,12 +633,14 @@ print("variant ok", prob.stat("spmm_staged"), prob.stat("bj_max_bandwidth"), pro
                                  {"PREALPS_BJ_MFMA": "2", "PREALPS_BJ_WIDE_FROM": "448", "PREALPS_TRSM_MFMA": "0"},
                                  {"PREALPS_BJ_SPLIT4": "0", "PREALPS_ECG_FUSE": "0"},
                                  {"PREALPS_BJ_PAIRS": "0"},
-                                 {"PREALPS_ECG_POLL": "1", "PREALPS_SPMM_GRAM": "1"}])
+                                 {"PREALPS_ECG_POLL": "1", "PREALPS_SPMM_GRAM": "1"},
+                                 {"PREALPS_ECG_LAZY_STOP": "0"}])
 def test_opt_in_kernel_variants(env):
     """Non-temporal SpMM loads (k_spmm<TS,true>), the column-split block solve (PREALPS_BJ_SPLIT),
     the matrix-core block solve at every width, the unsplit 4-column sweep, the four-pass first
     half, the narrow-band sweep on plain instead of paired records, and the host polling for the residual norm
-    (the default of multi-process runs) in one process: same answers as the oracle
+    (the default of multi-process runs) in one process, and the stopping test right after the update
+    (PREALPS_ECG_LAZY_STOP=0) instead of one half-step later: same answers as the oracle
     (Poisson 16^3, 16 slabs, band 256 -> register-set class 5; Poisson 12^3 in 27 boxes, class 2)."""
     r = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET % ROOT], capture_output=True, text=True,
                        env=dict(os.environ, **env), timeout=600)
