@@ -293,9 +293,9 @@ def main():
     # (k_spmm_runs, other panels) is timed next to it for comparison
     with_gram = prob.stat("spmm_gram_launches") > gram0
     plain_s = None
+    dx, dy = prob.panel(a.t, a.t), prob.panel(a.t, a.t)
+    prob.to_device(dx, np.random.default_rng(1).standard_normal((m_loc, a.t)), a.t)
     if with_gram:
-        dx, dy = prob.panel(a.t, a.t), prob.panel(a.t, a.t)
-        prob.to_device(dx, np.random.default_rng(1).standard_normal((m_loc, a.t)), a.t)
         tot = 0.0
         for _ in range(a.spmm_reps):
             check(L.preAlps_BlockJacobiApply(e.AP, e.Z), "BlockJacobiApply")
@@ -304,7 +304,6 @@ def main():
             check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
             tot += sec.value
         plain_s = tot / a.spmm_reps
-        prob.panel_free(dx); prob.panel_free(dy)
     # (b) back to back (matrix partly resident in the Infinity Cache): reported for comparison only
     check(L.preAlps_hip_timer_start(), "timer_start")
     for _ in range(a.spmm_reps):
@@ -318,11 +317,20 @@ def main():
         spmm_bytes += 8.0 * m_loc * a.t + 256.0 * prob.stat("spmm_blocks")     # rows of R read, one 8 x 4 block per workgroup written
     spmm_gbs = spmm_bytes / spmm_s / 1e9
     # block-Jacobi apply, same stopwatch
+    bjg0 = prob.stat("bj_gram_applies")
     check(L.preAlps_hip_timer_start(), "timer_start")
     for _ in range(a.spmm_reps):
         check(L.preAlps_BlockJacobiApply(e.AP, e.Z), "BlockJacobiApply")
     check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
+    bj_solver_s = sec.value / a.spmm_reps
+    bj_with_gram = prob.stat("bj_gram_applies") > bjg0      # the solver's apply AP -> Z also forms [AP | AP_prev]^T Z
+    # the block solve alone (other panels): this is the kernel the roofline figures below are about
+    check(L.preAlps_hip_timer_start(), "timer_start")
+    for _ in range(a.spmm_reps):
+        check(L.preAlps_BlockJacobiApply(C.byref(dx), C.byref(dy)), "BlockJacobiApply")
+    check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
     bj_s = sec.value / a.spmm_reps
+    prob.panel_free(dx); prob.panel_free(dy)
     bj_bytes = prob.stat("bj_factor_bytes") + 16.0 * m_loc * a.t + 8.0 * m_loc
     # streaming ceilings of this very device (calibration kernels of the library, 1 GiB buffers)
     copy_gbs, read_gbs = C.c_double(), C.c_double()
@@ -376,7 +384,8 @@ def main():
                          "note": "the same product on other panels, without the Gram block (what rounds 1-2 reported)"},
                      "note": "each timed launch follows one preconditioner apply (cache state of the solver loop)"
                              + ("; the solver's product also forms [AP | R]^T P (rows of R counted in the bytes)" if with_gram else "")},
-        "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "factor_bytes": prob.stat("bj_factor_bytes"),
+        "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "solver_apply_us": 1e6 * bj_solver_s, "solver_apply_forms_gram_block": bool(bj_with_gram),
+                         "factor_bytes": prob.stat("bj_factor_bytes"),
                          "traffic": bj_traffic, "frac": bj_bytes / bj_s / 1e9 / HBM_PEAK_GBS,
                          "achieved_GBs": bj_bytes / bj_s / 1e9,
                          # panels of up to 4 columns: ONE stored copy of the band (bj_g4.hip), streamed once by each of
@@ -389,7 +398,9 @@ def main():
                          "streamed_GBs": ((2.0 * prob.stat("bj_g4_bytes") if a.t <= 4 and prob.stat("bj_g4_bytes") > 0 else
                                            prob.stat("bj_factor_bytes")) + 16.0 * m_loc * a.t) / bj_s / 1e9,
                          "note": "achieved_GBs counts the plain two-sweep factor of SURVEY 8(d) (algorithmic bytes) + the "
-                                 "panels; streamed_GBs what the kernel really reads and writes"},
+                                 "panels; streamed_GBs what the kernel really reads and writes; avg_apply_us = the block solve on "
+                                 "panels of its own, solver_apply_us = the solver's AP -> Z, which also reads AP again and AP_prev "
+                                 "for the Gram block beta (16 B x t per row more; the PMC traffic averages both kinds of launch)"},
         "phases": {"iterations": a.phase_iters, "device_us_per_iteration": per_it,
                    "ecg_struct_timers_s": ecg_fields,
                    "note": "hipEvent pairs per phase (max over ranks); dense = gram + trsm + update + small; the pass "
