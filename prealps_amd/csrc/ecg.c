@@ -35,6 +35,13 @@
  * an iteration from HIP graphs captured on the first passes (see seg_begin below); -1 = decide from
  * PREALPS_ECG_GRAPH (default 0) at the next reset. */
 static int g_graphs = -1;
+/* > 0 inside preAlps_ECGSolve / preAlps_ECGAdvance.  Only there does the library ask its SpMM and its block
+ * solve for the Gram blocks of the next half-iteration: between preAlps_BlockOperator / BlockJacobiApply and
+ * preAlps_ECGIterate nothing else touches AP or Z in those loops, whereas a caller that drives the RCI
+ * protocol itself may (a shifted operator, a second preconditioner stage), and the blocks would be stale.
+ * PREALPS_RCI_FUSE=1: also for RCI callers who only call the two library routines. */
+static int g_own_loop = 0;
+static int rci_fuse(void) { static int v = -1; if (v < 0) { const char* e = getenv("PREALPS_RCI_FUSE"); v = e ? atoi(e) : 0; } return v; }
 void preAlps_hip_graphs(int on) { g_graphs = on; }
 
 /* The reference brackets every BLAS / MPI call with MPI_Wtime (ecg.c:316-320 ...).  Launches
@@ -173,8 +180,8 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
  * product P -> AP is the library's SpMM on 4-column panels, ask it to leave that block behind.
  * Called whenever the P / AP pointers have been published; anything else ends the request. */
 static void request_gram_from_spmm(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
-  if (pv->spmm_cap > 0 && pv->fuse && ecg->bs_red == NO_BS_RED && ecg->ortho_alg != ORTHODIR_FUSED &&
-      ecg->enlFac == 4 && ecg->P->info.n == 4)
+  if ((g_own_loop > 0 || rci_fuse()) && pv->spmm_cap > 0 && pv->fuse && ecg->bs_red == NO_BS_RED &&
+      ecg->ortho_alg != ORTHODIR_FUSED && ecg->enlFac == 4 && ecg->P->info.n == 4)
     pa_k_spmm_gram_arm(ecg->P->val, ecg->AP->val, pv->d_R, pv->d_spmm_parts, pv->spmm_cap);
   else
     pa_k_spmm_gram_disarm();
@@ -689,7 +696,8 @@ int _preAlps_ECGIterateOdir(preAlps_ECG_t* ecg, int* rci_request) {
     if (ecg->bs_red == NO_BS_RED && pv->fuse) {
       if (fused_first_half(ecg, pv, t)) return 1;
       /* next: Z = M^-1 AP by the caller, then beta = [AP | AP_prev]^T Z here: ask the block solve for it */
-      if (pv->bj_cap > 0 && t == 4 && ecg->beta->info.m == 8 && ecg->beta->info.lda == 8 && ecg->beta->info.n == 4)
+      if ((g_own_loop > 0 || rci_fuse()) && pv->bj_cap > 0 && t == 4 && ecg->beta->info.m == 8 &&
+          ecg->beta->info.lda == 8 && ecg->beta->info.n == 4)
         pa_k_bj_gram_arm(pv->buf_av[0], pv->buf_z, pv->buf_av[1], pv->d_bj_parts, pv->bj_cap);
       else pa_k_bj_gram_disarm();
     } else {
@@ -906,8 +914,20 @@ void preAlps_ECGPrint(preAlps_ECG_t* ecg, int verbosity) {
 
 /* The driver loop of examples/test_ecg_prealps_op.c:203-223 (fused:
  * examples/test_ecg_bench_fused.c:243-259). */
+static int ecg_solve_loop(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_hist, int* bs_hist,
+                          int max_hist, int* n_hist);
+static void leave_own_loop(void) {
+  if (--g_own_loop == 0) { pa_k_spmm_gram_disarm(); pa_k_bj_gram_disarm(); }
+}
 int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_hist, int* bs_hist,
                      int max_hist, int* n_hist) {
+  ++g_own_loop;
+  int rc = ecg_solve_loop(ecg, rhs, sol, res_hist, bs_hist, max_hist, n_hist);
+  leave_own_loop();
+  return rc;
+}
+static int ecg_solve_loop(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_hist, int* bs_hist,
+                          int max_hist, int* n_hist) {
   int rci = 0, stop = 0, nh = 0;
   if (preAlps_ECGInitialize(ecg, rhs, &rci)) return 1;
   if (preAlps_BlockJacobiApply(ecg->R, ecg->P)) return 1;
@@ -965,8 +985,17 @@ int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_h
 /* Advance the driver loop (examples/test_ecg_prealps_op.c:208-221) by nsteps full
  * iterations, restarting from the same rhs (as after preAlps_ECGInitialize) whenever the
  * stopping test fires; what bench.py times. */
+static int ecg_advance_loop(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int nsteps, int* restarts,
+                            int* last_iters, double* last_res);
 int preAlps_ECGAdvance(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int nsteps, int* restarts,
                        int* last_iters, double* last_res) {
+  ++g_own_loop;
+  int rc = ecg_advance_loop(ecg, rhs, rci_request, nsteps, restarts, last_iters, last_res);
+  leave_own_loop();
+  return rc;
+}
+static int ecg_advance_loop(preAlps_ECG_t* ecg, double* rhs, int* rci_request, int nsteps, int* restarts,
+                            int* last_iters, double* last_res) {
   int stop = 0, done = 0;
   if (ecg->ortho_alg == ORTHODIR_FUSED) {
     /* the loop of examples/test_ecg_bench_fused.c:252-259: one reduction per iteration; *rci_request

@@ -735,6 +735,34 @@ for shard in (None, (0, 3)):
         np.testing.assert_allclose(got.x, ref["x"], rtol=1e-5, atol=1e-7 * np.abs(ref["x"]).max())
     on = os.environ["PREALPS_SPMM_GRAM"] == "1"
     assert prob.stat("spmm_runs") == 1.0
+    if not shard:
+        # a caller that drives the RCI protocol itself gets no Gram blocks from the SpMM / block solve (it may
+        # change AP or Z between the library's routine and preAlps_ECGIterate) -- and the same residuals
+        import ctypes as C
+        import prealps_amd.lib as pl
+        from prealps_amd.lib import check
+        L = prob.L
+        g0, b0 = prob.stat("spmm_gram_launches"), prob.stat("bj_gram_applies")
+        e = prob.new_ecg(4, pl.ORTHODIR, pl.NO_BS_RED, 1e-5, 400)
+        rci, stop = C.c_int(0), C.c_int(0)
+        check(L.preAlps_ECGInitialize(C.byref(e), rhs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(rci)), "init")
+        check(L.preAlps_BlockJacobiApply(e.R, e.P), "bj")
+        hist = []
+        while stop.value != 1:
+            if rci.value == 0:
+                check(L.preAlps_BlockOperator(e.P, e.AP), "op")
+            else:
+                check(L.preAlps_ECGStoppingCriterion(C.byref(e), C.byref(stop)), "stop")
+                hist.append(e.res)
+                if stop.value == 1: break
+                check(L.preAlps_BlockJacobiApply(e.AP, e.Z), "bj")
+            check(L.preAlps_ECGIterate(C.byref(e), C.byref(rci)), "iterate")
+        sol = (C.c_double * prob.m)()
+        check(L.preAlps_ECGFinalize(C.byref(e), sol), "fin")
+        ref = O.ECG(Bs, rps, 4, O.ORTHODIR, O.NO_BS_RED, 1e-5, 400).solve(rhs)
+        assert len(hist) == ref["iters"], (len(hist), ref["iters"])
+        np.testing.assert_allclose(hist[:20], ref["res"][:20], rtol=1e-8)
+        assert prob.stat("spmm_gram_launches") == g0 and prob.stat("bj_gram_applies") == b0
     assert (prob.stat("spmm_gram_launches") - before >= 16) if on else (prob.stat("spmm_gram_launches") == before)
     # the block solve leaves beta = [AP | AP_prev]^T Z behind in the Orthodir solve (every block in one bj_g4 class)
     assert (prob.stat("bj_gram_applies") - before_bj >= 8) if on else (prob.stat("bj_gram_applies") == before_bj)
