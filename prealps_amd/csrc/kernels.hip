@@ -77,6 +77,70 @@ __device__ __forceinline__ void store_row_s(double* __restrict__ p, size_t row, 
   for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(r[2 * i], r[2 * i + 1]);
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// a[s] of lane c  <-  a[c] of lane s, within each quad of lanes (c = lane & 3)
+__device__ __forceinline__ void quad_transpose4(double (&a)[4], int c) {
+  const bool b0 = c & 1, b1 = c & 2;
+#pragma unroll
+  for (int p = 0; p < 4; p += 2) {          // partner lane ^ 1 (quad_perm [1,0,3,2]), registers (p, p+1)
+    const double recv = dpp_mov_f64<0xB1>(b0 ? a[p] : a[p + 1]);
+    a[p] = b0 ? recv : a[p];
+    a[p + 1] = b0 ? a[p + 1] : recv;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {             // partner lane ^ 2 (quad_perm [2,3,0,1]), registers (p, p+2)
+    const double recv = dpp_mov_f64<0x4E>(b1 ? a[p] : a[p + 2]);
+    a[p] = b1 ? recv : a[p];
+    a[p + 2] = b1 ? a[p + 2] : recv;
+  }
+}
+
+// The Gram epilogue of one slice (see k_spmm_runs_gram): acc = the lane's row of Y, xrow(r) = where row r of the
+// slice's X lies (LDS or memory), R rows from memory; gw / gg = the wavefront's two accumulators.
+template <typename XROW>
+__device__ __forceinline__ void spmm_gram_slice(const double (&acc)[4], int nr, int row_s, int lane,
+                                                const double* __restrict__ Rg, XROW xrow, double& gw, double& gg) {
+  const int g4 = lane & ~3, c = lane & 3;
+  double rv[4], xv[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {         // step st: the quad stands for row g4 + st of the slice
+    const int rr = g4 + st;
+    const bool on = rr < nr;
+    rv[st] = on ? Rg[(size_t)(row_s + rr) * 4 + c] : 0.0;
+    xv[st] = on ? xrow(rr)[c] : 0.0;
+  }
+  double ty[4] = {acc[0], acc[1], acc[2], acc[3]};
+  quad_transpose4(ty, c);
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    gw = __builtin_amdgcn_mfma_f64_4x4x4f64(ty[st], xv[st], gw, 0, 0, 0);
+    gg = __builtin_amdgcn_mfma_f64_4x4x4f64(rv[st], xv[st], gg, 0, 0, 0);
+  }
+}
+
+// ... and of the workgroup: the four blocks of a lane's row of 16 lanes (row_ror 4 / 8), then the four
+// wavefronts through the first 128 doubles of the staging area (no wavefront reads it any more after the
+// barrier), one 8 x 4 partial block out.
+__device__ __forceinline__ void spmm_gram_tail(double gw, double gg, double* sx, int wave, int lane, int tid,
+                                               double* __restrict__ gblock) {
+  gw += dpp_mov_f64<0x124>(gw); gw += dpp_mov_f64<0x128>(gw);
+  gg += dpp_mov_f64<0x124>(gg); gg += dpp_mov_f64<0x128>(gg);
+  __syncthreads();
+  if ((lane & 12) == 0) {
+    const int i = lane >> 4, j = lane & 3;
+    sx[wave * 32 + i + 8 * j] = gw;
+    sx[wave * 32 + 4 + i + 8 * j] = gg;
+  }
+  __syncthreads();
+  if (tid < 32) gblock[tid] = ((sx[tid] + sx[32 + tid]) + sx[64 + tid]) + sx[96 + tid];
+}
+
 // ---------------------------------------------------------------- SpMM ----
 // SELL-64 SpMM.  One workgroup per block of slices of one subdomain; the
 // subdomain's own X rows (where ~90 % of the nonzeros of a box partition
@@ -97,14 +161,16 @@ __device__ __forceinline__ void spmm_fma_row(double (&acc)[TS], double v, const 
   }
 }
 
-template <int TS, bool NT>
-__global__ __launch_bounds__(WG) void k_spmm(
+template <int TS, bool NT, bool GRAM>
+__device__ __forceinline__ void spmm_body(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
     const int* __restrict__ col, const double* __restrict__ val,
     const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
     const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y) {
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
+  static_assert(!GRAM || TS == 4, "the fused Gram block is built for 4-column panels");
   extern __shared__ double sx[];
   // XCD-aware order: consecutive logical blocks (which share X rows) run on one XCD.
   const int cpx = (nlist + 7) >> 3;
@@ -122,6 +188,7 @@ __global__ __launch_bounds__(WG) void k_spmm(
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  double gw = 0.0, gg = 0.0;      // GRAM: as in k_spmm_runs_gram
   for (int s = s0 + wave; s < s1; s += WG / 64) {
     const long long off = sl_off[s];
     const int len = sl_len[s];
@@ -140,8 +207,42 @@ __global__ __launch_bounds__(WG) void k_spmm(
       else if (cidx < m) spmm_fma_row<TS>(acc, v, X + (size_t)cidx * TS);
       else spmm_fma_row<TS>(acc, v, Xh + (size_t)(cidx - m) * TS);
     }
-    if (lane < sl_nrows[s]) store_row<TS>(Y, (size_t)(sl_row0[s] + lane), acc);
+    const int nr = sl_nrows[s], row_s = sl_row0[s];
+    if (lane < nr) store_row<TS>(Y, (size_t)(row_s + lane), acc);
+    if constexpr (GRAM) {
+      // a row of the slice's own X: in the window, or (a window cut short by win_cap) in memory
+      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) {
+        const unsigned wi = (unsigned)(row_s + rr - w0);
+        return wi < (unsigned)wlen ? (const double*)(sx + (size_t)wi * 4) : X + (size_t)(row_s + rr) * 4;
+      }, gw, gg);
+    }
   }
+  if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
+}
+
+template <int TS, bool NT>
+__global__ __launch_bounds__(WG) void k_spmm(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const int* __restrict__ col, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
+    const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y) {
+  spmm_body<TS, NT, false>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
+                           X, Xh, Y, nullptr, nullptr, 0);
+}
+
+// 4 columns with the Gram block [Y | R]^T X (see k_spmm_runs_gram)
+__global__ __launch_bounds__(WG) void k_spmm_gram(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const int* __restrict__ col, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
+    const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
+  spmm_body<4, false, true>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
+                            X, Xh, Y, Rg, gpart, gbase);
 }
 
 // Staged SELL-64 SpMM: the block first copies every X row it will touch into
@@ -216,30 +317,6 @@ __global__ __launch_bounds__(WG) void k_spmm_staged(
 // staging area: a 4 x 4 transpose inside each quad of lanes puts 16 rows x 4 columns into the
 // operand layout of v_mfma_f64_4x4x4 (lane 4g + c = column c of row g), four of which cover the
 // 64 rows of a slice; R is read in that layout directly.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-
-// a[s] of lane c  <-  a[c] of lane s, within each quad of lanes (c = lane & 3)
-__device__ __forceinline__ void quad_transpose4(double (&a)[4], int c) {
-  const bool b0 = c & 1, b1 = c & 2;
-#pragma unroll
-  for (int p = 0; p < 4; p += 2) {          // partner lane ^ 1 (quad_perm [1,0,3,2]), registers (p, p+1)
-    const double recv = dpp_mov_f64<0xB1>(b0 ? a[p] : a[p + 1]);
-    a[p] = b0 ? recv : a[p];
-    a[p + 1] = b0 ? a[p + 1] : recv;
-  }
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {             // partner lane ^ 2 (quad_perm [2,3,0,1]), registers (p, p+2)
-    const double recv = dpp_mov_f64<0x4E>(b1 ? a[p] : a[p + 2]);
-    a[p] = b1 ? recv : a[p];
-    a[p + 2] = b1 ? a[p + 2] : recv;
-  }
-}
-
 template <int TS, int XS, bool GRAM>
 __device__ __forceinline__ void spmm_runs_body(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
@@ -313,40 +390,12 @@ __device__ __forceinline__ void spmm_runs_body(
       for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
     }
     if constexpr (GRAM) {
-      const int g4 = lane & ~3, c = lane & 3;
       asm volatile("" ::"v"(touch));
-      double rv[4], xv[4];
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {         // step st: the quad stands for row g4 + st of the slice
-        const int rr = g4 + st;
-        const bool on = rr < nr;
-        rv[st] = on ? Rg[(size_t)(row_s + rr) * 4 + c] : 0.0;
-        xv[st] = on ? sx[(size_t)(nlow + row_s - r0 + rr) * 4 + c] : 0.0;
-      }
-      double ty[4] = {acc[0], acc[1], acc[2], acc[3]};
-      quad_transpose4(ty, c);
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        gw = __builtin_amdgcn_mfma_f64_4x4x4f64(ty[st], xv[st], gw, 0, 0, 0);
-        gg = __builtin_amdgcn_mfma_f64_4x4x4f64(rv[st], xv[st], gg, 0, 0, 0);
-      }
+      const double* own = sx + (size_t)(nlow + row_s - r0) * 4;
+      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) { return own + (size_t)rr * 4; }, gw, gg);
     }
   }
-  if constexpr (GRAM) {
-    // the four blocks of the lane's row of 16 lanes (row_ror 4 / 8), then the four wavefronts
-    // through the staging area, which no wavefront reads any more after the barrier
-    gw += dpp_mov_f64<0x124>(gw); gw += dpp_mov_f64<0x128>(gw);
-    gg += dpp_mov_f64<0x124>(gg); gg += dpp_mov_f64<0x128>(gg);
-    __syncthreads();
-    if ((lane & 12) == 0) {
-      const int i = lane >> 4, j = lane & 3;
-      sx[wave * 32 + i + 8 * j] = gw;
-      sx[wave * 32 + 4 + i + 8 * j] = gg;
-    }
-    __syncthreads();
-    if (tid < 32)
-      gpart[(size_t)(gbase + logical) * 32 + tid] = ((sx[tid] + sx[32 + tid]) + sx[64 + tid]) + sx[96 + tid];
-  }
+  if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
 }
 
 template <int TS, int XS>
@@ -2703,6 +2752,23 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
       g_sg.count += nlist;
       ++g_sg_launches;
       return kfail("k_spmm_runs");
+    }
+    if (g_sg.armed && !pl->runs && !pl->staged && X == g_sg.X && Y == g_sg.Y && g_sg.count >= 0 &&
+        g_sg.count + nlist <= g_sg.cap) {                             // the window kernel (e.g. 7-point Poisson)
+      int win_cap = pl->win_cap;
+      if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
+      const size_t ldsw = (size_t)win_cap * TS * 8;
+      static int ntw = -1;
+      if (ntw < 0) { const char* e = getenv("PREALPS_SPMM_NT"); ntw = e ? atoi(e) : 0; }
+      if (ldsw >= 1024 && !ntw) {
+        const int cpx = (nlist + 7) / 8;
+        PA_LAUNCH(k_spmm_gram, dim3(cpx * 8), dim3(WG), ldsw, cur_stream(), pl->m, pl->sl_off, pl->sl_len,
+                  pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice, pl->blk_win, order, nlist, win_cap,
+                  X, Xh, Y, g_sg.R, g_sg.partials, g_sg.count);
+        g_sg.count += nlist;
+        ++g_sg_launches;
+        return kfail("k_spmm_gram");
+      }
     }
     if (g_sg.armed && X == g_sg.X && Y == g_sg.Y) g_sg.count = -1;    // this product leaves no Gram block
   }

@@ -1219,7 +1219,7 @@ int pa_operator_gram_blocks(int ts) {
    * PREALPS_SPMM_GRAM=0: the separate Gram kernel */
   if (!o->info.built || g_plan_only || ts != 4 || !env_int("PREALPS_SPMM_GRAM", 1)) return 0;
   if (o->plan_ts != ts && build_plan(o, ts)) return 0;
-  return o->plan.runs ? o->plan.nblk : 0;
+  return (o->plan.runs || !o->plan.staged) ? o->plan.nblk : 0;    /* k_spmm_runs_gram, k_spmm_gram; not the staged plan */
 }
 
 /* AX = A X for the X->info.n current columns (operator.c:334-351). */

@@ -10,8 +10,12 @@ import prealps_amd
 from prealps_amd import gen
 name, va, vb = sys.argv[1], sys.argv[2], sys.argv[3]
 t = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-n = 70
-rp, ci, v = gen.elasticity3d_csr(n); part, P = gen.box_partition_nodes(n, (2, 4, 8))
+if os.environ.get("ECG_AB_WORKLOAD") == "poisson":       # BASELINE configs[1]
+    n = 100
+    rp, ci, v = gen.poisson3d_csr(n); part, P = gen.box_partition(n, (5, 5, 10))
+else:
+    n = 70
+    rp, ci, v = gen.elasticity3d_csr(n); part, P = gen.box_partition_nodes(n, (2, 4, 8))
 prob = prealps_amd.EcgProblem(rp, ci, v, P, part, scale=True, device=0)
 rhs = prob.reference_rhs()
 prob.solve(rhs, t, tol=1e-30, max_iter=50)
