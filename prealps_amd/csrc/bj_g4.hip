@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
   g4_fwd_tiles<NC, NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring);
 
   // y = D^-2 a
+  double ga_mid = 0.0;
   {
     const double* __restrict__ dv = invd_f + r0;
     double d[NT];
@@ -398,7 +399,18 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int q = 0; q < NT; ++q) T[c * NT + q] *= d[q] * d[q];
+      for (int q = 0; q < NT; ++q) {
+        const double a = T[c * NT + q];
+        T[c * NT + q] *= d[q] * d[q];
+        // in^T out = in^T L^-T D^-2 L^-1 in = a^T (D^-2 a): the first Gram block of pa_k_bj_g4_gram costs no
+        // load at all here, both operands are this tile (rows beyond the block masked out)
+        if constexpr (NC == 1) {
+          if (gpart) {
+            const bool on = 16 * q + trow < b;
+            ga_mid = __builtin_amdgcn_mfma_f64_4x4x4f64(on ? a : 0.0, on ? T[q] : 0.0, ga_mid, 0, 0, 0);
+          }
+        }
+      }
   }
   // (the last chunk of the forward sweep is the first of the backward one: it is still in its buffer,
   // and so is the one before it -- g4_bwd_chunk does not fetch that one again)
@@ -435,16 +447,15 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     // the result is still in registers.  A tile (lane = 16 hi + 4 blk + lo: row 4 blk + hi, column lo) is
     // the B operand of v_mfma_f64_4x4x4 as it stands (k = hi); the A operand, row 4 blk + k of the other
     // panel in column i = lo, sits at the tile's own address.  8 x 4 per block, the layout of k_gram<4, 2>.
+    // in^T out was formed between the sweeps (ga_mid); gprev^T out needs the rows of gprev.
     if constexpr (NC == 1) {
       if (gpart) {
-        double ga = 0.0, gp = 0.0;
+        double ga = ga_mid, gp = 0.0;
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
           const bool on = 16 * q + trow3 < b;
-          const double a = on ? in[rowoff[q]] : 0.0;
           const double ap = on ? gprev[rowoff[q]] : 0.0;
           const double z = on ? T[q] : 0.0;
-          ga = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z, ga, 0, 0, 0);
           gp = __builtin_amdgcn_mfma_f64_4x4x4f64(ap, z, gp, 0, 0, 0);
         }
         ga += row_ror<4>(ga); ga += row_ror<8>(ga);
