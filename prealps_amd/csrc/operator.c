@@ -1213,13 +1213,18 @@ int preAlps_hip_debug_move_plan(int which) {
 
 int pa_operator_gram_blocks(int ts) {
   pa_operator_t* o = &g_op;
-  /* measured inside one process with the two variants alternating (tools/probe/spmm_gram_ab.py,
-   * ecg_gram_ab.py): the SpMM with the block takes 9.5-11 us longer (159 against 149 us), the sum 8.7 us
-   * instead of 19.8 + 8.3 us for k_gram and its sum: 11-12 us per ECG iteration saved (409.5 -> 397.7 us).
-   * PREALPS_SPMM_GRAM=0: the separate Gram kernel */
-  if (!o->info.built || g_plan_only || ts != 4 || !env_int("PREALPS_SPMM_GRAM", 1)) return 0;
+  if (!o->info.built || g_plan_only || ts != 4) return 0;
   if (o->plan_ts != ts && build_plan(o, ts)) return 0;
-  return (o->plan.runs || !o->plan.staged) ? o->plan.nblk : 0;    /* k_spmm_runs_gram, k_spmm_gram; not the staged plan */
+  if (o->plan.staged && !o->plan.runs) return 0;            /* (the staged plan has no such kernel) */
+  /* Default, from absolute times of 800-iteration solves alternating in one process (tools/probe/abs_ab.py):
+   * the window kernel (k_spmm_gram; Poisson 100^3) 245.3 -> 236.9 us per iteration with the block: on.  The run
+   * kernel (k_spmm_runs_gram; elasticity 70^3): 397.0 -> 399.0 us with it in one process -- its epilogue and
+   * the rows of R cost what k_gram and its sum cost -- so off there; with several processes (small shards,
+   * every launch at its latency floor) it saves a launch, 113 -> 107 us on the one-shard rehearsal: on.
+   * PREALPS_SPMM_GRAM=0 / 1 forces. */
+  int dflt = !o->plan.runs || pa_world_size() > 1;
+  if (!env_int("PREALPS_SPMM_GRAM", dflt)) return 0;
+  return o->plan.nblk;
 }
 
 /* AX = A X for the X->info.n current columns (operator.c:334-351). */
