@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Same process, alternating: ECG iterations of the headline problem under two settings of a switch
+
+NOTE: superseded by abs_ab.py / abs_ab_sync.py -- the first solve after a switch pays for new allocations, which
+bends the slope this script computes (it read 11-12 us for a change that absolute 800-iteration times put at 0)."""Same process, alternating: ECG iterations of the headline problem under two settings of a switch
 that the library reads when a solver is created.  usage: ecg_ab.py NAME A B [t]   (NAME = an environment
 variable, or GRAPHS for preAlps_hip_graphs(A / B)).  Per-iteration time = difference of a 500- and a
 200-iteration solve (tol far below reach), so set-up and wrap-up cancel."""
