@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-
-NOTE: superseded by abs_ab.py / abs_ab_sync.py -- the first solve after a switch pays for new allocations, which
-bends the slope this script computes (it read 11-12 us for a change that absolute 800-iteration times put at 0)."""Same process, alternating: ECG iterations of the headline problem under two settings of a switch
+"""Same process, alternating: ECG iterations of the headline problem under two settings of a switch
 that the library reads when a solver is created.  usage: ecg_ab.py NAME A B [t]   (NAME = an environment
 variable, or GRAPHS for preAlps_hip_graphs(A / B)).  Per-iteration time = difference of a 500- and a
-200-iteration solve (tol far below reach), so set-up and wrap-up cancel."""
+200-iteration solve (tol far below reach), so set-up and wrap-up cancel.
+NOTE: superseded by abs_ab.py / abs_ab_sync.py -- the first solve after a switch pays for new allocations, which
+bends the slope this script computes (it read 11-12 us for a change that absolute 800-iteration times put at 0)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
