@@ -302,41 +302,64 @@ __device__ __forceinline__ void g4_fwd_tiles(double (&T)[NC * NT], int b, int w,
 
 // Backward: the last `ring` chunks are still where the forward sweep left them; chunk c requests chunk
 // c - (ring - 1) unless that one is among them.
-template <int NC, int NT, int DQ, int Q, int H>
+//
+// GP (the Gram block [in | prev]^T out of pa_k_bj_g4_gram): tile Q is final when its chunk H = 0 is done, and
+// its share prev(tile)^T z(tile) needs the tile's rows of `prev`.  Loaded behind the sweep by every wavefront at
+// once they arrive as one burst after the factor stream has ended (round 3: 137 us against 112 us for the
+// plain launch).  Here chunk (Q, 0) requests the rows of tile Q right behind its chunk request -- one more
+// VMEM operation among the LDS-DMAs, hand-issued so that the wait counts stay ours (the compiler's own count
+// would have to cover the chunk request and wait for it) -- and chunk (Q - 1, 1), whose wait covers everything
+// older than ITS chunk request, takes the product.  One register pair in flight; tile 0 is taken behind the sweep.
+struct g4_gram { const double* prev; unsigned base, xs; double ap, gp; };     // prev + (base + map * xs): the lane's entry of a row
+
+template <int NC, int NT, int DQ, int Q, int H, bool GP>
 __device__ __forceinline__ void g4_bwd_chunk(double (&T)[NC * NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                             int ring) {
+                                             int ring, g4_gram& gr, int trow, const unsigned (&mpk)[(NT + 3) / 4]) {
   constexpr int C = 2 * Q + H;
   const int nch = (b + 7) >> 3, nld = (chunk_doubles + 127) >> 7;
   const int cn = C - (ring - 1);
   if (cn >= 0 && C < nch - 1) g4_issue_chunk(rec, chunk_doubles, cn, lds0 + (cn & (ring - 1)) * lstride, lane);
+  int extra = 0;
+  if constexpr (GP && H == 0) {
+    const double* src = gr.prev + (gr.base + ((mpk[Q >> 2] >> (8 * (Q & 3))) & 255u) * gr.xs);
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(gr.ap) : "v"(src) : "memory");
+    extra = ring == 2 ? 1 : 0;          // (deeper rings: not counted, the wait then covers one piece more)
+  }
   {
     // chunks requested by this sweep that lie below c: indices max(0, c - ring + 1) .. min(c - 1, nch - ring - 1)
     const int lo = max(0, C - ring + 1), hi = min(C - 1, nch - ring - 1);
-    g4_wait_vm(max(0, hi - lo + 1) * nld);
+    g4_wait_vm(max(0, hi - lo + 1) * nld + extra);
+  }
+  if constexpr (GP && H == 1 && Q + 1 < NT) {
+    if (16 * (Q + 1) < b) {             // the rows of tile Q + 1 are here (requested before this chunk's own request)
+      asm volatile("" : "+v"(gr.ap));
+      const double z = 16 * (Q + 1) + trow < b ? T[Q + 1] : 0.0;
+      gr.gp = __builtin_amdgcn_mfma_f64_4x4x4f64(gr.ap, z, gr.gp, 0, 0, 0);
+    }
   }
   const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (ring - 1)) * lstride);
   g4_bwd_group<NC, NT, DQ, Q, 2 * H + 1>(T, cur + (unsigned)(w + 4) * 32u, w, ln);
   g4_bwd_group<NC, NT, DQ, Q, 2 * H>(T, cur, w, ln);
   asm volatile("" ::: "memory");
 }
-template <int NC, int NT, int DQ, int Q>
+template <int NC, int NT, int DQ, int Q, bool GP>
 __device__ __forceinline__ void g4_bwd_tiles(double (&T)[NC * NT], int b, int w, const double* __restrict__ rec,
                                              int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                             int ring) {
+                                             int ring, g4_gram& gr, int trow, const unsigned (&mpk)[(NT + 3) / 4]) {
   if constexpr (Q >= 0) {
     if (16 * Q < b) {
-      if (16 * Q + 8 < b) g4_bwd_chunk<NC, NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
-      g4_bwd_chunk<NC, NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+      if (16 * Q + 8 < b) g4_bwd_chunk<NC, NT, DQ, Q, 1, GP>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, gr, trow, mpk);
+      g4_bwd_chunk<NC, NT, DQ, Q, 0, GP>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, gr, trow, mpk);
     }
-    g4_bwd_tiles<NC, NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring);
+    g4_bwd_tiles<NC, NT, DQ, Q - 1, GP>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, gr, trow, mpk);
   }
 }
 
 // One wavefront per block.  NT tiles of 16 rows (b <= 16 NT), DQ = tiles a group's record reaches
 // (w + 15 < 16 DQ).  `xs` = row stride of the panels in doubles (2, 4; 8 / 16 when the kernel is
 // launched on a 4-column slice of a wider panel), `ncol` <= 4 columns starting at `in` / `out`.
-template <int NC, int NT, int DQ, int OCC>
+template <int NC, int NT, int DQ, int OCC, bool GP>
 __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     const int* __restrict__ list, int count, const int* __restrict__ row0, const int* __restrict__ nrows,
     const int* __restrict__ bw, const long long* __restrict__ off2, const int* __restrict__ map_f,
@@ -372,17 +395,36 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
   g4_issue_chunk(rec, chunk_doubles, 0, lds0, lane);
   double T[NC * NT];
   const int* __restrict__ mp = map_f + r0;
+  // Where the block's rows lie in the panel: row r0 + map[j], map < b <= 256 -- four of them to a register,
+  // kept across both sweeps (the addresses themselves would be NT registers; gathered again behind the
+  // backward sweep they put a dependent memory latency at the end of every block).
+  unsigned mpk[(NT + 3) / 4];        // (the host checks that m * xs fits 31 bits)
+#pragma unroll
+  for (int q = 0; q < (NT + 3) / 4; ++q) mpk[q] = 0u;
   {
-    unsigned rowoff[NT];        // (the host checks that m * xs fits 31 bits)
+    unsigned mpv[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int j = 16 * q + trow;
-      rowoff[q] = ((unsigned)r0 + (unsigned)mp[j < b ? j : 0]) * (unsigned)xs + lo;
+      mpv[q] = (unsigned)mp[j < b ? j : 0];
+    }
+    // (every load unconditional, rows and columns beyond the block's clamped onto valid ones and masked
+    // afterwards: a load inside a branch makes the compiler wait for everything in flight at the join, and
+    // the NT loads of a block would come one memory latency after the other)
+    const unsigned loc = (unsigned)min(lo, ncol - 1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const unsigned cc = (unsigned)min(4 * c, max(ncol - 1 - (int)loc, 0));
+#pragma unroll
+      for (int q = 0; q < NT; ++q) T[c * NT + q] = in[((unsigned)r0 + mpv[q]) * (unsigned)xs + loc + cc];
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int q = 0; q < NT; ++q) T[c * NT + q] = (16 * q + trow < b && 4 * c + lo < ncol) ? in[rowoff[q] + 4 * c] : 0.0;
+      for (int q = 0; q < NT; ++q)
+        T[c * NT + q] = (16 * q + trow < b && 4 * c + lo < ncol) ? T[c * NT + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) mpk[q >> 2] |= mpv[q] << (8 * (q & 3));
   }
   // the rest of the ring behind the panel loads, so that the newest requests are all chunks
   for (int c = 1; c < ring - 1 && 8 * c < b; ++c) g4_issue_chunk(rec, chunk_doubles, c, lds0 + c * lstride, lane);
@@ -404,16 +446,16 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
         T[c * NT + q] *= d[q] * d[q];
         // in^T out = in^T L^-T D^-2 L^-1 in = a^T (D^-2 a): the first Gram block of pa_k_bj_g4_gram costs no
         // load at all here, both operands are this tile (rows beyond the block masked out)
-        if constexpr (NC == 1) {
-          if (gpart) {
-            const bool on = 16 * q + trow < b;
-            ga_mid = __builtin_amdgcn_mfma_f64_4x4x4f64(on ? a : 0.0, on ? T[q] : 0.0, ga_mid, 0, 0, 0);
-          }
+        if constexpr (GP) {
+          const bool on = 16 * q + trow < b;
+          ga_mid = __builtin_amdgcn_mfma_f64_4x4x4f64(on ? a : 0.0, on ? T[q] : 0.0, ga_mid, 0, 0, 0);
         }
       }
   }
   // (the last chunk of the forward sweep is the first of the backward one: it is still in its buffer,
   // and so is the one before it -- g4_bwd_chunk does not fetch that one again)
+  g4_gram gr;
+  gr.prev = gprev; gr.base = 0u; gr.xs = (unsigned)xs; gr.ap = 0.0; gr.gp = 0.0;
   {
     int l2 = lane;
     asm volatile("" : "+v"(l2));                   // (recomputed here rather than kept across the forward sweep)
@@ -424,7 +466,8 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     lb.cg = (unsigned)hi2 * 32u + (unsigned)lo2 * 8u;    // Lt(hi, lo): the transposed corner
     lb.hi = hi2;
     lb.blk = blk2;
-    g4_bwd_tiles<NC, NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring);
+    gr.base = (unsigned)r0 * (unsigned)xs + (unsigned)lo2;
+    g4_bwd_tiles<NC, NT, DQ, NT - 1, GP>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring, gr, 4 * blk2 + hi2, mpk);
   }
 
   {
@@ -433,39 +476,32 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     const int trow3 = 4 * ((l3 >> 2) & 3) + (l3 >> 4), lo3 = l3 & 3;
     unsigned rowoff[NT];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-      const int j = 16 * q + trow3;
-      rowoff[q] = ((unsigned)r0 + (unsigned)mp[j < b ? j : 0]) * (unsigned)xs + lo3;
+    for (int q = 0; q < NT; ++q)
+      rowoff[q] = ((unsigned)r0 + ((mpk[q >> 2] >> (8 * (q & 3))) & 255u)) * (unsigned)xs + lo3;
+    if constexpr (GP) {          // tile 0's rows of gprev: the one operation still in flight (taken before the stores)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(gr.ap) :: "memory");
+      gr.gp = __builtin_amdgcn_mfma_f64_4x4x4f64(gr.ap, trow3 < b ? T[0] : 0.0, gr.gp, 0, 0, 0);
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int q = 0; q < NT; ++q)
         if (16 * q + trow3 < b && 4 * c + lo3 < ncol) out[rowoff[q] + 4 * c] = T[c * NT + q];
-    // gpart != null (4-column panels, pa_k_bj_g4_gram): the block's share of [in | gprev]^T out -- the Gram
-    // block the ECG iteration forms right after the apply (beta = [AP | AP_prev]^T Z, ecg.c:510) -- while
-    // the result is still in registers.  A tile (lane = 16 hi + 4 blk + lo: row 4 blk + hi, column lo) is
-    // the B operand of v_mfma_f64_4x4x4 as it stands (k = hi); the A operand, row 4 blk + k of the other
-    // panel in column i = lo, sits at the tile's own address.  8 x 4 per block, the layout of k_gram<4, 2>.
-    // in^T out was formed between the sweeps (ga_mid); gprev^T out needs the rows of gprev.
-    if constexpr (NC == 1) {
-      if (gpart) {
-        double ga = ga_mid, gp = 0.0;
-#pragma unroll
-        for (int q = 0; q < NT; ++q) {
-          const bool on = 16 * q + trow3 < b;
-          const double ap = on ? gprev[rowoff[q]] : 0.0;
-          const double z = on ? T[q] : 0.0;
-          gp = __builtin_amdgcn_mfma_f64_4x4x4f64(ap, z, gp, 0, 0, 0);
-        }
-        ga += row_ror<4>(ga); ga += row_ror<8>(ga);
-        gp += row_ror<4>(gp); gp += row_ror<8>(gp);
-        if (((l3 >> 2) & 3) == 0) {
-          const int i = l3 >> 4;
-          double* gq = gpart + (size_t)pi * 32;
-          gq[i + 8 * lo3] = ga;
-          gq[4 + i + 8 * lo3] = gp;
-        }
+    // GP (4-column panels, pa_k_bj_g4_gram): the block's share of [in | gprev]^T out -- the Gram block the ECG
+    // iteration forms right after the apply (beta = [AP | AP_prev]^T Z, ecg.c:510) -- while the result is still
+    // in registers.  A tile (lane = 16 hi + 4 blk + lo: row 4 blk + hi, column lo) is the B operand of
+    // v_mfma_f64_4x4x4 as it stands (k = hi); the A operand, row 4 blk + k of the other panel in column i = lo,
+    // sits at the tile's own address.  8 x 4 per block, the layout of k_gram<4, 2>.  in^T out was formed between
+    // the sweeps (ga_mid); the rows of gprev came in during the backward sweep (g4_bwd_chunk), tile 0 last.
+    if constexpr (GP) {
+      double ga = ga_mid, gp = gr.gp;
+      ga += row_ror<4>(ga); ga += row_ror<8>(ga);
+      gp += row_ror<4>(gp); gp += row_ror<8>(gp);
+      if (((l3 >> 2) & 3) == 0) {
+        const int i = l3 >> 4;
+        double* gq = gpart + (size_t)pi * 32;
+        gq[i + 8 * lo3] = ga;
+        gq[4 + i + 8 * lo3] = gp;
       }
     }
   }
@@ -504,16 +540,25 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
   const size_t lds = (size_t)waves * per_wave * 8;
   static size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NC, NT, DQ, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NC, NT, DQ, OCC, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        (NC == 1 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NC, NT, DQ, OCC, NC == 1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
       return kfail("hipFuncSetAttribute(k_bj_g4)");
     configured = lds;
   }
   const int blocks = (count + waves - 1) / waves;
-  const bool gram = NC == 1 && pa_g4_gram_part && xs == 4 && ncol == 4;
-  PA_LAUNCH((k_bj_g4<NC, NT, DQ, OCC>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
-                     pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out,
-                     gram ? pa_g4_gram_prev : (const double*)nullptr, gram ? pa_g4_gram_part : (double*)nullptr);
+  if constexpr (NC == 1) {
+    if (pa_g4_gram_part && xs == 4 && ncol == 4) {
+      PA_LAUNCH((k_bj_g4<NC, NT, DQ, OCC, true>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
+                pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out,
+                pa_g4_gram_prev, pa_g4_gram_part);
+      return kfail("k_bj_g4");
+    }
+  }
+  PA_LAUNCH((k_bj_g4<NC, NT, DQ, OCC, false>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
+            pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out,
+            (const double*)nullptr, (double*)nullptr);
   return kfail("k_bj_g4");
 }
 

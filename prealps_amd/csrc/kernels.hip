@@ -6,433 +6,10 @@
 // tall-skinny kernels t/8..t/4 flop/B against a ridge of ~10 flop/B), so the
 // design rules are coalesced 16-B accesses, LDS staging where rows are reused,
 // 64-wide shuffle reductions, and XCD-aware block order for the SpMM gathers.
-#include <hip/hip_runtime.h>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include "pa_device.h"
+#include "kernels_common.h"
 
-// a launch that a replayed graph segment makes in its place is skipped (runtime.hip: pa_rt_skip)
-#define PA_LAUNCH(...) do { if (!pa_rt_skipping()) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 namespace {
-
-constexpr int WG = 256;           // 4 wavefronts of 64
-constexpr int GRAM_MAX_BLOCKS = 512;
-
-inline hipStream_t cur_stream() { return (hipStream_t)pa_rt_stream(); }
-
-char g_kerr[256];
-int kfail(const char* what) {
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) return 0;
-  snprintf(g_kerr, sizeof(g_kerr), "%s: %s", what, hipGetErrorString(e));
-  fprintf(stderr, "[prealps_hip] kernel launch failed: %s\n", g_kerr);
-  return 1;
-}
-
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));   // C/D operand of v_mfma_f64_16x16x4
-
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, lane);
-  hi = __builtin_amdgcn_readlane(hi, lane);
-  return __hiloint2double(hi, lo);
-}
-
-// Load / store one panel row of TS doubles with 16-byte accesses.
-template <int TS>
-__device__ __forceinline__ void load_row(const double* __restrict__ p, size_t row, double (&r)[TS]) {
-  const double2* q = reinterpret_cast<const double2*>(p + row * TS);
-#pragma unroll
-  for (int i = 0; i < TS / 2; ++i) {
-    double2 v = q[i];
-    r[2 * i] = v.x;
-    r[2 * i + 1] = v.y;
-  }
-}
-template <int TS>
-__device__ __forceinline__ void store_row(double* __restrict__ p, size_t row, const double (&r)[TS]) {
-  double2* q = reinterpret_cast<double2*>(p + row * TS);
-#pragma unroll
-  for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(r[2 * i], r[2 * i + 1]);
-}
-
-// The same for TS columns of a panel whose rows are XS doubles apart (p already points at the
-// first of those columns).
-template <int TS, int XS>
-__device__ __forceinline__ void load_row_s(const double* __restrict__ p, size_t row, double (&r)[TS]) {
-  const double2* q = reinterpret_cast<const double2*>(p + row * XS);
-#pragma unroll
-  for (int i = 0; i < TS / 2; ++i) {
-    double2 v = q[i];
-    r[2 * i] = v.x;
-    r[2 * i + 1] = v.y;
-  }
-}
-template <int TS, int XS>
-__device__ __forceinline__ void store_row_s(double* __restrict__ p, size_t row, const double (&r)[TS]) {
-  double2* q = reinterpret_cast<double2*>(p + row * XS);
-#pragma unroll
-  for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(r[2 * i], r[2 * i + 1]);
-}
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-
-// a[s] of lane c  <-  a[c] of lane s, within each quad of lanes (c = lane & 3)
-__device__ __forceinline__ void quad_transpose4(double (&a)[4], int c) {
-  const bool b0 = c & 1, b1 = c & 2;
-#pragma unroll
-  for (int p = 0; p < 4; p += 2) {          // partner lane ^ 1 (quad_perm [1,0,3,2]), registers (p, p+1)
-    const double recv = dpp_mov_f64<0xB1>(b0 ? a[p] : a[p + 1]);
-    a[p] = b0 ? recv : a[p];
-    a[p + 1] = b0 ? a[p + 1] : recv;
-  }
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {             // partner lane ^ 2 (quad_perm [2,3,0,1]), registers (p, p+2)
-    const double recv = dpp_mov_f64<0x4E>(b1 ? a[p] : a[p + 2]);
-    a[p] = b1 ? recv : a[p];
-    a[p + 2] = b1 ? a[p + 2] : recv;
-  }
-}
-
-// The Gram epilogue of one slice (see k_spmm_runs_gram): acc = the lane's row of Y, xrow(r) = where row r of the
-// slice's X lies (LDS or memory), R rows from memory; gw / gg = the wavefront's two accumulators.
-template <typename XROW>
-__device__ __forceinline__ void spmm_gram_slice(const double (&acc)[4], int nr, int row_s, int lane,
-                                                const double* __restrict__ Rg, XROW xrow, double& gw, double& gg) {
-  const int g4 = lane & ~3, c = lane & 3;
-  double rv[4], xv[4];
-#pragma unroll
-  for (int st = 0; st < 4; ++st) {         // step st: the quad stands for row g4 + st of the slice
-    const int rr = g4 + st;
-    const bool on = rr < nr;
-    rv[st] = on ? Rg[(size_t)(row_s + rr) * 4 + c] : 0.0;
-    xv[st] = on ? xrow(rr)[c] : 0.0;
-  }
-  double ty[4] = {acc[0], acc[1], acc[2], acc[3]};
-  quad_transpose4(ty, c);
-#pragma unroll
-  for (int st = 0; st < 4; ++st) {
-    gw = __builtin_amdgcn_mfma_f64_4x4x4f64(ty[st], xv[st], gw, 0, 0, 0);
-    gg = __builtin_amdgcn_mfma_f64_4x4x4f64(rv[st], xv[st], gg, 0, 0, 0);
-  }
-}
-
-// ... and of the workgroup: the four blocks of a lane's row of 16 lanes (row_ror 4 / 8), then the four
-// wavefronts through the first 128 doubles of the staging area (no wavefront reads it any more after the
-// barrier), one 8 x 4 partial block out.
-__device__ __forceinline__ void spmm_gram_tail(double gw, double gg, double* sx, int wave, int lane, int tid,
-                                               double* __restrict__ gblock) {
-  gw += dpp_mov_f64<0x124>(gw); gw += dpp_mov_f64<0x128>(gw);
-  gg += dpp_mov_f64<0x124>(gg); gg += dpp_mov_f64<0x128>(gg);
-  __syncthreads();
-  if ((lane & 12) == 0) {
-    const int i = lane >> 4, j = lane & 3;
-    sx[wave * 32 + i + 8 * j] = gw;
-    sx[wave * 32 + 4 + i + 8 * j] = gg;
-  }
-  __syncthreads();
-  if (tid < 32) gblock[tid] = ((sx[tid] + sx[32 + tid]) + sx[64 + tid]) + sx[96 + tid];
-}
-
-// ---------------------------------------------------------------- SpMM ----
-// SELL-64 SpMM.  One workgroup per block of slices of one subdomain; the
-// subdomain's own X rows (where ~90 % of the nonzeros of a box partition
-// point) are staged once into LDS with coalesced 16-B loads, every wavefront
-// then walks whole slices: lane r owns row r of the slice, keeps its TS sums
-// in registers and reads val/col of entry k at [off + k*64 + r] -- one fully
-// coalesced 512-B / 256-B load per wave instruction for the 12 B/nonzero
-// stream.  Columns outside the window (neighbour subdomains, halo rows) are
-// gathered as whole 8*TS-byte rows from L2.
-template <int TS>
-__device__ __forceinline__ void spmm_fma_row(double (&acc)[TS], double v, const double* __restrict__ xr) {
-  const double2* q = reinterpret_cast<const double2*>(xr);
-#pragma unroll
-  for (int i = 0; i < TS / 2; ++i) {
-    const double2 x = q[i];
-    acc[2 * i] = fma(v, x.x, acc[2 * i]);
-    acc[2 * i + 1] = fma(v, x.y, acc[2 * i + 1]);
-  }
-}
-
-template <int TS, bool NT, bool GRAM>
-__device__ __forceinline__ void spmm_body(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const int* __restrict__ col, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
-    const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y,
-    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
-  static_assert(!GRAM || TS == 4, "the fused Gram block is built for 4-column panels");
-  extern __shared__ double sx[];
-  // XCD-aware order: consecutive logical blocks (which share X rows) run on one XCD.
-  const int cpx = (nlist + 7) >> 3;
-  const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-  if (logical >= nlist) return;
-  const int b = order[logical];
-  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
-  const int w0 = blk_win[2 * b];
-  const int wlen = min(blk_win[2 * b + 1] - w0, win_cap);
-  const int tid = threadIdx.x;
-  {
-    const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)w0 * TS);
-    const int nx2 = (wlen * TS) >> 1;
-    for (int i = tid; i < nx2; i += WG) reinterpret_cast<double2*>(sx)[i] = xsrc[i];
-  }
-  __syncthreads();
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  double gw = 0.0, gg = 0.0;      // GRAM: as in k_spmm_runs_gram
-  for (int s = s0 + wave; s < s1; s += WG / 64) {
-    const long long off = sl_off[s];
-    const int len = sl_len[s];
-    const int* __restrict__ cp = col + off + lane;
-    const double* __restrict__ vp = val + off + lane;
-    double acc[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < len; ++k) {
-      // the matrix is streamed once: keep it out of the way of the X rows in L2
-      const double v = NT ? __builtin_nontemporal_load(vp + (size_t)k * 64) : vp[(size_t)k * 64];
-      const int cidx = NT ? __builtin_nontemporal_load(cp + (size_t)k * 64) : cp[(size_t)k * 64];
-      const unsigned wi = (unsigned)(cidx - w0);
-      if (wi < (unsigned)wlen) spmm_fma_row<TS>(acc, v, sx + (size_t)wi * TS);
-      else if (cidx < m) spmm_fma_row<TS>(acc, v, X + (size_t)cidx * TS);
-      else spmm_fma_row<TS>(acc, v, Xh + (size_t)(cidx - m) * TS);
-    }
-    const int nr = sl_nrows[s], row_s = sl_row0[s];
-    if (lane < nr) store_row<TS>(Y, (size_t)(row_s + lane), acc);
-    if constexpr (GRAM) {
-      // a row of the slice's own X: in the window, or (a window cut short by win_cap) in memory
-      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) {
-        const unsigned wi = (unsigned)(row_s + rr - w0);
-        return wi < (unsigned)wlen ? (const double*)(sx + (size_t)wi * 4) : X + (size_t)(row_s + rr) * 4;
-      }, gw, gg);
-    }
-  }
-  if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
-}
-
-template <int TS, bool NT>
-__global__ __launch_bounds__(WG) void k_spmm(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const int* __restrict__ col, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
-    const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y) {
-  spmm_body<TS, NT, false>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
-                           X, Xh, Y, nullptr, nullptr, 0);
-}
-
-// 4 columns with the Gram block [Y | R]^T X (see k_spmm_runs_gram)
-__global__ __launch_bounds__(WG) void k_spmm_gram(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const int* __restrict__ col, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
-    const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y,
-    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
-  spmm_body<4, false, true>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
-                            X, Xh, Y, Rg, gpart, gbase);
-}
-
-// Staged SELL-64 SpMM: the block first copies every X row it will touch into
-// LDS (own rows as one coalesced range, then the listed neighbour / halo rows,
-// 16 B per lane), so the inner loop is branch-free: one coalesced 8-B value,
-// one coalesced 2-B LDS slot, TS/2 ds_read_b128 and TS FMAs per nonzero, and
-// the matrix stream shrinks from 12 to 10 bytes per nonzero.
-template <int TS>
-__global__ __launch_bounds__(WG) void k_spmm_staged(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ col16, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
-    const int* __restrict__ ext_rows, const int* __restrict__ order, int nlist,
-    const double* __restrict__ X, const double* __restrict__ Xh, double* __restrict__ Y) {
-  extern __shared__ double sx[];
-  const int cpx = (nlist + 7) >> 3;
-  const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-  if (logical >= nlist) return;
-  const int b = order[logical];
-  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
-  const int r0 = sl_row0[s0];
-  const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
-  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0;
-  const int tid = threadIdx.x;
-  constexpr int H = TS / 2;  // double2 per row
-  {
-    const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)r0 * TS);
-    double2* dst = reinterpret_cast<double2*>(sx);
-    for (int i = tid; i < nown * H; i += WG) dst[i] = xsrc[i];
-    for (int q = tid; q < next * H; q += WG) {
-      const int i = q / H, j = q - i * H;
-      const int id = ext_rows[e0 + i];
-      const double2* src = reinterpret_cast<const double2*>(id < m ? X + (size_t)id * TS
-                                                                     : Xh + (size_t)(id - m) * TS);
-      dst[(size_t)(nown + i) * H + j] = src[j];
-    }
-  }
-  __syncthreads();
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  for (int s = s0 + wave; s < s1; s += WG / 64) {
-    const long long off = sl_off[s];
-    const int len = sl_len[s];
-    const unsigned short* __restrict__ cp = col16 + off + lane;
-    const double* __restrict__ vp = val + off + lane;
-    double acc[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < len; ++k) {
-      const double v = vp[(size_t)k * 64];
-      const int slot = cp[(size_t)k * 64];
-      spmm_fma_row<TS>(acc, v, sx + (size_t)slot * TS);
-    }
-    if (lane < sl_nrows[s]) store_row<TS>(Y, (size_t)(sl_row0[s] + lane), acc);
-  }
-}
-
-// Staged SpMM over runs of three consecutive LDS slots (rows whose nonzeros sit in groups
-// of neighbouring columns, e.g. the 3 dofs of a node): per run one coalesced 2-B slot, three
-// coalesced 8-B values and 3*TS/2 ds_read_b128 off one address -- 8.67 B of matrix stream
-// per nonzero instead of 10 and a third of the index arithmetic.  The staging area is
-// [external rows below | own rows | external rows above | two zero rows].
-// XS = panel stride in doubles.  XS = 2 TS splits a wide panel by columns: two workgroups per
-// block (neighbours in the dispatch order of one XCD, so the second one finds the matrix slice
-// in that XCD's L2), each staging and computing TS of the XS columns.
-//
-// GRAM (4-column panels): the workgroup also leaves the block's share of [Y | R]^T X -- the
-// Gram block the ECG iteration forms right after A P (ecg.c:425-436: W = AP^T P, G^T = R^T P)
-// -- in gpart[gbase + logical] (8 x 4, column major, the layout of k_gram<4, 2>), so that the
-// panels are not read a second time.  Y rows sit one per lane in registers and X rows in the
-// staging area: a 4 x 4 transpose inside each quad of lanes puts 16 rows x 4 columns into the
-// operand layout of v_mfma_f64_4x4x4 (lane 4g + c = column c of row g), four of which cover the
-// 64 rows of a slice; R is read in that layout directly.
-template <int TS, int XS, bool GRAM>
-__device__ __forceinline__ void spmm_runs_body(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
-    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
-    const int* __restrict__ order, int nlist, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y,
-    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
-  static_assert(!GRAM || (TS == 4 && XS == 4), "the fused Gram block is built for 4-column panels");
-  extern __shared__ double sx[];
-  constexpr int NS = XS / TS;
-  const int cpx = (nlist + 7) >> 3;
-  const int idx = blockIdx.x >> 3;
-  const int logical = (blockIdx.x & 7) * cpx + idx / NS;
-  if (logical >= nlist) return;
-  const int coff = (idx % NS) * TS;
-  const int b = order[logical];
-  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
-  const int r0 = sl_row0[s0];
-  const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
-  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0, nlow = blk_nlow[b];
-  const int tid = threadIdx.x;
-  constexpr int H = TS / 2;  // double2 per staged row
-  {
-    double2* dst = reinterpret_cast<double2*>(sx);
-    for (int q = tid; q < nown * H; q += WG) {
-      const int i = q / H, j = q - i * H;
-      dst[(size_t)(nlow + i) * H + j] = reinterpret_cast<const double2*>(X + (size_t)(r0 + i) * XS + coff)[j];
-    }
-    for (int q = tid; q < next * H; q += WG) {
-      const int i = q / H, j = q - i * H;
-      const int id = ext_rows[e0 + i];
-      const double2* src = reinterpret_cast<const double2*>((id < m ? X + (size_t)id * XS
-                                                                      : Xh + (size_t)(id - m) * XS) + coff);
-      dst[(size_t)(i < nlow ? i : nown + i) * H + j] = src[j];
-    }
-    if (tid < 2 * H) dst[(size_t)(nown + next) * H + tid] = make_double2(0.0, 0.0);
-  }
-  __syncthreads();
-  // (the wavefront's number as a scalar: the slice loop and everything indexed by it stay in SGPRs)
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  double gw = 0.0, gg = 0.0;      // GRAM: D[i][j] of the lane's 4 x 4 block (lane = 16 i + 4 q + j)
-  for (int s = s0 + wave; s < s1; s += WG / 64) {
-    const long long off = sl_off[s];
-    const int len = sl_len[s];
-    const unsigned short* __restrict__ cp = slot16 + off + lane;
-    const double* __restrict__ vp = val + 3 * off + lane;
-    double acc[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-    int touch = 0;
-    if constexpr (GRAM)       // the slice's rows of R on their way into the L2 while the matrix streams
-      touch = reinterpret_cast<const int*>(Rg)[((size_t)sl_row0[s] + min(lane, sl_nrows[s] - 1)) * 8];
-#pragma unroll 4
-    for (int k = 0; k < len; ++k) {
-      const int slot = cp[(size_t)k * 64];
-      const double v0 = vp[(size_t)(3 * k) * 64];
-      const double v1 = vp[(size_t)(3 * k + 1) * 64];
-      const double v2 = vp[(size_t)(3 * k + 2) * 64];
-      const double* __restrict__ xr = sx + (size_t)slot * TS;
-      spmm_fma_row<TS>(acc, v0, xr);
-      spmm_fma_row<TS>(acc, v1, xr + TS);
-      spmm_fma_row<TS>(acc, v2, xr + 2 * TS);
-    }
-    const int nr = sl_nrows[s], row_s = sl_row0[s];
-    if (lane < nr) {
-      double2* q = reinterpret_cast<double2*>(Y + (size_t)(row_s + lane) * XS + coff);
-#pragma unroll
-      for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
-    }
-    if constexpr (GRAM) {
-      asm volatile("" ::"v"(touch));
-      const double* own = sx + (size_t)(nlow + row_s - r0) * 4;
-      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) { return own + (size_t)rr * 4; }, gw, gg);
-    }
-  }
-  if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
-}
-
-template <int TS, int XS>
-__global__ __launch_bounds__(WG) void k_spmm_runs(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
-    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
-    const int* __restrict__ order, int nlist, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y) {
-  spmm_runs_body<TS, XS, false>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
-                                ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
-}
-
-// 4 columns with the Gram block; five wavefronts per SIMD as k_spmm_runs<4, 4> (32 KiB of staging each)
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_spmm_runs_gram(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
-    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
-    const int* __restrict__ order, int nlist, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y,
-    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
-  spmm_runs_body<4, 4, true>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
-                             ext_rows, order, nlist, X, Xh, Y, Rg, gpart, gbase);
-}
-
-template <int TS>
-__global__ __launch_bounds__(WG) void k_pack_rows(int n, const int* __restrict__ idx,
-                                                  const double* __restrict__ X,
-                                                  double* __restrict__ out) {
-  const int i = (blockIdx.x * WG + threadIdx.x) / TS, c = threadIdx.x % TS;
-  if (i < n) out[(size_t)i * TS + c] = X[(size_t)idx[i] * TS + c];
-}
-
 // Window (rows in flight = record length) of a wide block and the register sets per lane it
 // needs: the same rule as block_jacobi.c (bj_wide_window).
 __host__ __device__ inline int bjw_window(int w) {
@@ -2719,127 +2296,6 @@ static inline double take_note_seq(const double* host) {
   return v;
 }
 
-#define TS_DISPATCH(ts, CALL)                      \
-  switch (ts) {                                    \
-    case 2: { constexpr int TS_ = 2; CALL; } break;   \
-    case 4: { constexpr int TS_ = 4; CALL; } break;   \
-    case 8: { constexpr int TS_ = 8; CALL; } break;   \
-    case 16: { constexpr int TS_ = 16; CALL; } break; \
-    default: snprintf(g_kerr, sizeof(g_kerr), "unsupported panel stride %d", ts); return 1; \
-  }
-
-// A Gram block requested from the next SpMM that reads X and writes Y (pa_k_spmm_gram_arm):
-// k_spmm_runs_gram leaves one partial block per workgroup, `count` of them so far.
-static struct {
-  const double* X; const double* Y; const double* R;
-  double* partials; int cap, count, armed;
-} g_sg;
-
-static long long g_sg_launches = 0;
-
-template <int TS>
-static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, const double* X,
-                       const double* Xh, double* Y) {
-  if (nlist <= 0) return 0;
-  if constexpr (TS == 4) {
-    const size_t lds = (size_t)pl->stage_cap * TS * 8;
-    if (g_sg.armed && pl->runs && lds <= 64 * 1024 && X == g_sg.X && Y == g_sg.Y && g_sg.count >= 0 &&
-        g_sg.count + nlist <= g_sg.cap) {
-      const int cpx = (nlist + 7) / 8;
-      PA_LAUNCH(k_spmm_runs_gram, dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice, pl->blk_ext_off,
-                pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y, g_sg.R, g_sg.partials, g_sg.count);
-      g_sg.count += nlist;
-      ++g_sg_launches;
-      return kfail("k_spmm_runs");
-    }
-    if (g_sg.armed && !pl->runs && !pl->staged && X == g_sg.X && Y == g_sg.Y && g_sg.count >= 0 &&
-        g_sg.count + nlist <= g_sg.cap) {                             // the window kernel (e.g. 7-point Poisson)
-      int win_cap = pl->win_cap;
-      if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
-      const size_t ldsw = (size_t)win_cap * TS * 8;
-      static int ntw = -1;
-      if (ntw < 0) { const char* e = getenv("PREALPS_SPMM_NT"); ntw = e ? atoi(e) : 0; }
-      if (ldsw >= 1024 && !ntw) {
-        const int cpx = (nlist + 7) / 8;
-        PA_LAUNCH(k_spmm_gram, dim3(cpx * 8), dim3(WG), ldsw, cur_stream(), pl->m, pl->sl_off, pl->sl_len,
-                  pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice, pl->blk_win, order, nlist, win_cap,
-                  X, Xh, Y, g_sg.R, g_sg.partials, g_sg.count);
-        g_sg.count += nlist;
-        ++g_sg_launches;
-        return kfail("k_spmm_gram");
-      }
-    }
-    if (g_sg.armed && X == g_sg.X && Y == g_sg.Y) g_sg.count = -1;    // this product leaves no Gram block
-  }
-  if (pl->runs) {
-    // a plan cut for half the panel stride: two workgroups per block, 8 of the 16 columns each;
-    // for the whole stride (pl->runs_cols == TS): one workgroup, the matrix is streamed once
-    if constexpr (TS >= 16) {
-      if (pl->runs_cols == TS) {
-        const size_t lds = (size_t)pl->stage_cap * TS * 8;
-        static size_t configured = 0;
-        if (lds > 64 * 1024 && lds > configured) {
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TS, TS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return kfail("hipFuncSetAttribute(k_spmm_runs)");
-          configured = lds;
-        }
-        const int cpx = (nlist + 7) / 8;
-        PA_LAUNCH((k_spmm_runs<TS, TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                  pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
-                  pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
-        return kfail("k_spmm_runs");
-      }
-    }
-    constexpr int TC = TS >= 16 ? TS / 2 : TS;
-    const int ns = TS / TC;
-    const size_t lds = (size_t)pl->stage_cap * TC * 8;
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TC, TS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return kfail("hipFuncSetAttribute(k_spmm_runs)");
-      configured = lds;
-    }
-    const int cpx = (nlist + 7) / 8;
-    PA_LAUNCH((k_spmm_runs<TC, TS>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
-                       pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
-    return kfail("k_spmm_runs");
-  }
-  if (pl->staged) {
-    const size_t lds = (size_t)pl->stage_cap * TS * 8;
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_staged<TS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return kfail("hipFuncSetAttribute(k_spmm_staged)");
-      configured = lds;
-    }
-    const int cpx = (nlist + 7) / 8;
-    PA_LAUNCH((k_spmm_staged<TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
-                       pl->blk_ext_off, pl->ext_rows, order, nlist, X, Xh, Y);
-    return kfail("k_spmm_staged");
-  }
-  // the X window shares the 160 KiB LDS of a CU with other workgroups: at most 32 KiB of rows
-  int win_cap = pl->win_cap;
-  if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
-  const size_t lds = (size_t)win_cap * TS * 8;
-  const int cpx = (nlist + 7) / 8;
-  static int nt = -1;
-  if (nt < 0) { const char* e = getenv("PREALPS_SPMM_NT"); nt = e ? atoi(e) : 0; }
-  if (nt)
-    PA_LAUNCH((k_spmm<TS, true>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
-                       pl->blk_win, order, nlist, win_cap, X, Xh, Y);
-  else
-    PA_LAUNCH((k_spmm<TS, false>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
-                       pl->blk_win, order, nlist, win_cap, X, Xh, Y);
-  return kfail("k_spmm");
-}
 
 template <int TS, int CH, int XS>
 static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, int count,
@@ -3089,24 +2545,6 @@ int pa_gram_max_blocks(void) { return GRAM_MAX_BLOCKS; }
 
 void pa_k_note_seq(double seq) { g_note_seq = seq; }
 
-void pa_k_spmm_gram_arm(const double* X, const double* Y, const double* R, double* partials, int cap) {
-  g_sg.X = X; g_sg.Y = Y; g_sg.R = R; g_sg.partials = partials; g_sg.cap = cap; g_sg.count = 0;
-  g_sg.armed = (X && Y && R && partials && cap > 0);
-}
-
-long long pa_k_spmm_gram_launches(void) { return g_sg_launches; }
-
-void pa_k_spmm_gram_disarm(void) { g_sg.armed = 0; g_sg.count = 0; }
-
-/* The number of partial blocks the armed products X -> Y have left since the request (0: none,
- * or the operator was applied with another kernel); the request stays armed for the same pointers. */
-int pa_k_spmm_gram_take(const double* X, const double* Y) {
-  if (!g_sg.armed || X != g_sg.X || Y != g_sg.Y) return 0;
-  const int n = g_sg.count > 0 ? g_sg.count : 0;
-  g_sg.armed = 0; g_sg.count = 0;
-  return n;
-}
-
 int pa_finish32_scratch_blocks(void) { return FIN32_WG; }
 
 int pa_k_finish32(const double* partials, int nblk, double* scratch, int t, int T, double* out, double* mu,
@@ -3121,26 +2559,6 @@ int pa_k_finish32_trace(const double* partials, int nblk, double* scratch, doubl
   PA_LAUNCH(k_finish32, dim3(FIN32_WG), dim3(WG), 0, cur_stream(), partials, nblk, scratch, 0, 0, out,
             (double*)nullptr, (double*)nullptr, info, rtr_partials, rtr_nblk, ts, nc, res2);
   return kfail("k_finish32");
-}
-
-int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo, double* Y,
-              int phase) {
-  const int* order = pl->order;
-  int n = pl->nblk;
-  if (phase != 1 && g_sg.armed && X == g_sg.X && Y == g_sg.Y) g_sg.count = 0;   /* a new product starts */
-  if (phase == 0) n = pl->n_interior;
-  else if (phase == 1) { order += pl->n_interior; n = pl->nblk - pl->n_interior; }
-  const double* Xh = Xhalo ? Xhalo : X;
-  TS_DISPATCH(ts, return launch_spmm<TS_>(pl, order, n, X, Xh, Y));
-  return 0;
-}
-
-int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendbuf) {
-  if (n <= 0) return 0;
-  const int blocks = (int)(((long long)n * ts + WG - 1) / WG);
-  TS_DISPATCH(ts, PA_LAUNCH((k_pack_rows<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), n,
-                                     idx, X, sendbuf));
-  return kfail("k_pack_rows");
 }
 
 int pa_k_probe(int which, size_t bytes, const double* src, double* dst) {

@@ -410,7 +410,7 @@ static int build_plan_staged(pa_operator_t* o, int ts) {
     o->d_val = (double*)pa_rt_malloc((tot + 64) * sizeof(double));
     o->d_blk_slice = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
     o->d_blk_ext_off = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
-    o->d_ext_rows = (int*)pa_rt_malloc((next_tot ? next_tot : 1) * sizeof(int));
+    o->d_ext_rows = (int*)pa_rt_malloc((next_tot + 1) * sizeof(int));   /* one spare entry: k_spmm_runs reads ids unconditionally */
     o->d_order = (int*)pa_rt_malloc((nblk > 0 ? nblk : 1) * sizeof(int));
     int bad = (!o->d_sl_off || !o->d_sl_len || !o->d_sl_row0 || !o->d_sl_nrows || !o->d_col16 || !o->d_val ||
                !o->d_blk_slice || !o->d_blk_ext_off || !o->d_ext_rows || !o->d_order);
@@ -1507,7 +1507,7 @@ static int build_plan_runs(pa_operator_t* o, int ts) {
     o->d_blk_slice = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
     o->d_blk_ext_off = (int*)pa_rt_malloc(((size_t)nblk + 1) * sizeof(int));
     o->d_blk_nlow = (int*)pa_rt_malloc((size_t)(nblk > 0 ? nblk : 1) * sizeof(int));
-    o->d_ext_rows = (int*)pa_rt_malloc((next_tot ? next_tot : 1) * sizeof(int));
+    o->d_ext_rows = (int*)pa_rt_malloc((next_tot + 1) * sizeof(int));   /* one spare entry: k_spmm_runs reads ids unconditionally */
     o->d_order = (int*)pa_rt_malloc((nblk > 0 ? nblk : 1) * sizeof(int));
     int bad = (!o->d_sl_off || !o->d_sl_len || !o->d_sl_row0 || !o->d_sl_nrows || !o->d_col16 || !o->d_val ||
                !o->d_blk_slice || !o->d_blk_ext_off || !o->d_blk_nlow || !o->d_ext_rows || !o->d_order);

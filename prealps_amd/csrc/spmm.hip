@@ -1,0 +1,781 @@
+// spmm.hip -- the block operator AP = A P (utils/operator.c:334-351 -> cplm_v0_matmult_v2.c:108-343 ->
+// mkl_dcsrmm of the reference): SELL-64 CSR x panel kernels, the row pack of the halo exchange, launchers.
+#include "kernels_common.h"
+
+namespace {
+
+// The Gram epilogue of one slice (see k_spmm_runs_gram): acc = the lane's row of Y, xrow(r) = where row r of the
+// slice's X lies (LDS or memory), R rows from memory; gw / gg = the wavefront's two accumulators.
+template <typename XROW>
+__device__ __forceinline__ void spmm_gram_slice(const double (&acc)[4], int nr, int row_s, int lane,
+                                                const double* __restrict__ Rg, XROW xrow, double& gw, double& gg) {
+  const int g4 = lane & ~3, c = lane & 3;
+  double rv[4], xv[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {         // step st: the quad stands for row g4 + st of the slice
+    const int rr = g4 + st;
+    const bool on = rr < nr;
+    rv[st] = on ? Rg[(size_t)(row_s + rr) * 4 + c] : 0.0;
+    xv[st] = on ? xrow(rr)[c] : 0.0;
+  }
+  double ty[4] = {acc[0], acc[1], acc[2], acc[3]};
+  quad_transpose4(ty, c);
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    gw = __builtin_amdgcn_mfma_f64_4x4x4f64(ty[st], xv[st], gw, 0, 0, 0);
+    gg = __builtin_amdgcn_mfma_f64_4x4x4f64(rv[st], xv[st], gg, 0, 0, 0);
+  }
+}
+
+// ... and of the workgroup: the four blocks of a lane's row of 16 lanes (row_ror 4 / 8), then the four
+// wavefronts through the first 128 doubles of the staging area (no wavefront reads it any more after the
+// barrier), one 8 x 4 partial block out.
+__device__ __forceinline__ void spmm_gram_tail(double gw, double gg, double* sx, int wave, int lane, int tid,
+                                               double* __restrict__ gblock) {
+  gw += dpp_mov_f64<0x124>(gw); gw += dpp_mov_f64<0x128>(gw);
+  gg += dpp_mov_f64<0x124>(gg); gg += dpp_mov_f64<0x128>(gg);
+  __syncthreads();
+  if ((lane & 12) == 0) {
+    const int i = lane >> 4, j = lane & 3;
+    sx[wave * 32 + i + 8 * j] = gw;
+    sx[wave * 32 + 4 + i + 8 * j] = gg;
+  }
+  __syncthreads();
+  if (tid < 32) gblock[tid] = ((sx[tid] + sx[32 + tid]) + sx[64 + tid]) + sx[96 + tid];
+}
+
+// ---------------------------------------------------------------- SpMM ----
+// SELL-64 SpMM.  One workgroup per block of slices of one subdomain; the
+// subdomain's own X rows (where ~90 % of the nonzeros of a box partition
+// point) are staged once into LDS with coalesced 16-B loads, every wavefront
+// then walks whole slices: lane r owns row r of the slice, keeps its TS sums
+// in registers and reads val/col of entry k at [off + k*64 + r] -- one fully
+// coalesced 512-B / 256-B load per wave instruction for the 12 B/nonzero
+// stream.  Columns outside the window (neighbour subdomains, halo rows) are
+// gathered as whole 8*TS-byte rows from L2.
+template <int TS>
+__device__ __forceinline__ void spmm_fma_row(double (&acc)[TS], double v, const double* __restrict__ xr) {
+  const double2* q = reinterpret_cast<const double2*>(xr);
+#pragma unroll
+  for (int i = 0; i < TS / 2; ++i) {
+    const double2 x = q[i];
+    acc[2 * i] = fma(v, x.x, acc[2 * i]);
+    acc[2 * i + 1] = fma(v, x.y, acc[2 * i + 1]);
+  }
+}
+
+template <int TS, bool NT, bool GRAM>
+__device__ __forceinline__ void spmm_body(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const int* __restrict__ col, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
+    const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
+  static_assert(!GRAM || TS == 4, "the fused Gram block is built for 4-column panels");
+  extern __shared__ double sx[];
+  // XCD-aware order: consecutive logical blocks (which share X rows) run on one XCD.
+  const int cpx = (nlist + 7) >> 3;
+  const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  if (logical >= nlist) return;
+  const int b = order[logical];
+  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
+  const int w0 = blk_win[2 * b];
+  const int wlen = min(blk_win[2 * b + 1] - w0, win_cap);
+  const int tid = threadIdx.x;
+  {
+    const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)w0 * TS);
+    const int nx2 = (wlen * TS) >> 1;
+    for (int i = tid; i < nx2; i += WG) reinterpret_cast<double2*>(sx)[i] = xsrc[i];
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  double gw = 0.0, gg = 0.0;      // GRAM: as in k_spmm_runs_gram
+  for (int s = s0 + wave; s < s1; s += WG / 64) {
+    const long long off = sl_off[s];
+    const int len = sl_len[s];
+    const int* __restrict__ cp = col + off + lane;
+    const double* __restrict__ vp = val + off + lane;
+    double acc[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < len; ++k) {
+      // the matrix is streamed once: keep it out of the way of the X rows in L2
+      const double v = NT ? __builtin_nontemporal_load(vp + (size_t)k * 64) : vp[(size_t)k * 64];
+      const int cidx = NT ? __builtin_nontemporal_load(cp + (size_t)k * 64) : cp[(size_t)k * 64];
+      const unsigned wi = (unsigned)(cidx - w0);
+      if (wi < (unsigned)wlen) spmm_fma_row<TS>(acc, v, sx + (size_t)wi * TS);
+      else if (cidx < m) spmm_fma_row<TS>(acc, v, X + (size_t)cidx * TS);
+      else spmm_fma_row<TS>(acc, v, Xh + (size_t)(cidx - m) * TS);
+    }
+    const int nr = sl_nrows[s], row_s = sl_row0[s];
+    if (lane < nr) store_row<TS>(Y, (size_t)(row_s + lane), acc);
+    if constexpr (GRAM) {
+      // a row of the slice's own X: in the window, or (a window cut short by win_cap) in memory
+      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) {
+        const unsigned wi = (unsigned)(row_s + rr - w0);
+        return wi < (unsigned)wlen ? (const double*)(sx + (size_t)wi * 4) : X + (size_t)(row_s + rr) * 4;
+      }, gw, gg);
+    }
+  }
+  if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
+}
+
+template <int TS, bool NT>
+__global__ __launch_bounds__(WG) void k_spmm(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const int* __restrict__ col, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
+    const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y) {
+  spmm_body<TS, NT, false>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
+                           X, Xh, Y, nullptr, nullptr, 0);
+}
+
+// 4 columns with the Gram block [Y | R]^T X (see k_spmm_runs_gram)
+__global__ __launch_bounds__(WG) void k_spmm_gram(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const int* __restrict__ col, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
+    const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
+  spmm_body<4, false, true>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
+                            X, Xh, Y, Rg, gpart, gbase);
+}
+
+// Staged SELL-64 SpMM: the block first copies every X row it will touch into
+// LDS (own rows as one coalesced range, then the listed neighbour / halo rows,
+// 16 B per lane), so the inner loop is branch-free: one coalesced 8-B value,
+// one coalesced 2-B LDS slot, TS/2 ds_read_b128 and TS FMAs per nonzero, and
+// the matrix stream shrinks from 12 to 10 bytes per nonzero.
+template <int TS>
+__global__ __launch_bounds__(WG) void k_spmm_staged(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ col16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ ext_rows, const int* __restrict__ order, int nlist,
+    const double* __restrict__ X, const double* __restrict__ Xh, double* __restrict__ Y) {
+  extern __shared__ double sx[];
+  const int cpx = (nlist + 7) >> 3;
+  const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  if (logical >= nlist) return;
+  const int b = order[logical];
+  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
+  const int r0 = sl_row0[s0];
+  const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
+  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0;
+  const int tid = threadIdx.x;
+  constexpr int H = TS / 2;  // double2 per row
+  {
+    const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)r0 * TS);
+    double2* dst = reinterpret_cast<double2*>(sx);
+    for (int i = tid; i < nown * H; i += WG) dst[i] = xsrc[i];
+    for (int q = tid; q < next * H; q += WG) {
+      const int i = q / H, j = q - i * H;
+      const int id = ext_rows[e0 + i];
+      const double2* src = reinterpret_cast<const double2*>(id < m ? X + (size_t)id * TS
+                                                                     : Xh + (size_t)(id - m) * TS);
+      dst[(size_t)(nown + i) * H + j] = src[j];
+    }
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  for (int s = s0 + wave; s < s1; s += WG / 64) {
+    const long long off = sl_off[s];
+    const int len = sl_len[s];
+    const unsigned short* __restrict__ cp = col16 + off + lane;
+    const double* __restrict__ vp = val + off + lane;
+    double acc[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < len; ++k) {
+      const double v = vp[(size_t)k * 64];
+      const int slot = cp[(size_t)k * 64];
+      spmm_fma_row<TS>(acc, v, sx + (size_t)slot * TS);
+    }
+    if (lane < sl_nrows[s]) store_row<TS>(Y, (size_t)(sl_row0[s] + lane), acc);
+  }
+}
+
+// Staged SpMM over runs of three consecutive LDS slots (rows whose nonzeros sit in groups
+// of neighbouring columns, e.g. the 3 dofs of a node): per run one coalesced 2-B slot, three
+// coalesced 8-B values and 3*TS/2 ds_read_b128 off one address -- 8.67 B of matrix stream
+// per nonzero instead of 10 and a third of the index arithmetic.  The staging area is
+// [external rows below | own rows | external rows above | two zero rows].
+// XS = panel stride in doubles.  XS = 2 TS splits a wide panel by columns: two workgroups per
+// block (neighbours in the dispatch order of one XCD, so the second one finds the matrix slice
+// in that XCD's L2), each staging and computing TS of the XS columns.
+//
+// GRAM (4-column panels): the workgroup also leaves the block's share of [Y | R]^T X -- the
+// Gram block the ECG iteration forms right after A P (ecg.c:425-436: W = AP^T P, G^T = R^T P)
+// -- in gpart[gbase + logical] (8 x 4, column major, the layout of k_gram<4, 2>), so that the
+// panels are not read a second time.  Y rows sit one per lane in registers and X rows in the
+// staging area: a 4 x 4 transpose inside each quad of lanes puts 16 rows x 4 columns into the
+// operand layout of v_mfma_f64_4x4x4 (lane 4g + c = column c of row g), four of which cover the
+// 64 rows of a slice; R is read in that layout directly.
+// One group of RU runs of a slice: RU slots and 3 RU values per lane, all coalesced.  `g` is clamped by the
+// caller, so that the loads are unconditional (a conditional load makes the compiler's wait-count
+// bookkeeping join two histories at the next use, and the join waits for everything in flight); a run
+// beyond the slice's last one takes that one's slot and its values from a block of zeros -- the choice is
+// between two scalar addresses, the vector code is the same for every group.
+__device__ const double g_zero_run[192] = {0.0};
+template <int RU>
+__device__ __forceinline__ void spmm_runs_load(const unsigned short* __restrict__ cp, const double* __restrict__ vp,
+                                               unsigned lane, int g, int len, int (&sl)[RU], double (&vv)[3 * RU]) {
+  // cp / vp: the slice's slots and values, wavefront-uniform; the run index is uniform too, so every address
+  // is a scalar base plus the lane
+#pragma unroll
+  for (int j = 0; j < RU; ++j) {
+    const int k = g * RU + j, kc = min(k, len - 1);
+    const unsigned short* __restrict__ ck = cp + (size_t)kc * 64;
+    typedef const __attribute__((address_space(1))) double* gdp;     // (a select of two pointers would go flat)
+    const gdp vk = k < len ? (gdp)(vp + (size_t)(3 * k) * 64) : (gdp)g_zero_run;
+    sl[j] = ck[lane];
+    vv[3 * j] = vk[lane];
+    vv[3 * j + 1] = vk[64 + lane];
+    vv[3 * j + 2] = vk[128 + lane];
+  }
+}
+template <int TS, int RU>
+__device__ __forceinline__ void spmm_runs_fma(const double* sx, const int (&sl)[RU], const double (&vv)[3 * RU],
+                                              double (&acc)[TS]) {
+#pragma unroll
+  for (int j = 0; j < RU; ++j) {
+    const double* __restrict__ xr = sx + (size_t)sl[j] * TS;
+    spmm_fma_row<TS>(acc, vv[3 * j], xr);
+    spmm_fma_row<TS>(acc, vv[3 * j + 1], xr + TS);
+    spmm_fma_row<TS>(acc, vv[3 * j + 2], xr + 2 * TS);
+  }
+}
+
+template <int TS, int XS, bool GRAM, int RU, int DBG>
+__device__ __forceinline__ void spmm_runs_block(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase, int logical, int coff);
+
+template <int TS, int XS, bool GRAM, int RU = 3, int DBG = 0>
+__device__ __forceinline__ void spmm_runs_body(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, int nlist, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
+  constexpr int NS = XS / TS;
+  const int cpx = (nlist + 7) >> 3;
+  const int idx = blockIdx.x >> 3;
+  const int logical = (blockIdx.x & 7) * cpx + idx / NS;
+  if (logical >= nlist) return;
+  spmm_runs_block<TS, XS, GRAM, RU, DBG>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+                                         ext_rows, order, X, Xh, Y, Rg, gpart, gbase, logical, (idx % NS) * TS);
+}
+
+// One block of slices: `logical` = its place in the launch's list, `coff` = first of the TS columns.
+template <int TS, int XS, bool GRAM, int RU, int DBG>
+__device__ __forceinline__ void spmm_runs_block(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase, int logical, int coff) {
+  static_assert(!GRAM || (TS == 4 && XS == 4), "the fused Gram block is built for 4-column panels");
+  extern __shared__ double sx[];
+  const int b = order[logical];
+  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
+  const int r0 = sl_row0[s0];
+  const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
+  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0, nlow = blk_nlow[b];
+  const int tid = threadIdx.x;
+  // (the wavefront's number as a scalar: the slice loop and everything indexed by it stay in SGPRs)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  constexpr int H = TS / 2;  // double2 per staged row
+
+  // The matrix stream of the wavefront's first slice is requested BEFORE the staging of X: its first group
+  // is on its way while the rows are gathered (two dependent memory latencies) and the workgroup meets at
+  // the barrier.
+  int slA[RU], slB[RU];
+  double vA[3 * RU], vB[3 * RU];
+  int s = s0 + wave;
+  int len = 0;
+  const unsigned short* __restrict__ cp = slot16;
+  const double* __restrict__ vp = val;
+  if (s < s1) {
+    const long long off = sl_off[s];
+    len = sl_len[s];
+    cp = slot16 + off;
+    vp = val + 3 * off;
+    if (len > 0) spmm_runs_load<RU>(cp, vp, lane, 0, len, slA, vA);
+  }
+
+  // Staging: LDS row L of [external rows below | own rows | external rows above] comes from global row
+  // id(L); H lanes per row, WG / H rows per pass, SB passes in flight at a time: all ids, then all rows,
+  // then the LDS stores -- two memory latencies per batch instead of two per pass.
+  if constexpr (!(DBG & 1)) {
+    constexpr int RPP = WG / H, SB = 8;
+    double2* dst = reinterpret_cast<double2*>(sx);
+    const int j = tid % H, l0 = tid / H, nst = nown + next;
+    // (no conditional anywhere: lanes beyond the last row repeat it -- same bytes to the same place --
+    // and every lane reads an id from ext_rows, which has one spare entry at its end)
+    const int emax = max(next - 1, 0);
+    for (int base = 0; base < nst; base += SB * RPP) {
+      int L[SB], id[SB];
+#pragma unroll
+      for (int it = 0; it < SB; ++it) {
+        L[it] = min(base + it * RPP + l0, nst - 1);
+        id[it] = ext_rows[e0 + min(max(L[it] < nlow ? L[it] : L[it] - nown, 0), emax)];
+      }
+      double2 v[SB];
+#pragma unroll
+      for (int it = 0; it < SB; ++it) {
+        const bool own = L[it] >= nlow && L[it] < nlow + nown;
+        const int r = own ? r0 + (L[it] - nlow) : id[it];
+        const double* src = (r < m ? X + (size_t)r * XS : Xh + (size_t)(r - m) * XS) + coff;
+        v[it] = reinterpret_cast<const double2*>(src)[j];
+      }
+#pragma unroll
+      for (int it = 0; it < SB; ++it) dst[(size_t)L[it] * H + j] = v[it];
+    }
+    if (tid < 2 * H) dst[(size_t)nst * H + tid] = make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  double gw = 0.0, gg = 0.0;      // GRAM: D[i][j] of the lane's 4 x 4 block (lane = 16 i + 4 q + j)
+  for (; s < s1; s += WG / 64) {
+    double acc[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+    int touch = 0;
+    if constexpr (GRAM)       // the slice's rows of R on their way into the L2 while the matrix streams
+      touch = reinterpret_cast<const int*>(Rg)[((size_t)sl_row0[s] + min(lane, sl_nrows[s] - 1)) * 8];
+    if (len > 0) {
+      // two register sets: while one group is summed up the next one is in flight
+      const int ngt = (len + RU - 1) / RU;
+      // (one exit at the bottom and the odd group behind the loop: with an exit in the middle the register
+      // allocator copies the set that is in flight at the end of every round, behind a full wait)
+      for (int i = 0; i < (ngt >> 1); ++i) {
+        spmm_runs_load<RU>(cp, vp, lane, 2 * i + 1, len, slB, vB);
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the requests in front of the sums of the group before)
+        spmm_runs_fma<TS, RU>(sx, slA, vA, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        spmm_runs_load<RU>(cp, vp, lane, min(2 * i + 2, ngt - 1), len, slA, vA);
+        __builtin_amdgcn_sched_barrier(0);
+        spmm_runs_fma<TS, RU>(sx, slB, vB, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ngt & 1) spmm_runs_fma<TS, RU>(sx, slA, vA, acc);
+    }
+    const int nr = sl_nrows[s], row_s = sl_row0[s];
+    if constexpr (DBG & 4) {          // DEV: the bytes of the store as whole lines (wrong values)
+      double2* q = reinterpret_cast<double2*>(Y + (size_t)row_s * XS);
+      if (lane < 2 * nr) q[lane] = make_double2(acc[0], acc[1]);
+      if (lane + 64 < 2 * nr) q[64 + lane] = make_double2(acc[2], acc[3]);
+    } else if constexpr (DBG & 16) {  // DEV: every store into one 2 MB region (stays in the L2)
+      if (lane < nr) {
+        double2* q = reinterpret_cast<double2*>(Y + (size_t)((row_s + lane) & 0xFFFF) * XS + coff);
+#pragma unroll
+        for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
+      }
+    } else if constexpr (DBG & 8) {   // DEV: nontemporal
+      if (lane < nr) {
+        double* q = Y + (size_t)(row_s + lane) * XS + coff;
+#pragma unroll
+        for (int i = 0; i < TS; ++i) __builtin_nontemporal_store(acc[i], q + i);
+      }
+    } else
+    if (lane < ((DBG & 2) ? (acc[0] == 1.2345 ? nr : 0) : nr)) {
+      double2* q = reinterpret_cast<double2*>(Y + (size_t)(row_s + lane) * XS + coff);
+#pragma unroll
+      for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
+    }
+    if constexpr (GRAM) {
+      asm volatile("" ::"v"(touch));
+      const double* own = sx + (size_t)(nlow + row_s - r0) * 4;
+      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) { return own + (size_t)rr * 4; }, gw, gg);
+    }
+    if (s + WG / 64 < s1) {       // (a block of more than four slices: the wavefront's next one)
+      const int sn = s + WG / 64;
+      const long long off = sl_off[sn];
+      len = sl_len[sn];
+      cp = slot16 + off;
+      vp = val + 3 * off;
+      if (len > 0) spmm_runs_load<RU>(cp, vp, lane, 0, len, slA, vA);
+    }
+  }
+  if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
+}
+
+// (registers: five wavefronts per SIMD is what 32 KiB of staging per workgroup allow at 4 columns -- 96
+// VGPRs; the wider panels stage 48 KiB, three workgroups per CU)
+template <int TS, int XS>
+__global__ __launch_bounds__(WG, (TS <= 4 ? 5 : 3)) void k_spmm_runs(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, int nlist, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y) {
+  spmm_runs_body<TS, XS, false>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+                                ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
+}
+
+// TEMPORARY dev variants (PREALPS_SPMM_OLD = 2 + index)
+template <int RU, int DBG>
+__global__ __launch_bounds__(WG, 5) void k_spmm_runs_dev(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, int nlist, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y) {
+  spmm_runs_body<4, 4, false, RU, DBG>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+                                ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
+}
+// DEV: resident workgroups, each walks the blocks i, i + G, ... of its XCD's share
+template <int RU, int DBG>
+__global__ __launch_bounds__(WG, 5) void k_spmm_runs_pers(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, int nlist, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y) {
+  const int cpx = (nlist + 7) >> 3, G = gridDim.x >> 3, xcd = blockIdx.x & 7;
+  for (int i = blockIdx.x >> 3; i < cpx; i += G) {
+    const int logical = xcd * cpx + i;
+    if (logical >= nlist) break;
+    if (i != (int)(blockIdx.x >> 3)) __syncthreads();      // every wavefront is done with the staged rows of the block before
+    spmm_runs_block<4, 4, false, RU, DBG>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+                                          ext_rows, order, X, Xh, Y, nullptr, nullptr, 0, logical, 0);
+  }
+}
+// TEMPORARY (A/B of the round-4 rewrite, PREALPS_SPMM_OLD=1): round 3's kernel
+template <int TS, int XS, bool GRAM>
+__device__ __forceinline__ void spmm_runs_body_old(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, int nlist, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
+  static_assert(!GRAM || (TS == 4 && XS == 4), "the fused Gram block is built for 4-column panels");
+  extern __shared__ double sx[];
+  constexpr int NS = XS / TS;
+  const int cpx = (nlist + 7) >> 3;
+  const int idx = blockIdx.x >> 3;
+  const int logical = (blockIdx.x & 7) * cpx + idx / NS;
+  if (logical >= nlist) return;
+  const int coff = (idx % NS) * TS;
+  const int b = order[logical];
+  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
+  const int r0 = sl_row0[s0];
+  const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
+  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0, nlow = blk_nlow[b];
+  const int tid = threadIdx.x;
+  constexpr int H = TS / 2;  // double2 per staged row
+  {
+    double2* dst = reinterpret_cast<double2*>(sx);
+    for (int q = tid; q < nown * H; q += WG) {
+      const int i = q / H, j = q - i * H;
+      dst[(size_t)(nlow + i) * H + j] = reinterpret_cast<const double2*>(X + (size_t)(r0 + i) * XS + coff)[j];
+    }
+    for (int q = tid; q < next * H; q += WG) {
+      const int i = q / H, j = q - i * H;
+      const int id = ext_rows[e0 + i];
+      const double2* src = reinterpret_cast<const double2*>((id < m ? X + (size_t)id * XS
+                                                                      : Xh + (size_t)(id - m) * XS) + coff);
+      dst[(size_t)(i < nlow ? i : nown + i) * H + j] = src[j];
+    }
+    if (tid < 2 * H) dst[(size_t)(nown + next) * H + tid] = make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  // (the wavefront's number as a scalar: the slice loop and everything indexed by it stay in SGPRs)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  double gw = 0.0, gg = 0.0;      // GRAM: D[i][j] of the lane's 4 x 4 block (lane = 16 i + 4 q + j)
+  for (int s = s0 + wave; s < s1; s += WG / 64) {
+    const long long off = sl_off[s];
+    const int len = sl_len[s];
+    const unsigned short* __restrict__ cp = slot16 + off + lane;
+    const double* __restrict__ vp = val + 3 * off + lane;
+    double acc[TS];
+#pragma unroll
+    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
+    int touch = 0;
+    if constexpr (GRAM)       // the slice's rows of R on their way into the L2 while the matrix streams
+      touch = reinterpret_cast<const int*>(Rg)[((size_t)sl_row0[s] + min(lane, sl_nrows[s] - 1)) * 8];
+#pragma unroll 4
+    for (int k = 0; k < len; ++k) {
+      const int slot = cp[(size_t)k * 64];
+      const double v0 = vp[(size_t)(3 * k) * 64];
+      const double v1 = vp[(size_t)(3 * k + 1) * 64];
+      const double v2 = vp[(size_t)(3 * k + 2) * 64];
+      const double* __restrict__ xr = sx + (size_t)slot * TS;
+      spmm_fma_row<TS>(acc, v0, xr);
+      spmm_fma_row<TS>(acc, v1, xr + TS);
+      spmm_fma_row<TS>(acc, v2, xr + 2 * TS);
+    }
+    const int nr = sl_nrows[s], row_s = sl_row0[s];
+    if (lane < nr) {
+      double2* q = reinterpret_cast<double2*>(Y + (size_t)(row_s + lane) * XS + coff);
+#pragma unroll
+      for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
+    }
+    if constexpr (GRAM) {
+      asm volatile("" ::"v"(touch));
+      const double* own = sx + (size_t)(nlow + row_s - r0) * 4;
+      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) { return own + (size_t)rr * 4; }, gw, gg);
+    }
+  }
+  if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
+}
+
+template <int TS, int XS>
+__global__ __launch_bounds__(WG) void k_spmm_runs_old(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, int nlist, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y) {
+  spmm_runs_body_old<TS, XS, false>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+                                ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
+}
+
+
+// 4 columns with the Gram block; five wavefronts per SIMD as k_spmm_runs<4, 4> (32 KiB of staging each)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_spmm_runs_gram(
+    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
+    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
+    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
+    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
+    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
+    const int* __restrict__ order, int nlist, const double* __restrict__ X,
+    const double* __restrict__ Xh, double* __restrict__ Y,
+    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
+  spmm_runs_body<4, 4, true>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+                             ext_rows, order, nlist, X, Xh, Y, Rg, gpart, gbase);
+}
+
+template <int TS>
+__global__ __launch_bounds__(WG) void k_pack_rows(int n, const int* __restrict__ idx,
+                                                  const double* __restrict__ X,
+                                                  double* __restrict__ out) {
+  const int i = (blockIdx.x * WG + threadIdx.x) / TS, c = threadIdx.x % TS;
+  if (i < n) out[(size_t)i * TS + c] = X[(size_t)idx[i] * TS + c];
+}
+
+}  // namespace
+
+// A Gram block requested from the next SpMM that reads X and writes Y (pa_k_spmm_gram_arm):
+// k_spmm_runs_gram leaves one partial block per workgroup, `count` of them so far.
+static struct {
+  const double* X; const double* Y; const double* R;
+  double* partials; int cap, count, armed;
+} g_sg;
+
+static long long g_sg_launches = 0;
+
+template <int TS>
+static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, const double* X,
+                       const double* Xh, double* Y) {
+  if (nlist <= 0) return 0;
+  if constexpr (TS == 4) {
+    const size_t lds = (size_t)pl->stage_cap * TS * 8;
+    if (g_sg.armed && pl->runs && lds <= 64 * 1024 && X == g_sg.X && Y == g_sg.Y && g_sg.count >= 0 &&
+        g_sg.count + nlist <= g_sg.cap) {
+      const int cpx = (nlist + 7) / 8;
+      PA_LAUNCH(k_spmm_runs_gram, dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice, pl->blk_ext_off,
+                pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y, g_sg.R, g_sg.partials, g_sg.count);
+      g_sg.count += nlist;
+      ++g_sg_launches;
+      return kfail("k_spmm_runs");
+    }
+    if (g_sg.armed && !pl->runs && !pl->staged && X == g_sg.X && Y == g_sg.Y && g_sg.count >= 0 &&
+        g_sg.count + nlist <= g_sg.cap) {                             // the window kernel (e.g. 7-point Poisson)
+      int win_cap = pl->win_cap;
+      if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
+      const size_t ldsw = (size_t)win_cap * TS * 8;
+      static int ntw = -1;
+      if (ntw < 0) { const char* e = getenv("PREALPS_SPMM_NT"); ntw = e ? atoi(e) : 0; }
+      if (ldsw >= 1024 && !ntw) {
+        const int cpx = (nlist + 7) / 8;
+        PA_LAUNCH(k_spmm_gram, dim3(cpx * 8), dim3(WG), ldsw, cur_stream(), pl->m, pl->sl_off, pl->sl_len,
+                  pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice, pl->blk_win, order, nlist, win_cap,
+                  X, Xh, Y, g_sg.R, g_sg.partials, g_sg.count);
+        g_sg.count += nlist;
+        ++g_sg_launches;
+        return kfail("k_spmm_gram");
+      }
+    }
+    if (g_sg.armed && X == g_sg.X && Y == g_sg.Y) g_sg.count = -1;    // this product leaves no Gram block
+  }
+  if (pl->runs) {
+    // a plan cut for half the panel stride: two workgroups per block, 8 of the 16 columns each;
+    // for the whole stride (pl->runs_cols == TS): one workgroup, the matrix is streamed once
+    if constexpr (TS >= 16) {
+      if (pl->runs_cols == TS) {
+        const size_t lds = (size_t)pl->stage_cap * TS * 8;
+        static size_t configured = 0;
+        if (lds > 64 * 1024 && lds > configured) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TS, TS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return kfail("hipFuncSetAttribute(k_spmm_runs)");
+          configured = lds;
+        }
+        const int cpx = (nlist + 7) / 8;
+        PA_LAUNCH((k_spmm_runs<TS, TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                  pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
+                  pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
+        return kfail("k_spmm_runs");
+      }
+    }
+    constexpr int TC = TS >= 16 ? TS / 2 : TS;
+    const int ns = TS / TC;
+    const size_t lds = (size_t)pl->stage_cap * TC * 8;
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TC, TS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return kfail("hipFuncSetAttribute(k_spmm_runs)");
+      configured = lds;
+    }
+    const int cpx = (nlist + 7) / 8;
+    static int old_k = -1;
+    if (old_k < 0) { const char* e = getenv("PREALPS_SPMM_OLD"); old_k = e ? atoi(e) : 0; }
+    { const char* e = getenv("PREALPS_SPMM_OLD"); if (e) old_k = atoi(e); }
+    if constexpr (TS == 4) {
+      if (old_k >= 2) {
+#define DEVK(R, D) PA_LAUNCH((k_spmm_runs_dev<R, D>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off, \
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice, \
+                       pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y)
+        switch (old_k) {
+          case 2: DEVK(3, 1); break;      // no staging
+          case 3: DEVK(3, 2); break;      // no store
+          case 4: DEVK(3, 3); break;      // neither
+          case 5: DEVK(2, 0); break;
+          case 6: DEVK(4, 0); break;
+          case 8: DEVK(3, 4); break;
+          case 9: DEVK(3, 8); break;
+          case 10: DEVK(3, 16); break;
+          case 11: case 12: case 13: case 14: {
+            const int per_cu = old_k == 11 ? 5 : old_k == 12 ? 4 : old_k == 13 ? 3 : 10;
+            int g = (pa_rt_num_cus() > 0 ? pa_rt_num_cus() : 256) * per_cu;
+            if (g > cpx * 8) g = cpx * 8;
+            g &= ~7;
+            PA_LAUNCH((k_spmm_runs_pers<3, 0>), dim3(g), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
+                       pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
+          } break;
+          default: DEVK(1, 0); break;
+        }
+        return kfail("k_spmm_runs_dev");
+      }
+    }
+    if (old_k == 1) {
+      PA_LAUNCH((k_spmm_runs_old<TC, TS>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
+                       pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
+      return kfail("k_spmm_runs_old");
+    }
+    PA_LAUNCH((k_spmm_runs<TC, TS>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
+                       pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
+    return kfail("k_spmm_runs");
+  }
+  if (pl->staged) {
+    const size_t lds = (size_t)pl->stage_cap * TS * 8;
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_staged<TS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return kfail("hipFuncSetAttribute(k_spmm_staged)");
+      configured = lds;
+    }
+    const int cpx = (nlist + 7) / 8;
+    PA_LAUNCH((k_spmm_staged<TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
+                       pl->blk_ext_off, pl->ext_rows, order, nlist, X, Xh, Y);
+    return kfail("k_spmm_staged");
+  }
+  // the X window shares the 160 KiB LDS of a CU with other workgroups: at most 32 KiB of rows
+  int win_cap = pl->win_cap;
+  if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
+  const size_t lds = (size_t)win_cap * TS * 8;
+  const int cpx = (nlist + 7) / 8;
+  static int nt = -1;
+  if (nt < 0) { const char* e = getenv("PREALPS_SPMM_NT"); nt = e ? atoi(e) : 0; }
+  if (nt)
+    PA_LAUNCH((k_spmm<TS, true>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
+                       pl->blk_win, order, nlist, win_cap, X, Xh, Y);
+  else
+    PA_LAUNCH((k_spmm<TS, false>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
+                       pl->blk_win, order, nlist, win_cap, X, Xh, Y);
+  return kfail("k_spmm");
+}
+
+extern "C" {
+
+void pa_k_spmm_gram_arm(const double* X, const double* Y, const double* R, double* partials, int cap) {
+  g_sg.X = X; g_sg.Y = Y; g_sg.R = R; g_sg.partials = partials; g_sg.cap = cap; g_sg.count = 0;
+  g_sg.armed = (X && Y && R && partials && cap > 0);
+}
+
+long long pa_k_spmm_gram_launches(void) { return g_sg_launches; }
+
+void pa_k_spmm_gram_disarm(void) { g_sg.armed = 0; g_sg.count = 0; }
+
+/* The number of partial blocks the armed products X -> Y have left since the request (0: none,
+ * or the operator was applied with another kernel); the request stays armed for the same pointers. */
+int pa_k_spmm_gram_take(const double* X, const double* Y) {
+  if (!g_sg.armed || X != g_sg.X || Y != g_sg.Y) return 0;
+  const int n = g_sg.count > 0 ? g_sg.count : 0;
+  g_sg.armed = 0; g_sg.count = 0;
+  return n;
+}
+
+int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* Xhalo, double* Y,
+              int phase) {
+  const int* order = pl->order;
+  int n = pl->nblk;
+  if (phase != 1 && g_sg.armed && X == g_sg.X && Y == g_sg.Y) g_sg.count = 0;   /* a new product starts */
+  if (phase == 0) n = pl->n_interior;
+  else if (phase == 1) { order += pl->n_interior; n = pl->nblk - pl->n_interior; }
+  const double* Xh = Xhalo ? Xhalo : X;
+  TS_DISPATCH(ts, return launch_spmm<TS_>(pl, order, n, X, Xh, Y));
+  return 0;
+}
+
+int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendbuf) {
+  if (n <= 0) return 0;
+  const int blocks = (int)(((long long)n * ts + WG - 1) / WG);
+  TS_DISPATCH(ts, PA_LAUNCH((k_pack_rows<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), n,
+                                     idx, X, sendbuf));
+  return kfail("k_pack_rows");
+}
+
+}  // extern "C"
