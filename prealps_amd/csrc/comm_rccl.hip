@@ -32,9 +32,15 @@ char g_err[256] = "";
 
 int load_api() {
   if (api.h) return 0;
-  api.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!api.h) api.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!api.h) { snprintf(g_err, sizeof(g_err), "cannot load librccl.so: %s", dlerror()); return 1; }
+  /* PREALPS_RCCL_LIB: another library with the nine nccl* entry points used here (tests/c/rccl_standin.c
+   * drives this binding with several ranks on ONE device, where the real RCCL refuses to start) */
+  const char* name = getenv("PREALPS_RCCL_LIB");
+  if (name && *name) api.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+  else {
+    api.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!api.h) api.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  }
+  if (!api.h) { snprintf(g_err, sizeof(g_err), "cannot load %s: %s", name && *name ? name : "librccl.so", dlerror()); return 1; }
 #define SYM(field, name)                                                     \
   *(void**)(&api.field) = dlsym(api.h, name);                                \
   if (!api.field) { snprintf(g_err, sizeof(g_err), "librccl.so lacks %s", name); return 1; }
@@ -96,12 +102,16 @@ int pa_rccl_exchange(void* ctx, const double* send, const int* send_counts, doub
   if (!g_comm) { snprintf(g_err, sizeof(g_err), "RCCL communicator not initialised"); return 1; }
   hipStream_t st = (hipStream_t)pa_rt_stream();
   if (nfail(api.GroupStart(), "ncclGroupStart")) return 1;
-  for (int i = 0; i < npeers; ++i) {
-    if (send_counts[i] > 0 && nfail(api.Send(send, (size_t)send_counts[i], ncclDouble, peers[i], g_comm, st), "ncclSend")) return 1;
-    if (recv_counts[i] > 0 && nfail(api.Recv(recv, (size_t)recv_counts[i], ncclDouble, peers[i], g_comm, st), "ncclRecv")) return 1;
+  int bad = 0;
+  for (int i = 0; i < npeers && !bad; ++i) {
+    if (send_counts[i] > 0) bad = nfail(api.Send(send, (size_t)send_counts[i], ncclDouble, peers[i], g_comm, st), "ncclSend");
+    if (!bad && recv_counts[i] > 0) bad = nfail(api.Recv(recv, (size_t)recv_counts[i], ncclDouble, peers[i], g_comm, st), "ncclRecv");
     send += send_counts[i];
     recv += recv_counts[i];
   }
+  /* the group is closed whatever happened inside it (an open group would swallow every later call on this
+   * thread); the first error is the one reported */
+  if (bad) { char first[sizeof(g_err)]; snprintf(first, sizeof(first), "%s", g_err); api.GroupEnd(); snprintf(g_err, sizeof(g_err), "%s", first); return 1; }
   return nfail(api.GroupEnd(), "ncclGroupEnd");
 }
 

@@ -99,6 +99,7 @@ int pa_fail_at(const char* func, const char* fmt, ...) {
     /* same shape as the reference's abort banner */
     fprintf(stderr, "\nABORTING from %s : [Proc: %d] %s\n\n", func, g_rank, msg);
     fflush(stderr);
+    pa_mpi_abort();       /* with an MPI attached: MPI_Abort(MPI_COMM_WORLD, 1) like CPLM_Abort, every rank ends */
     abort();
   }
   return 1;

@@ -1737,16 +1737,19 @@ __device__ __forceinline__ void bjm_tile(mfma_d4 (&acc)[NT], int (&rid)[NT][4], 
     else
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cg[0]), "+v"(cg[1]), "+v"(cg[2]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]), "+v"(ct[6]), "+v"(ct[7]));
     // the four pivots among themselves: the value of pivot a (lanes hi == a) goes down to the
-    // rows below it with ds_bpermute (issued by hand: behind an LDS-DMA the compiler would
-    // drain all outstanding VMEM in front of every DS instruction); the matrix pipe is the
-    // bottleneck of this kernel, so these three steps are not worth four masked MFMAs
+    // rows below it with ds_bpermute -- through the builtin, NOT by hand: `y` is the result of a
+    // double-precision matrix instruction (and then of an FMA), which needs wait states before a DS
+    // instruction may read it, and the hazard recogniser does not look into inline assembly (bj_g4.hip
+    // read stale registers that way; here the nearest producer was 13 instructions ahead: safe by
+    // distance only).  The permute touches no LDS memory, so the compiler does not drain the LDS-DMA
+    // in flight in front of it (checked in the ISA).  The matrix pipe is the bottleneck of this
+    // kernel, so these three steps are not worth four masked MFMAs.
     double y = acc[TP][r];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const int from = (a * 16 + lo) * 4;
-      int ylo = __double2loint(y), yhi = __double2hiint(y), plo, phi;
-      asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(plo), "=&v"(phi) : "v"(from), "v"(ylo), "v"(yhi));
+      const int plo = __builtin_amdgcn_ds_bpermute(from, __double2loint(y));
+      const int phi = __builtin_amdgcn_ds_bpermute(from, __double2hiint(y));
       const double ya = __hiloint2double(phi, plo);
       y = fma((hi > a) ? -cg[a] : 0.0, ya, y);
     }

@@ -42,6 +42,7 @@ typedef struct { int count_lo, count_hi_and_cancelled, source, tag, error; } mp_
 #define MP_STATUS_IGNORE ((mp_status*)1)
 #define MP_INFO_NULL ((mp_info)0x1c000000)
 #define MP_COMM_TYPE_SHARED 1
+#define MP_COMM_WORLD ((mp_comm)0x44000000)
 
 static struct {
   int resolved;        /* 0: not tried, 1: usable, -1: no MPI in this process */
@@ -61,6 +62,7 @@ static struct {
   int (*Alltoall)(const void*, int, mp_dtype, void*, int, mp_dtype, mp_comm);
   int (*Alltoallv)(const void*, const int*, const int*, mp_dtype, void*, const int*, const int*, mp_dtype, mp_comm);
   int (*Barrier)(mp_comm);
+  int (*Abort)(mp_comm, int);
 } M;
 
 static mp_comm g_comm;
@@ -87,7 +89,7 @@ static int resolve(void) {
   }
 #define S(f) do { *(void**)(&M.f) = sym(lib, "MPI_" #f); if (!M.f) return 0; } while (0)
   S(Initialized); S(Finalized); S(Comm_rank); S(Comm_size); S(Comm_split_type); S(Comm_free); S(Ibcast); S(Test);
-  S(Send); S(Isend); S(Irecv); S(Waitall); S(Allreduce); S(Alltoall); S(Alltoallv); S(Barrier);
+  S(Send); S(Isend); S(Irecv); S(Waitall); S(Allreduce); S(Alltoall); S(Alltoallv); S(Barrier); S(Abort);
 #undef S
   M.resolved = 1;
   return 1;
@@ -102,18 +104,19 @@ static int is_mpich_comm(int c) {
 
 /* 1: the process runs under an initialised MPI, `comm` has more than one rank and the caller
  * has not described the process group itself (preAlps_hip_set_world): the library takes rank
- * and size from the communicator, as the reference does (utils/operator.c:42-43). */
+ * and size from the communicator, as the reference does (utils/operator.c:42-43).  0: no MPI to attach
+ * to (one process).  -1: started by an MPI this library cannot speak to -- the caller must fail, NOT go on
+ * alone (every rank would build and solve the whole problem). */
 int pa_mpi_attach(MPI_Comm comm, int* rank, int* size) {
   if (g_active && (mp_comm)comm == g_comm) { *rank = g_mrank; *size = g_msize; return 1; }
   {
-    /* an Open MPI launcher: its communicators are pointers, this library speaks the MPICH ABI only.
-     * Going on would make every rank solve the whole problem on its own: refuse loudly. */
+    /* an Open MPI launcher: its communicators are pointers, this library speaks the MPICH ABI only */
     const char* os = getenv("OMPI_COMM_WORLD_SIZE");
     if (os && atoi(os) > 1 && pa_world_size() == 1) {
       PA_FAIL("started by Open MPI with %s ranks: this library resolves MPI at run time with the MPICH ABI (MPICH, Intel MPI, "
               "MVAPICH, Cray MPI); with Open MPI describe the process group yourself (preAlps_hip_set_world / "
               "preAlps_hip_set_comm or preAlps_hip_rccl_init, INTEGRATION.md section 2)", os);
-      return 0;
+      return -1;
     }
   }
   if (!resolve()) return 0;
@@ -136,13 +139,38 @@ static void nap(void) {
   struct timespec ts = {0, 200000};   /* 0.2 ms */
   nanosleep(&ts, NULL);
 }
+/* Seconds a rank waits inside one set-up message (rank 0 may be reading and partitioning a large file
+ * meanwhile); PREALPS_MPI_TIMEOUT overrides, 0 = for ever. */
+static double wait_limit(void) {
+  static double lim = -1.0;
+  if (lim < 0.0) { const char* e = getenv("PREALPS_MPI_TIMEOUT"); lim = e ? atof(e) : 3600.0; if (lim < 0.0) lim = 0.0; }
+  return lim;
+}
 static int quiet_wait(mp_req* rq) {
   int done = 0;
+  const double t0 = pa_wtime(), lim = wait_limit();
   for (;;) {
     if (M.Test(rq, &done, MP_STATUS_IGNORE)) return 1;
     if (done) return 0;
+    if (lim > 0.0 && pa_wtime() - t0 > lim) return PA_FAIL("no answer from the other ranks within %.0f s (PREALPS_MPI_TIMEOUT)", lim);
     nap();
   }
+}
+
+/* The reference ends a failed run with MPI_Abort(MPI_COMM_WORLD, 1) (utils/cplm_core/cplm_utils.c:42-58): when
+ * an MPI is attached the library's abort goes the same way, so that no rank is left inside a collective. */
+void pa_mpi_abort(void) {
+  if (g_active && M.resolved > 0 && M.Abort) M.Abort(MP_COMM_WORLD, 1);
+}
+
+/* Collective: nonzero on every rank as soon as `rc` is nonzero on one -- called between the stages of the
+ * set-up so that a rank that failed locally (memory, device) does not leave the others inside the next
+ * collective when the library returns error codes instead of aborting. */
+int pa_mpi_agree(int rc) {
+  int v = rc ? 1 : 0;
+  if (!g_active) return v;
+  if (M.Allreduce(MP_IN_PLACE, &v, 1, MP_INT, MP_MAX, g_comm)) return 1;
+  return v;
 }
 
 #define MP_CHUNK ((size_t)1 << 30)
@@ -263,22 +291,27 @@ int pa_mpi_bind(void) {
   int lr = 0, ls = 1;
   if (local_rank(&lr, &ls)) return PA_FAIL("MPI_Comm_split_type failed");
   int ndev = pa_rt_device_count();
+  int bad = 0;
   if (!pa_rt_ready()) {
-    if (ndev < 1) return PA_FAIL("HIP device unavailable: %s", "no device is visible to this rank; this library has no CPU path");
-    if (preAlps_hip_init(lr % ndev)) return 1;
+    if (ndev < 1) bad = PA_FAIL("HIP device unavailable: %s", "no device is visible to this rank; this library has no CPU path");
+    else bad = preAlps_hip_init(lr % ndev);
   }
+  if (pa_mpi_agree(bad)) return bad ? 1 : PA_FAIL("another rank found no usable device");
   const char* how = getenv("PREALPS_COMM");
+  const char* alt = getenv("PREALPS_RCCL_LIB");      /* (a stand-in library may serve several ranks of one device) */
   int want_rccl = !(how && !strcmp(how, "mpi"));
-  int can = want_rccl && ls <= ndev && pa_rccl_available() == 0;
+  int can = want_rccl && (ls <= ndev || (alt && *alt)) && pa_rccl_available() == 0;
   if (pa_mpi_min_int(&can)) return 1;
   if (how && !strcmp(how, "rccl") && !can)
     return PA_FAIL("PREALPS_COMM=rccl, but %s", ls > ndev ? "several ranks share a device (RCCL refuses that)" : pa_rccl_error());
   if (can) {
     char id[128];
     memset(id, 0, sizeof(id));
-    if (g_mrank == 0 && preAlps_hip_rccl_unique_id(id)) return 1;
+    bad = (g_mrank == 0) ? preAlps_hip_rccl_unique_id(id) : 0;
+    if (pa_mpi_agree(bad)) return bad ? 1 : PA_FAIL("rank 0 could not create the RCCL id");
     if (pa_mpi_bcast(id, sizeof(id), 0)) return 1;
-    if (preAlps_hip_rccl_init(id, g_mrank, g_msize)) return 1;
+    bad = preAlps_hip_rccl_init(id, g_mrank, g_msize);
+    if (pa_mpi_agree(bad)) return bad ? 1 : PA_FAIL("another rank could not join the RCCL communicator");
     g_binding = "rccl";
   } else {
     if (preAlps_hip_set_world(g_mrank, g_msize)) return 1;

@@ -1001,7 +1001,11 @@ static int build_distributed(const char* file, int rank, int size) {
     in->perm = (int*)malloc((size_t)N * sizeof(int));
     iperm = (int*)malloc((size_t)N * sizeof(int));
     d = (double*)malloc((size_t)N * sizeof(double));
-    if (!in->rowPos || !in->perm || !iperm || !d) return PA_FAIL("out of host memory");
+  }
+  {
+    /* (a rank that cannot hold the vectors must not leave the others inside the broadcasts) */
+    const int mine = rank != 0 && (!in->rowPos || !in->perm || !iperm || !d);
+    if (pa_mpi_agree(mine)) return mine ? PA_FAIL("out of host memory") : PA_FAIL("another rank ran out of host memory");
   }
   if (pa_mpi_bcast(in->rowPos, ((size_t)nparts + 1) * sizeof(int), 0) || pa_mpi_bcast(in->perm, (size_t)N * sizeof(int), 0) ||
       pa_mpi_bcast(d, (size_t)N * sizeof(double), 0))
@@ -1010,22 +1014,35 @@ static int build_distributed(const char* file, int rank, int size) {
     for (int k = 0; k < N; ++k) iperm[in->perm[k]] = k;
   TRACE("ordering + scaling vector (broadcast)");
   int* recv_by_proc = NULL;
+  int prc = 0;
+  /* entries of every rank's panel, announced before the rows travel: every buffer of the exchange exists (and
+   * the ranks have agreed that it does) before the first message */
+  long long* nzs = (long long*)calloc((size_t)size, sizeof(long long));
+  if (pa_mpi_agree(nzs == NULL)) { free(nzs); return PA_FAIL("out of host memory"); }
   if (rank == 0) {
     /* raw rows of every other panel: row lengths, column ids, values -- three messages per rank */
-    size_t cap = 0;
-    int* bl = NULL; int* bc = NULL; double* bv = NULL;
+    /* buffers for the largest panel, made before the first message: the ranks that wait for their rows
+     * hear about a failure here (pa_mpi_agree below) instead of waiting for ever */
+    size_t cap = 0, capm = 0;
     for (int g = 1; g < size; ++g) {
       int p0 = (int)((long long)g * nparts / size), p1 = (int)((long long)(g + 1) * nparts / size);
       int r0 = in->rowPos[p0], mg = in->rowPos[p1] - r0;
       size_t nz = 0;
       for (int i = 0; i < mg; ++i) { int old = in->perm[r0 + i]; nz += (size_t)(rp[old + 1] - rp[old]); }
-      if (nz > cap || !bl) {
-        free(bc); free(bv);
-        cap = nz + nz / 8 + 16;
-        bc = (int*)big_alloc(cap * sizeof(int)); bv = (double*)big_alloc(cap * sizeof(double));
-      }
-      bl = (int*)realloc(bl, ((size_t)mg + 1) * sizeof(int));
-      if (!bl || !bc || !bv) return PA_FAIL("out of host memory for the panel of rank %d", g);
+      if (nz > cap) cap = nz;
+      if ((size_t)mg > capm) capm = (size_t)mg;
+      nzs[g] = (long long)nz;
+    }
+    if (pa_mpi_bcast(nzs, (size_t)size * sizeof(long long), 0)) { free(nzs); return 1; }
+    int* bl = (int*)malloc((capm + 1) * sizeof(int));
+    int* bc = (int*)big_alloc((cap + 16) * sizeof(int));
+    double* bv = (double*)big_alloc((cap + 16) * sizeof(double));
+    if (pa_mpi_agree(!bl || !bc || !bv)) { free(bl); free(bc); free(bv); free(nzs); return PA_FAIL("out of host memory for the row panels"); }
+    for (int g = 1; g < size; ++g) {
+      int p0 = (int)((long long)g * nparts / size), p1 = (int)((long long)(g + 1) * nparts / size);
+      int r0 = in->rowPos[p0], mg = in->rowPos[p1] - r0;
+      size_t nz = 0;
+      for (int i = 0; i < mg; ++i) { int old = in->perm[r0 + i]; nz += (size_t)(rp[old + 1] - rp[old]); }
       bl[0] = 0;
       for (int i = 0; i < mg; ++i) { int old = in->perm[r0 + i]; bl[i + 1] = bl[i] + (rp[old + 1] - rp[old]); }
 #pragma omp parallel for num_threads(pa_host_threads()) schedule(static)
@@ -1040,43 +1057,53 @@ static int build_distributed(const char* file, int rank, int size) {
     }
     free(bl); free(bc); free(bv);
     TRACE("rank 0: panels sent");
-    if (build_panel(o, rp, ci, v, 1, d, iperm, hdr[3], &recv_by_proc)) return 1;
+    prc = build_panel(o, rp, ci, v, 1, d, iperm, hdr[3], &recv_by_proc);
     free(rp); free(ci); free(v);
   } else {
     int p0 = (int)((long long)rank * nparts / size), p1 = (int)((long long)(rank + 1) * nparts / size);
     int mg = in->rowPos[p1] - in->rowPos[p0];
+    if (pa_mpi_bcast(nzs, (size_t)size * sizeof(long long), 0)) { free(nzs); return PA_FAIL("receiving the panel sizes failed"); }
+    size_t nz = (size_t)nzs[rank];
     int* lrp = (int*)malloc(((size_t)mg + 1) * sizeof(int));
-    if (!lrp || pa_mpi_recv(lrp, ((size_t)mg + 1) * sizeof(int), 0, 41)) return PA_FAIL("receiving the panel failed");
-    size_t nz = (size_t)lrp[mg];
     int* lci = (int*)big_alloc((nz ? nz : 1) * sizeof(int));
     double* lv = (double*)big_alloc((nz ? nz : 1) * sizeof(double));
-    if (!lci || !lv) return PA_FAIL("out of host memory for the row panel (%zu entries)", nz);
+    if (pa_mpi_agree(!lrp || !lci || !lv)) {      /* (pairs with rank 0's) */
+      free(lrp); free(lci); free(lv); free(nzs);
+      return PA_FAIL("out of host memory for the row panels (%zu entries here)", nz);
+    }
+    if (pa_mpi_recv(lrp, ((size_t)mg + 1) * sizeof(int), 0, 41) || (size_t)lrp[mg] != nz) return PA_FAIL("receiving the panel failed");
     if (pa_mpi_recv(lci, nz * sizeof(int), 0, 42) || pa_mpi_recv(lv, nz * sizeof(double), 0, 43)) return 1;
     TRACE("panel received");
     int rc = build_panel(o, lrp, lci, lv, 0, d, iperm, hdr[3], &recv_by_proc);
     free(lrp); free(lci); free(lv);
-    if (rc) return 1;
+    prc = rc;
   }
+  free(nzs);
+  if (pa_mpi_agree(prc)) return prc ? 1 : PA_FAIL("another rank could not build its row panel");
   free(d);
   /* send lists: every rank asks the owners for the rows behind its halo slots (halo_cols is
    * ascending, hence grouped by owner); what a rank is asked for, in that order, is what it packs */
   int* asked = NULL;
   int* asked_cnt = (int*)calloc((size_t)size, sizeof(int));
-  if (!asked_cnt || pa_mpi_swap_lists(o->halo_cols, recv_by_proc, &asked, asked_cnt)) return 1;
+  if (pa_mpi_agree(asked_cnt == NULL)) { free(asked_cnt); return PA_FAIL("out of host memory"); }
+  if (pa_mpi_swap_lists(o->halo_cols, recv_by_proc, &asked, asked_cnt)) return 1;
   {
     long long tot = 0;
     for (int g = 0; g < size; ++g) tot += asked_cnt[g];
     for (long long k = 0; k < tot; ++k) {
       int r = asked[k] - in->row_off;
-      if (r < 0 || r >= in->m) return PA_FAIL("a neighbour asked for row %d, which this rank does not own", asked[k]);
+      if (r < 0 || r >= in->m) { prc = PA_FAIL("a neighbour asked for row %d, which this rank does not own", asked[k]); break; }
       asked[k] = r;
     }
   }
   free(iperm);
-  finish_peers(o, recv_by_proc, asked, asked_cnt);
+  if (!prc) finish_peers(o, recv_by_proc, asked, asked_cnt);
   free(recv_by_proc); free(asked_cnt);
   TRACE("peer lists (exchanged)");
-  return upload_operator(o, t_build0);
+  if (!prc) prc = upload_operator(o, t_build0);
+  /* every rank leaves with the same answer: the solver's collectives come next */
+  if (pa_mpi_agree(prc)) return prc ? 1 : PA_FAIL("another rank could not finish its part of the operator");
+  return 0;
 }
 
 /* The number of subdomains is PREALPS_NPARTS (default: the process count, as in the
@@ -1091,7 +1118,9 @@ int preAlps_OperatorBuild(const char* matrixFilename, MPI_Comm comm) {
     return PA_FAIL("Only MatrixMarket (.mtx) files are supported: %s", matrixFilename);
   if (env_int("PREALPS_PLAN_ONLY", 0)) g_plan_only = 1;
   int mrank = 0, msize = 1;
-  if (pa_mpi_attach(comm, &mrank, &msize)) {
+  const int att = pa_mpi_attach(comm, &mrank, &msize);
+  if (att < 0) return 1;       /* (an MPI this library cannot speak to: never go on as a lone process) */
+  if (att) {
     if (g_op.info.built) preAlps_OperatorFree();
     if (preAlps_hip_set_world(mrank, msize)) return 1;
     if (!g_plan_only && pa_mpi_bind()) return 1;

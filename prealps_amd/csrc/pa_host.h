@@ -36,7 +36,9 @@ int pa_exchange(const double* dev_send, const int* send_counts, double* dev_recv
                 const int* recv_counts, const int* peers, int npeers);
 
 /* ---- an MPI launcher around us (mpi_glue.c): resolved at run time, MPICH ABI -------------- */
-int pa_mpi_attach(MPI_Comm comm, int* rank, int* size);   /* 1: take rank / size from comm (> 1 ranks) */
+int pa_mpi_attach(MPI_Comm comm, int* rank, int* size);   /* 1: take rank / size from comm (> 1 ranks); 0: none; -1: an MPI this library cannot use */
+void pa_mpi_abort(void);                                  /* MPI_Abort(MPI_COMM_WORLD, 1) when an MPI is attached */
+int pa_mpi_agree(int rc);                                 /* collective: nonzero everywhere when nonzero anywhere */
 int pa_mpi_active(void);
 const char* pa_mpi_binding(void);                         /* "rccl", "mpi-host-staged", "none" */
 int pa_mpi_bind(void);                                    /* device of this rank + the two hooks; collective */

@@ -110,6 +110,50 @@ def test_mpi_driver_two_ranks_two_gpus_native_rccl(tmp_path):
     np.testing.assert_allclose(x, ref["x"], rtol=1e-7, atol=1e-10 * np.abs(ref["x"]).max())
 
 
+@pytest.mark.skipif(not have_mpi, reason="no MPI launcher in this image")
+@pytest.mark.parametrize("alg", [0, 1])
+def test_rccl_binding_three_ranks_one_gpu_through_a_stand_in(tmp_path, alg):
+    """The `rccl` branch of pa_mpi_bind with more than one rank: unique id from rank 0 broadcast over MPI,
+    ncclCommInitRank on every rank, the self-test, then a whole solve whose halo exchange is a grouped
+    ncclSend / ncclRecv with TWO peers on the middle rank and whose sums are ncclAllReduce calls on the library's
+    stream.  The real RCCL refuses ranks that share a device, so PREALPS_RCCL_LIB points the binding
+    (comm_rccl.hip) at tests/c/rccl_standin.c -- test infrastructure that stages every call through the host and
+    MPI.  What is checked is the binding and the library's call sequence, not RCCL."""
+    from oracle import oracle as O
+    n, nparts, world, t = 12, 9, 3, 4
+    (rp, ci, v), B, perm, rowpos = _problem(n, nparts)
+    mtx = str(tmp_path / "a.mtx")
+    _write_mtx(mtx, rp, ci, v)
+    prealps_amd.load()
+    standin = str(tmp_path / "librccl_standin.so")
+    subprocess.check_call(["gcc", "-w", "-shared", "-fPIC", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + MPI_INC,
+                           os.path.join(ROOT, "tests", "c", "rccl_standin.c"), "-o", standin, "-L/opt/rocm/lib", "-lamdhip64",
+                           os.path.join(MPI_LIB, "libmpi.so.12"), "-Wl,-rpath," + MPI_LIB, "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu"])
+    exe = str(tmp_path / "ecg_driver_mpi")
+    subprocess.check_call(["gcc", "-std=gnu11", "-DPREALPS_USE_SYSTEM_MPI", "-I" + MPI_INC, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "ecg_driver.c"), "-L" + os.path.join(ROOT, "prealps_amd"),
+                           "-lprealps_hip", os.path.join(MPI_LIB, "libmpi.so.12"), "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu",
+                           "-Wl,-rpath," + os.path.join(ROOT, "prealps_amd"), "-Wl,-rpath," + MPI_LIB, "-lm", "-o", exe])
+    env = dict(os.environ, PREALPS_NPARTS=str(nparts), PREALPS_SETUP_TRACE="1", OMP_NUM_THREADS="4",
+               PREALPS_RCCL_LIB=standin, PREALPS_COMM="rccl")
+    r = subprocess.run([MPIEXEC, "-n", str(world), exe, "-m", mtx, "-e", str(t), "-o", str(alg), "-x", str(tmp_path / "sol")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stderr.count("hooks: rccl") == world, r.stderr[-3000:]
+    it = int(re.search(r"iter: (\d+)", r.stdout).group(1))
+    ref = O.ECG(B, rowpos, t, ortho_alg=O.ORTHODIR if alg == 0 else O.ORTHOMIN).solve(O.reference_rhs(rowpos))
+    assert it == ref["iters"], (it, ref["iters"])
+    x = np.concatenate([np.fromfile(str(tmp_path / "sol") + ".%d" % k) for k in range(world)])
+    np.testing.assert_allclose(x, ref["x"], rtol=1e-7, atol=1e-10 * np.abs(ref["x"]).max())
+    # the stand-in's own count, printed when the communicator goes: the middle rank talks to two peers
+    stats = {int(m.group(1)): tuple(int(g) for g in m.groups()[1:])
+             for m in re.finditer(r"\[rccl stand-in\] rank (\d+): (\d+) all-reduces, (\d+) sends, (\d+) receives, (\d+) groups", r.stderr)}
+    if stats:
+        assert stats[1][0] >= 2 * it and stats[1][3] >= it          # >= two sums and one exchange per iteration
+        # (every group but the self-test's ring step sends to and receives from both neighbours)
+        assert stats[1][1] >= 2 * (stats[1][3] - 1) and stats[1][2] >= 2 * (stats[1][3] - 1)
+
+
 @pytest.mark.skipif(not (have_mpi and os.path.exists(REF_BIN)), reason="needs MPI and the prebuilt reference driver (oracle/Makefile)")
 def test_unmodified_reference_driver_two_ranks_one_gpu(tmp_path):
     """The reference's examples/test_ecg_prealps_op.c, compiled unchanged where the reference tree

@@ -141,3 +141,45 @@ def test_unmodified_reference_driver_plans_under_mpiexec(tmp_path):
     assert r.returncode != 0
     assert "rank 0: panels sent" in r.stderr and "panel received" in r.stderr and "peer lists (exchanged)" in r.stderr
     assert "ABORTING from" in r.stderr
+
+
+# ---- failure semantics (reference: every fatal error -> MPI_Abort(MPI_COMM_WORLD, 1), utils/cplm_core/cplm_utils.c:42-58) ----
+@pytest.mark.skipif(not have_mpi, reason="no MPI launcher in this image")
+@pytest.mark.parametrize("abort_mode", [1, 0])
+def test_failure_on_rank_zero_ends_every_rank(tmp_path, abort_mode):
+    """Only rank 0 reads the matrix; here the file does not exist.  Abort mode (default): the banner, then
+    MPI_Abort takes all three ranks down (no rank stays inside the broadcast).  Return-code mode: all three
+    ranks come back from preAlps_OperatorBuild with 1 and finish normally."""
+    exe = str(tmp_path / "mpi_fail_probe")
+    _cc(os.path.join(ROOT, "tests", "c", "mpi_fail_probe.c"), exe)
+    r = subprocess.run([MPIEXEC, "-n", "3", exe, str(tmp_path / "nothing_here.mtx"), str(abort_mode)],
+                       env=dict(os.environ, OMP_NUM_THREADS="2", PREALPS_MPI_TIMEOUT="60"), capture_output=True, text=True, timeout=120)
+    if abort_mode:
+        assert r.returncode != 0
+        assert "ABORTING from" in r.stderr and "[Proc: 0]" in r.stderr
+        assert "rc" not in r.stdout                     # nobody got as far as the print
+    else:
+        assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+        assert sorted(r.stdout.split("\n")[:3]) == ["rank 0: rc 1", "rank 1: rc 1", "rank 2: rc 1"]
+
+
+def test_open_mpi_launcher_is_refused_in_return_code_mode(tmp_path):
+    """Under an Open MPI launcher (its communicators are pointers, the run-time binding speaks the MPICH ABI)
+    preAlps_OperatorBuild must fail -- also when the library returns error codes instead of aborting: going on
+    would make every rank build and solve the whole problem alone."""
+    rp, ci, v = gen.poisson3d_csr(4)
+    mtx = str(tmp_path / "a.mtx")
+    write_mtx(mtx, rp, ci, v)
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import prealps_amd
+L = prealps_amd.load()
+L.preAlps_hip_plan_only(1)
+L.preAlps_hip_set_abort_mode(0)
+rc = L.preAlps_OperatorBuild(%r.encode(), 0x44000000)
+print("rc", rc, L.preAlps_hip_last_error().decode()[:60])
+""" % (ROOT, mtx)
+    r = subprocess.run([os.sys.executable, "-c", code], env=dict(os.environ, OMPI_COMM_WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.startswith("rc 1 ") and "Open MPI" in r.stdout, r.stdout
