@@ -529,11 +529,9 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
   const int simds = 4 * (pa_rt_num_cus() > 0 ? pa_rt_num_cus() : 256);
   int ring = ring_env == 2 || ring_env == 4 || ring_env == 8 ? ring_env : (count < 2 * simds ? 8 : 2);
   while (ring > 2 && ((ring - 1) * nld > 15 || (size_t)ring * cbuf * 8 > 40 * 1024)) ring >>= 1;
-  // PREALPS_BJ_G4_LDSPAD = extra KiB of LDS per wavefront: lowers the number of resident blocks (an
-  // experiment: fewer blocks in flight keep the records of a block in the Infinity Cache between its sweeps)
-  static int pad_kib = -1;
-  if (pad_kib < 0) { const char* e = getenv("PREALPS_BJ_G4_LDSPAD"); pad_kib = e ? atoi(e) : 0; }
-  const int per_wave = ring * cbuf + pad_kib * 128;
+  // (Fewer resident blocks, so that a block's records survive in the Infinity Cache between its two sweeps, was
+  // tried with padded LDS in round 3: 130.4 / 144.9 us against 122.1 us.  The switch is gone.)
+  const int per_wave = ring * cbuf;
   int waves = (160 * 1024) / (per_wave * 8);
   if (waves > 4) waves = 4;
   if (waves < 1) return 1;

@@ -2305,14 +2305,11 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
                         const double* in, double* out) {
   // LDS per wave: two chunk buffers of CH records of the widest band in this class
   const int wr = (wmax + 2) & ~1;
-  // PREALPS_BJ_RING=1: a ring of three buffers for narrow bands (two chunks in flight, counted
-  // waits).  Measured neutral (183.6 vs 187.1 us on elasticity, 173.6 vs 172.1 on Poisson, same box):
-  // the sweep does not wait for its band -- the counters show the VALU busy 62 % of the time and the
-  // waves waiting on LDS reads and lane moves, not on VMEM -- so two buffers stay the default.
-  static int ring = -1;
-  if (ring < 0) { const char* e = getenv("PREALPS_BJ_RING"); ring = e ? atoi(e) : 0; }
+  // Two chunk buffers.  (A ring of three with counted waits measured neutral in round 2 -- 183.6 vs 187.1 us
+  // on elasticity, 173.6 vs 172.1 on Poisson, same box: the sweep does not wait for its band -- and its
+  // switch is gone; the kernels still take the ring depth as an argument.)
   const int cbuf = (CH * wr + 127) & ~127;      // doubles, each buffer a multiple of 1 KiB
-  const int nbuf = (ring && (CH * wr * 8 + 1023) / 1024 <= 4 && 3 * cbuf * 8 * 16 <= 160 * 1024) ? 3 : 2;
+  const int nbuf = 2;
   int per_wave = nbuf * cbuf;
   int waves = (160 * 1024) / (per_wave * 8);
   if (waves > 4) waves = 4;
@@ -2338,7 +2335,7 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
     if (pl->Lf2 && (R == 2 || R == 3)) {
       const int wr2 = wmax + 4;
       const int cb2 = (CH * wr2 + 127) & ~127;
-      const int nbuf2 = (ring && (CH * wr2 * 8 + 1023) / 1024 <= 4 && 3 * cb2 * 8 * 16 <= 160 * 1024) ? 3 : 2;
+      const int nbuf2 = 2;
       const int pw2 = nbuf2 * cb2;
       int wv2 = (160 * 1024) / (pw2 * 8);
       if (wv2 > 4) wv2 = 4;
@@ -2363,22 +2360,6 @@ static int bj_launch_ch(const pa_bj_plan_t* pl, int R, int wmax, const int* list
                              pl->invd_b, pw2, nbuf2, in, out);
         return kfail("k_bj_apply_pairs");
       }
-    }
-  }
-  // narrow bands at up to 4 columns: variants that leave room for 5 / 6 wavefronts per SIMD
-  if constexpr (TS <= 4 && XS == TS) {
-    static int occ = -1;
-    if (occ < 0) { const char* e = getenv("PREALPS_BJ_OCC"); occ = e ? atoi(e) : 0; }
-    if (R == 2 && occ >= 5 && lds <= 64 * 1024) {
-      if (occ == 5)
-        PA_LAUNCH((k_bj_apply<TS, 2, CH, XS, 5>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
-                           pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
-                           pl->invd_b, per_wave, nbuf, in, out);
-      else
-        PA_LAUNCH((k_bj_apply<TS, 2, CH, XS, 6>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count,
-                           pl->row0, pl->nrows, pl->bw, pl->off, pl->map_f, pl->map_b, pl->Lf, pl->Lb, pl->invd_f,
-                           pl->invd_b, per_wave, nbuf, in, out);
-      return kfail("k_bj_apply");
     }
   }
   switch (R) {
@@ -2417,23 +2398,15 @@ static int bj_launch(const pa_bj_plan_t* pl, int R, int wmax, const int* list, i
 #undef BJM_LAUNCH
     return kfail("k_bj_mfma");
   }
-  // PREALPS_BJ_SPLIT=1: panels of 8 / 16 columns as 2 / 4 wavefronts of 4 columns each per
-  // subdomain.  Measured slower (each wavefront streams the factor again through L2: 257 vs
-  // 243 us at 8 columns, 485 vs 434 us at 16), so one wavefront carries all columns by default.
-  static int split = -1;
-  if (split < 0) { const char* e = getenv("PREALPS_BJ_SPLIT"); split = e ? atoi(e) : 0; }
-  if constexpr (TS >= 8) {
-    if (split) return bj_launch_ch<4, 8, TS>(pl, R, wmax, list, count, in, out);
-  }
+  // (Panels of 8 / 16 columns as 2 / 4 wavefronts of 4 columns each per subdomain measured slower in round 1 --
+  // each wavefront streams the factor again through L2: 257 vs 243 us at 8 columns, 485 vs 434 us at 16 -- and
+  // the variant is gone.)
   // Few blocks (a GPU of a multi-GPU run holds 1/8 of them): below one wavefront per SIMD the
   // sweep is latency bound, so a 4-column panel is shared by two wavefronts of 2 columns each
   // (half the FMAs and pivot broadcasts per wavefront; the band is read twice, from L2).
-  // PREALPS_BJ_SPLIT4: -1 (default) when a class has fewer blocks than the chip has SIMDs, 0 never, 1 always.
   if constexpr (TS == 4) {
-    static int split4 = -2;
-    if (split4 == -2) { const char* e = getenv("PREALPS_BJ_SPLIT4"); split4 = e ? atoi(e) : -1; }
     const int simds = 4 * (pa_rt_num_cus() > 0 ? pa_rt_num_cus() : 256);
-    if (split4 == 1 || (split4 < 0 && count < simds)) return bj_launch_ch<2, 8, 4>(pl, R, wmax, list, count, in, out);
+    if (count < simds) return bj_launch_ch<2, 8, 4>(pl, R, wmax, list, count, in, out);
   }
   return bj_launch_ch<TS, 8, TS>(pl, R, wmax, list, count, in, out);
 }
@@ -2494,27 +2467,18 @@ static int bj_factor_big_launch(const int* list, int count, int wmax, const int*
 
 // 16-column panels: all columns in one pass over the factor (172 VGPRs, two wavefronts per SIMD: 2.6 TB/s
 // of factor bytes) instead of two 8-column passes at 4.5 TB/s each: 4.37 against 5.09 ms per apply on the
-// 64-block elasticity problem.  PREALPS_ND_WIDE16=0: the two passes.
-static int nd_wide16() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PREALPS_ND_WIDE16"); v = e ? atoi(e) : 1; }
-  return v;
-}
-
+// 64-block elasticity problem (round 3, same-call A/B).
 // one level of the tree; launches of few workgroups put more threads on each output
 template <int XS>
 static int nd_launch_fwd(const nd_args& a, const int* cfront, const int* crow0, int nwg, const double* in) {
   if (nwg <= 0) return 0;
-  static int few = -1;
-  if (few < 0) { const char* e = getenv("PREALPS_ND_FEW"); few = e ? atoi(e) : 1024; }
-  if constexpr (XS == 16) {                   // all 16 columns in one pass over the factor (nd_wide16)
-    if (nd_wide16()) {
-      if (nwg < few) PA_LAUNCH((k_nd_forward<16, 16, 2>), dim3(nwg), dim3(ND_CHUNK * 2), 0, cur_stream(), a, cfront, crow0, in);
-      else PA_LAUNCH((k_nd_forward<16, 16, 1>), dim3(nwg), dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, in);
-      return kfail("k_nd_forward");
-    }
+  constexpr int few = 1024;
+  if constexpr (XS == 16) {                   // all 16 columns in one pass over the factor
+    if (nwg < few) PA_LAUNCH((k_nd_forward<16, 16, 2>), dim3(nwg), dim3(ND_CHUNK * 2), 0, cur_stream(), a, cfront, crow0, in);
+    else PA_LAUNCH((k_nd_forward<16, 16, 1>), dim3(nwg), dim3(ND_CHUNK), 0, cur_stream(), a, cfront, crow0, in);
+    return kfail("k_nd_forward");
   }
-  constexpr int TS = XS <= 8 ? XS : 8;        // 16-column panels in two column groups (LDS, registers)
+  constexpr int TS = XS <= 8 ? XS : 8;
   constexpr int QB = TS >= 8 ? 2 : 4;
   const dim3 grid(nwg, XS / TS);
   if (nwg < few) PA_LAUNCH((k_nd_forward<TS, XS, QB>), grid, dim3(ND_CHUNK * QB), 0, cur_stream(), a, cfront, crow0, in);
@@ -2525,13 +2489,10 @@ static int nd_launch_fwd(const nd_args& a, const int* cfront, const int* crow0, 
 template <int XS>
 static int nd_launch_bwd(const nd_args& a, const int* cfront, const int* ccol0, int nwg, double* out) {
   if (nwg <= 0) return 0;
-  static int few = -1;
-  if (few < 0) { const char* e = getenv("PREALPS_ND_FEW_BWD"); few = e ? atoi(e) : 2048; }
+  constexpr int few = 2048;
   if constexpr (XS == 16) {
-    if (nd_wide16()) {
-      PA_LAUNCH((k_nd_backward<16, 16, 4>), dim3(nwg), dim3(256), 0, cur_stream(), a, cfront, ccol0, out);
-      return kfail("k_nd_backward");
-    }
+    PA_LAUNCH((k_nd_backward<16, 16, 4>), dim3(nwg), dim3(256), 0, cur_stream(), a, cfront, ccol0, out);
+    return kfail("k_nd_backward");
   }
   constexpr int TS = XS <= 8 ? XS : 8;
   constexpr int WB = TS >= 8 ? 8 : 16;

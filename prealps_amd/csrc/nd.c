@@ -406,7 +406,7 @@ static double nd_selinv(int n, int m, int ld, double* pf, double* wk) {
  * laid out supernode after supernode) and dinv (1 / L_jj per new index).  *fail = 1 + new index
  * of a non-positive pivot.  invert: 1 = panels in selective-inversion form (nd_selinv; what the
  * device kernels expect; *dev = largest deviation of an inverse), 0 = the plain factor (selfcheck). */
-static double g_cpu_factor, g_cpu_selinv;   /* PREALPS_ND_TRACE: CPU seconds over all threads */
+static double g_cpu_factor, g_cpu_selinv;   /* PREALPS_SETUP_TRACE: CPU seconds over all threads */
 static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv, int* fail, int invert, double* dev) {
   const int nsn = B->tree.nsn, b = B->b;
   double t_fac = 0.0, t_inv = 0.0;
@@ -480,7 +480,7 @@ static int nd_numeric(const nd_block_t* B, double* hF, double* hB, double* dinv,
   }
   for (int s = 0; s < nsn; ++s) free(upd[s]);
   free(upd); free(loc);
-  if (getenv("PREALPS_ND_TRACE")) {
+  if (getenv("PREALPS_SETUP_TRACE")) {
 #pragma omp critical
     { g_cpu_factor += t_fac; g_cpu_selinv += t_inv; }
   }
@@ -553,7 +553,7 @@ static int nd_numeric_device(pa_nd_t* S, const nd_block_t* B, int nblk, const in
                              const int* h_m, const int* h_ld, const int* h_rows_off, const int* h_height, int maxh,
                              long long totrows, int* fail_g, int* fail_col) {
   int rc = 0;
-  const int trace = getenv("PREALPS_ND_TRACE") != NULL;
+  const int trace = getenv("PREALPS_SETUP_TRACE") != NULL;
   double t0 = pa_wtime();
   if (pa_nd_chunk_rows() != 256) return PA_FAIL("block solve: chunk size and factor kernels disagree");
   int* h_child = (int*)malloc((size_t)2 * nsn * sizeof(int));
@@ -712,7 +712,7 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
   if (!B) return PA_FAIL("out of host memory");
   int rc = 0;
   *fail_row = -1;
-  const int trace = getenv("PREALPS_ND_TRACE") != NULL;
+  const int trace = getenv("PREALPS_SETUP_TRACE") != NULL;
   double t_phase = pa_wtime();
 #pragma omp parallel for num_threads(pa_host_threads()) schedule(dynamic, 1)
   for (int x = 0; x < nblk; ++x) {
@@ -877,7 +877,7 @@ int pa_nd_create(const CPLM_Mat_CSR_t* A, int nblk, const int* blocks, const int
         for (int k0 = 0; k0 < h_n[g]; k0 += CB) { bf[y] = g; bc[y++] = k0; }
       }
       S->f_count[h] = (int)nf; S->b_count[h] = (int)nb;
-      if (getenv("PREALPS_ND_TRACE")) {
+      if (getenv("PREALPS_SETUP_TRACE")) {
         long long by = 0; int cnt = 0, nmx = 0, fmx = 0;
         for (int g = 0; g < nsn; ++g) if (h_height[g] == h) {
           ++cnt; by += (long long)h_ld[g] * h_n[g];
@@ -1020,7 +1020,7 @@ int preAlps_hip_nd_selfcheck(int n, const int* rowPtr, const int* colInd, const 
       }
     double num = 0.0, den = 0.0;
     for (int i = 0; i < n; ++i) { num += (w[i] - ax[i]) * (w[i] - ax[i]); den += ax[i] * ax[i]; }
-    if (getenv("PREALPS_ND_TRACE"))
+    if (getenv("PREALPS_SETUP_TRACE"))
       for (int s2 = B.tree.nsn - 1; s2 >= 0 && s2 >= B.tree.nsn - 40; --s2)
         if (B.height[s2] >= maxh - 2)
           fprintf(stderr, "[nd] supernode %d height %d: %d columns, %d rows below\n", s2, B.height[s2],

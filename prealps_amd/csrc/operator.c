@@ -84,8 +84,6 @@ static void* big_alloc(size_t bytes) {
 static int env_int(const char* name, int dflt);
 static size_t g_dbg_val_bytes, g_dbg_slot_bytes;
 static int spmm_block_rows(int m, int dflt) {
-  const char* e = getenv("PREALPS_SPMM_BLOCK_ROWS");
-  if (e && *e) return atoi(e);
   int cus = pa_rt_num_cus() > 0 ? pa_rt_num_cus() : 256;
   int rows = dflt;
   while (rows > 64 && (long long)m / rows < 4LL * cus) rows -= 64;
@@ -149,9 +147,9 @@ void preAlps_OperatorFree(void) {
 
 /* ------------------------------------------------------------ the plan ---- */
 /* Local CSR (local column ids) -> SELL-64 slices + workgroup blocks.  A block
- * is a run of slices of one subdomain (at most PREALPS_SPMM_BLOCK_ROWS rows);
- * its LDS window is the subdomain's own row range, or the PREALPS_SPMM_WIN_CAP
- * rows around the block when the subdomain is larger than that. */
+ * is a run of slices of one subdomain (at most spmm_block_rows() rows);
+ * its LDS window is the subdomain's own row range, or the 256 rows around the
+ * block when the subdomain is larger than that (1024-row windows measured slower). */
 static int build_plan_staged(pa_operator_t* o, int ts);
 static int build_plan_runs(pa_operator_t* o, int ts);
 
@@ -183,7 +181,7 @@ static int build_plan(pa_operator_t* o, int ts) {
     }
     free_plan(o); /* too many rows to stage, or not worth it: use the general kernel */
   }
-  int win_cap = env_int("PREALPS_SPMM_WIN_CAP", 256);
+  int win_cap = 256;
   int blk_rows = spmm_block_rows(m, 256);
   if (blk_rows < 64) blk_rows = 64;
   blk_rows &= ~63;
@@ -300,7 +298,7 @@ static int build_plan_staged(pa_operator_t* o, int ts) {
   const double* val = in->A.val;
   int m = in->m, ncols = m + in->halo;
   /* LDS budget of a block: 32 KiB at ts <= 4, 64 KiB at ts = 8 (two workgroups per CU) */
-  int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", ts <= 4 ? 32768 : 49152) / (ts * 8);
+  int cap_rows = (ts <= 4 ? 32768 : 49152) / (ts * 8);
   if (cap_rows > 65535) cap_rows = 65535;
   /* 8-column panels: 192 rows and 48 KiB of staging (three workgroups per CU) measured 7 % faster */
   int blk_rows = spmm_block_rows(m, ts <= 4 ? 256 : 192);
@@ -1387,11 +1385,11 @@ static int build_plan_runs(pa_operator_t* o, int ts) {
   const int* colind = o->lcol;
   const double* val = in->A.val;
   int m = in->m, ncols = m + in->halo;
-  /* panels of 16 columns: one workgroup stages all 16 (PREALPS_SPMM_WIDE16=1, the matrix is then
-   * streamed once), or two workgroups per block take 8 columns each (kernels.hip; staging area and
-   * pay-off test of stride 8) */
-  if (ts >= 16 && !env_int("PREALPS_SPMM_WIDE16", 0)) ts /= 2;
-  int cap_rows = env_int("PREALPS_SPMM_STAGE_BYTES", ts <= 4 ? 32768 : 49152) / (ts * 8) - 2;
+  /* panels of 16 columns: the plan is cut for 8 columns and a block is worked twice, once per half of the
+   * panel (spmm.hip; staging area and pay-off test of stride 8).  One workgroup staging all 16 columns was
+   * measured slower: 628 against 371 us, the LDS reads of 128 B per nonzero and lane dominate. */
+  if (ts >= 16) ts /= 2;
+  int cap_rows = (ts <= 4 ? 32768 : 49152) / (ts * 8) - 2;
   if (cap_rows > 65533) cap_rows = 65533;
   /* 8-column panels: 192 rows and 48 KiB of staging (three workgroups per CU) measured 7 % faster */
   int blk_rows = spmm_block_rows(m, ts <= 4 ? 256 : 192);

@@ -485,7 +485,7 @@ static int bisect(const graph_t* g, int k, int* part) {
   rb_t c;
   int* list = (int*)malloc((size_t)n * sizeof(int));
   int rc = rb_alloc(&c, g, part) || !list;
-  { const char* e = getenv("PREALPS_PARTITION_SMOOTH"); c.smooth = e ? atoi(e) : 0; }
+  c.smooth = 0;
   if (!rc) {
     long long wtot = 0;
     for (int v = 0; v < n; ++v) { list[v] = v; wtot += g->vw[v]; }
@@ -617,7 +617,7 @@ static int nd_rec(nd_ctx_t* c, int* list, int len, long long w) {
    * 1) comes from a maximum matching (Koenig).  On a jagged cut it is up to a third smaller than
    * the lighter boundary; the fill of the factor goes with the square.  side bit 4 = in the cover. */
   int cover_ok = 0;
-  if (getenv("PREALPS_ND_COVER") == NULL || atoi(getenv("PREALPS_ND_COVER"))) {
+  {
     int* mate = c->rb.queue;            /* list-local: matched partner or -1 (boundary vertices only) */
     int* dist = c->rb.tmp;              /* BFS layers of the left side */
     int* stack = (int*)c->rb.ki;        /* DFS stack / BFS queue (len ints fit: keyidx_t is 16 bytes) */
@@ -744,7 +744,7 @@ int pa_nd_order(int n, const int* rp, const int* ci, int leaf_rows, pa_nd_tree_t
   c.vorder = (int*)malloc((size_t)g.n * sizeof(int));
   int* list = (int*)malloc((size_t)g.n * sizeof(int));
   int rc = rb_alloc(&c.rb, &g, NULL) || !c.vorder || !list;
-  { const char* e = getenv("PREALPS_ND_SMOOTH"); c.rb.smooth = e ? atoi(e) : 30; }
+  c.rb.smooth = 30;
   if (!rc) {
     /* connected components are independent trees: handled by the bisection itself (a cut that
      * separates components has an empty separator) */
@@ -795,9 +795,8 @@ int preAlps_hip_partition_kway(int N, const int* rowPtr, const int* colInd, int 
   if (!cid) return PA_FAIL("out of host memory");
   graph_t g;
   memset(&g, 0, sizeof(g));
-  const char* me = getenv("PREALPS_PARTITION_MERGE");
-  int merge = me ? atoi(me) : 1;
-  const int trace = getenv("PREALPS_PARTITION_TRACE") != NULL;
+  int merge = 1;       /* rows with identical column lists (the dofs of a node) become one weighted vertex */
+  const int trace = getenv("PREALPS_SETUP_TRACE") != NULL;
   double t0 = pa_wtime();
   int rc = build_graph(N, rowPtr, colInd, merge, cid, &g);
   if (!rc && merge && g.n < 4 * (long long)nparts && g.n < N) {   /* too few merged vertices per part: plain rows */

@@ -64,7 +64,7 @@ __device__ __forceinline__ void spmm_fma_row(double (&acc)[TS], double v, const 
   }
 }
 
-template <int TS, bool NT, bool GRAM>
+template <int TS, bool GRAM>
 __device__ __forceinline__ void spmm_body(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -102,9 +102,10 @@ __device__ __forceinline__ void spmm_body(
     for (int c = 0; c < TS; ++c) acc[c] = 0.0;
 #pragma unroll 4
     for (int k = 0; k < len; ++k) {
-      // the matrix is streamed once: keep it out of the way of the X rows in L2
-      const double v = NT ? __builtin_nontemporal_load(vp + (size_t)k * 64) : vp[(size_t)k * 64];
-      const int cidx = NT ? __builtin_nontemporal_load(cp + (size_t)k * 64) : cp[(size_t)k * 64];
+      // (nontemporal loads of the matrix stream measured 30 % slower in round 1: the stream is partly served
+      // by the Infinity Cache)
+      const double v = vp[(size_t)k * 64];
+      const int cidx = cp[(size_t)k * 64];
       const unsigned wi = (unsigned)(cidx - w0);
       if (wi < (unsigned)wlen) spmm_fma_row<TS>(acc, v, sx + (size_t)wi * TS);
       else if (cidx < m) spmm_fma_row<TS>(acc, v, X + (size_t)cidx * TS);
@@ -123,7 +124,7 @@ __device__ __forceinline__ void spmm_body(
   if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
 }
 
-template <int TS, bool NT>
+template <int TS>
 __global__ __launch_bounds__(WG) void k_spmm(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(WG) void k_spmm(
     const int* __restrict__ blk_slice, const int* __restrict__ blk_win,
     const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
     const double* __restrict__ Xh, double* __restrict__ Y) {
-  spmm_body<TS, NT, false>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
+  spmm_body<TS, false>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
                            X, Xh, Y, nullptr, nullptr, 0);
 }
 
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(WG) void k_spmm_gram(
     const int* __restrict__ order, int nlist, int win_cap, const double* __restrict__ X,
     const double* __restrict__ Xh, double* __restrict__ Y,
     const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
-  spmm_body<4, false, true>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
+  spmm_body<4, true>(m, sl_off, sl_len, sl_row0, sl_nrows, col, val, blk_slice, blk_win, order, nlist, win_cap,
                             X, Xh, Y, Rg, gpart, gbase);
 }
 
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(WG) void k_spmm_staged(
 // bookkeeping join two histories at the next use, and the join waits for everything in flight); a run
 // beyond the slice's last one takes that one's slot and its values from a block of zeros -- the choice is
 // between two scalar addresses, the vector code is the same for every group.
+constexpr int RU = 3;     // runs per group: 12 loads; 1, 2 and 4 measured the same (profiles/r04_spmm_variants_ab.txt)
 __device__ const double g_zero_run[192] = {0.0};
-template <int RU>
 __device__ __forceinline__ void spmm_runs_load(const unsigned short* __restrict__ cp, const double* __restrict__ vp,
                                                unsigned lane, int g, int len, int (&sl)[RU], double (&vv)[3 * RU]) {
   // cp / vp: the slice's slots and values, wavefront-uniform; the run index is uniform too, so every address
@@ -243,7 +244,7 @@ __device__ __forceinline__ void spmm_runs_load(const unsigned short* __restrict_
     vv[3 * j + 2] = vk[128 + lane];
   }
 }
-template <int TS, int RU>
+template <int TS>
 __device__ __forceinline__ void spmm_runs_fma(const double* sx, const int (&sl)[RU], const double (&vv)[3 * RU],
                                               double (&acc)[TS]) {
 #pragma unroll
@@ -255,7 +256,7 @@ __device__ __forceinline__ void spmm_runs_fma(const double* sx, const int (&sl)[
   }
 }
 
-template <int TS, int XS, bool GRAM, int RU, int DBG>
+template <int TS, int XS, bool GRAM>
 __device__ __forceinline__ void spmm_runs_block(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -266,7 +267,7 @@ __device__ __forceinline__ void spmm_runs_block(
     const double* __restrict__ Xh, double* __restrict__ Y,
     const double* __restrict__ Rg, double* __restrict__ gpart, int gbase, int logical, int coff);
 
-template <int TS, int XS, bool GRAM, int RU = 3, int DBG = 0>
+template <int TS, int XS, bool GRAM>
 __device__ __forceinline__ void spmm_runs_body(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -281,12 +282,12 @@ __device__ __forceinline__ void spmm_runs_body(
   const int idx = blockIdx.x >> 3;
   const int logical = (blockIdx.x & 7) * cpx + idx / NS;
   if (logical >= nlist) return;
-  spmm_runs_block<TS, XS, GRAM, RU, DBG>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+  spmm_runs_block<TS, XS, GRAM>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
                                          ext_rows, order, X, Xh, Y, Rg, gpart, gbase, logical, (idx % NS) * TS);
 }
 
 // One block of slices: `logical` = its place in the launch's list, `coff` = first of the TS columns.
-template <int TS, int XS, bool GRAM, int RU, int DBG>
+template <int TS, int XS, bool GRAM>
 __device__ __forceinline__ void spmm_runs_block(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -322,13 +323,13 @@ __device__ __forceinline__ void spmm_runs_block(
     len = sl_len[s];
     cp = slot16 + off;
     vp = val + 3 * off;
-    if (len > 0) spmm_runs_load<RU>(cp, vp, lane, 0, len, slA, vA);
+    if (len > 0) spmm_runs_load(cp, vp, lane, 0, len, slA, vA);
   }
 
   // Staging: LDS row L of [external rows below | own rows | external rows above] comes from global row
   // id(L); H lanes per row, WG / H rows per pass, SB passes in flight at a time: all ids, then all rows,
   // then the LDS stores -- two memory latencies per batch instead of two per pass.
-  if constexpr (!(DBG & 1)) {
+  {
     constexpr int RPP = WG / H, SB = 8;
     double2* dst = reinterpret_cast<double2*>(sx);
     const int j = tid % H, l0 = tid / H, nst = nown + next;
@@ -370,36 +371,19 @@ __device__ __forceinline__ void spmm_runs_block(
       // (one exit at the bottom and the odd group behind the loop: with an exit in the middle the register
       // allocator copies the set that is in flight at the end of every round, behind a full wait)
       for (int i = 0; i < (ngt >> 1); ++i) {
-        spmm_runs_load<RU>(cp, vp, lane, 2 * i + 1, len, slB, vB);
+        spmm_runs_load(cp, vp, lane, 2 * i + 1, len, slB, vB);
         __builtin_amdgcn_sched_barrier(0);      // (keeps the requests in front of the sums of the group before)
-        spmm_runs_fma<TS, RU>(sx, slA, vA, acc);
+        spmm_runs_fma<TS>(sx, slA, vA, acc);
         __builtin_amdgcn_sched_barrier(0);
-        spmm_runs_load<RU>(cp, vp, lane, min(2 * i + 2, ngt - 1), len, slA, vA);
+        spmm_runs_load(cp, vp, lane, min(2 * i + 2, ngt - 1), len, slA, vA);
         __builtin_amdgcn_sched_barrier(0);
-        spmm_runs_fma<TS, RU>(sx, slB, vB, acc);
+        spmm_runs_fma<TS>(sx, slB, vB, acc);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (ngt & 1) spmm_runs_fma<TS, RU>(sx, slA, vA, acc);
+      if (ngt & 1) spmm_runs_fma<TS>(sx, slA, vA, acc);
     }
     const int nr = sl_nrows[s], row_s = sl_row0[s];
-    if constexpr (DBG & 4) {          // DEV: the bytes of the store as whole lines (wrong values)
-      double2* q = reinterpret_cast<double2*>(Y + (size_t)row_s * XS);
-      if (lane < 2 * nr) q[lane] = make_double2(acc[0], acc[1]);
-      if (lane + 64 < 2 * nr) q[64 + lane] = make_double2(acc[2], acc[3]);
-    } else if constexpr (DBG & 16) {  // DEV: every store into one 2 MB region (stays in the L2)
-      if (lane < nr) {
-        double2* q = reinterpret_cast<double2*>(Y + (size_t)((row_s + lane) & 0xFFFF) * XS + coff);
-#pragma unroll
-        for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
-      }
-    } else if constexpr (DBG & 8) {   // DEV: nontemporal
-      if (lane < nr) {
-        double* q = Y + (size_t)(row_s + lane) * XS + coff;
-#pragma unroll
-        for (int i = 0; i < TS; ++i) __builtin_nontemporal_store(acc[i], q + i);
-      }
-    } else
-    if (lane < ((DBG & 2) ? (acc[0] == 1.2345 ? nr : 0) : nr)) {
+    if (lane < nr) {
       double2* q = reinterpret_cast<double2*>(Y + (size_t)(row_s + lane) * XS + coff);
 #pragma unroll
       for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
@@ -415,7 +399,7 @@ __device__ __forceinline__ void spmm_runs_block(
       len = sl_len[sn];
       cp = slot16 + off;
       vp = val + 3 * off;
-      if (len > 0) spmm_runs_load<RU>(cp, vp, lane, 0, len, slA, vA);
+      if (len > 0) spmm_runs_load(cp, vp, lane, 0, len, slA, vA);
     }
   }
   if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
@@ -435,134 +419,6 @@ __global__ __launch_bounds__(WG, (TS <= 4 ? 5 : 3)) void k_spmm_runs(
   spmm_runs_body<TS, XS, false>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
                                 ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
 }
-
-// TEMPORARY dev variants (PREALPS_SPMM_OLD = 2 + index)
-template <int RU, int DBG>
-__global__ __launch_bounds__(WG, 5) void k_spmm_runs_dev(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
-    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
-    const int* __restrict__ order, int nlist, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y) {
-  spmm_runs_body<4, 4, false, RU, DBG>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
-                                ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
-}
-// DEV: resident workgroups, each walks the blocks i, i + G, ... of its XCD's share
-template <int RU, int DBG>
-__global__ __launch_bounds__(WG, 5) void k_spmm_runs_pers(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
-    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
-    const int* __restrict__ order, int nlist, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y) {
-  const int cpx = (nlist + 7) >> 3, G = gridDim.x >> 3, xcd = blockIdx.x & 7;
-  for (int i = blockIdx.x >> 3; i < cpx; i += G) {
-    const int logical = xcd * cpx + i;
-    if (logical >= nlist) break;
-    if (i != (int)(blockIdx.x >> 3)) __syncthreads();      // every wavefront is done with the staged rows of the block before
-    spmm_runs_block<4, 4, false, RU, DBG>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
-                                          ext_rows, order, X, Xh, Y, nullptr, nullptr, 0, logical, 0);
-  }
-}
-// TEMPORARY (A/B of the round-4 rewrite, PREALPS_SPMM_OLD=1): round 3's kernel
-template <int TS, int XS, bool GRAM>
-__device__ __forceinline__ void spmm_runs_body_old(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
-    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
-    const int* __restrict__ order, int nlist, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y,
-    const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
-  static_assert(!GRAM || (TS == 4 && XS == 4), "the fused Gram block is built for 4-column panels");
-  extern __shared__ double sx[];
-  constexpr int NS = XS / TS;
-  const int cpx = (nlist + 7) >> 3;
-  const int idx = blockIdx.x >> 3;
-  const int logical = (blockIdx.x & 7) * cpx + idx / NS;
-  if (logical >= nlist) return;
-  const int coff = (idx % NS) * TS;
-  const int b = order[logical];
-  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
-  const int r0 = sl_row0[s0];
-  const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
-  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0, nlow = blk_nlow[b];
-  const int tid = threadIdx.x;
-  constexpr int H = TS / 2;  // double2 per staged row
-  {
-    double2* dst = reinterpret_cast<double2*>(sx);
-    for (int q = tid; q < nown * H; q += WG) {
-      const int i = q / H, j = q - i * H;
-      dst[(size_t)(nlow + i) * H + j] = reinterpret_cast<const double2*>(X + (size_t)(r0 + i) * XS + coff)[j];
-    }
-    for (int q = tid; q < next * H; q += WG) {
-      const int i = q / H, j = q - i * H;
-      const int id = ext_rows[e0 + i];
-      const double2* src = reinterpret_cast<const double2*>((id < m ? X + (size_t)id * XS
-                                                                      : Xh + (size_t)(id - m) * XS) + coff);
-      dst[(size_t)(i < nlow ? i : nown + i) * H + j] = src[j];
-    }
-    if (tid < 2 * H) dst[(size_t)(nown + next) * H + tid] = make_double2(0.0, 0.0);
-  }
-  __syncthreads();
-  // (the wavefront's number as a scalar: the slice loop and everything indexed by it stay in SGPRs)
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  double gw = 0.0, gg = 0.0;      // GRAM: D[i][j] of the lane's 4 x 4 block (lane = 16 i + 4 q + j)
-  for (int s = s0 + wave; s < s1; s += WG / 64) {
-    const long long off = sl_off[s];
-    const int len = sl_len[s];
-    const unsigned short* __restrict__ cp = slot16 + off + lane;
-    const double* __restrict__ vp = val + 3 * off + lane;
-    double acc[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-    int touch = 0;
-    if constexpr (GRAM)       // the slice's rows of R on their way into the L2 while the matrix streams
-      touch = reinterpret_cast<const int*>(Rg)[((size_t)sl_row0[s] + min(lane, sl_nrows[s] - 1)) * 8];
-#pragma unroll 4
-    for (int k = 0; k < len; ++k) {
-      const int slot = cp[(size_t)k * 64];
-      const double v0 = vp[(size_t)(3 * k) * 64];
-      const double v1 = vp[(size_t)(3 * k + 1) * 64];
-      const double v2 = vp[(size_t)(3 * k + 2) * 64];
-      const double* __restrict__ xr = sx + (size_t)slot * TS;
-      spmm_fma_row<TS>(acc, v0, xr);
-      spmm_fma_row<TS>(acc, v1, xr + TS);
-      spmm_fma_row<TS>(acc, v2, xr + 2 * TS);
-    }
-    const int nr = sl_nrows[s], row_s = sl_row0[s];
-    if (lane < nr) {
-      double2* q = reinterpret_cast<double2*>(Y + (size_t)(row_s + lane) * XS + coff);
-#pragma unroll
-      for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
-    }
-    if constexpr (GRAM) {
-      asm volatile("" ::"v"(touch));
-      const double* own = sx + (size_t)(nlow + row_s - r0) * 4;
-      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) { return own + (size_t)rr * 4; }, gw, gg);
-    }
-  }
-  if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
-}
-
-template <int TS, int XS>
-__global__ __launch_bounds__(WG) void k_spmm_runs_old(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ slot16, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
-    const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
-    const int* __restrict__ order, int nlist, const double* __restrict__ X,
-    const double* __restrict__ Xh, double* __restrict__ Y) {
-  spmm_runs_body_old<TS, XS, false>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
-                                ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
-}
-
 
 // 4 columns with the Gram block; five wavefronts per SIMD as k_spmm_runs<4, 4> (32 KiB of staging each)
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_spmm_runs_gram(
@@ -618,9 +474,7 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
       int win_cap = pl->win_cap;
       if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
       const size_t ldsw = (size_t)win_cap * TS * 8;
-      static int ntw = -1;
-      if (ntw < 0) { const char* e = getenv("PREALPS_SPMM_NT"); ntw = e ? atoi(e) : 0; }
-      if (ldsw >= 1024 && !ntw) {
+      if (ldsw >= 1024) {
         const int cpx = (nlist + 7) / 8;
         PA_LAUNCH(k_spmm_gram, dim3(cpx * 8), dim3(WG), ldsw, cur_stream(), pl->m, pl->sl_off, pl->sl_len,
                   pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice, pl->blk_win, order, nlist, win_cap,
@@ -633,25 +487,7 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
     if (g_sg.armed && X == g_sg.X && Y == g_sg.Y) g_sg.count = -1;    // this product leaves no Gram block
   }
   if (pl->runs) {
-    // a plan cut for half the panel stride: two workgroups per block, 8 of the 16 columns each;
-    // for the whole stride (pl->runs_cols == TS): one workgroup, the matrix is streamed once
-    if constexpr (TS >= 16) {
-      if (pl->runs_cols == TS) {
-        const size_t lds = (size_t)pl->stage_cap * TS * 8;
-        static size_t configured = 0;
-        if (lds > 64 * 1024 && lds > configured) {
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TS, TS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return kfail("hipFuncSetAttribute(k_spmm_runs)");
-          configured = lds;
-        }
-        const int cpx = (nlist + 7) / 8;
-        PA_LAUNCH((k_spmm_runs<TS, TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                  pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
-                  pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
-        return kfail("k_spmm_runs");
-      }
-    }
+    // a plan cut for half the panel stride (16 columns): two workgroups per block, 8 of the 16 columns each
     constexpr int TC = TS >= 16 ? TS / 2 : TS;
     const int ns = TS / TC;
     const size_t lds = (size_t)pl->stage_cap * TC * 8;
@@ -663,43 +499,6 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
       configured = lds;
     }
     const int cpx = (nlist + 7) / 8;
-    static int old_k = -1;
-    if (old_k < 0) { const char* e = getenv("PREALPS_SPMM_OLD"); old_k = e ? atoi(e) : 0; }
-    { const char* e = getenv("PREALPS_SPMM_OLD"); if (e) old_k = atoi(e); }
-    if constexpr (TS == 4) {
-      if (old_k >= 2) {
-#define DEVK(R, D) PA_LAUNCH((k_spmm_runs_dev<R, D>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off, \
-                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice, \
-                       pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y)
-        switch (old_k) {
-          case 2: DEVK(3, 1); break;      // no staging
-          case 3: DEVK(3, 2); break;      // no store
-          case 4: DEVK(3, 3); break;      // neither
-          case 5: DEVK(2, 0); break;
-          case 6: DEVK(4, 0); break;
-          case 8: DEVK(3, 4); break;
-          case 9: DEVK(3, 8); break;
-          case 10: DEVK(3, 16); break;
-          case 11: case 12: case 13: case 14: {
-            const int per_cu = old_k == 11 ? 5 : old_k == 12 ? 4 : old_k == 13 ? 3 : 10;
-            int g = (pa_rt_num_cus() > 0 ? pa_rt_num_cus() : 256) * per_cu;
-            if (g > cpx * 8) g = cpx * 8;
-            g &= ~7;
-            PA_LAUNCH((k_spmm_runs_pers<3, 0>), dim3(g), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
-                       pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
-          } break;
-          default: DEVK(1, 0); break;
-        }
-        return kfail("k_spmm_runs_dev");
-      }
-    }
-    if (old_k == 1) {
-      PA_LAUNCH((k_spmm_runs_old<TC, TS>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
-                       pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
-      return kfail("k_spmm_runs_old");
-    }
     PA_LAUNCH((k_spmm_runs<TC, TS>), dim3(cpx * 8 * ns), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
                        pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
                        pl->blk_ext_off, pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y);
@@ -725,16 +524,9 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
   if ((size_t)win_cap * TS * 8 > 32 * 1024) win_cap = (32 * 1024) / (TS * 8);
   const size_t lds = (size_t)win_cap * TS * 8;
   const int cpx = (nlist + 7) / 8;
-  static int nt = -1;
-  if (nt < 0) { const char* e = getenv("PREALPS_SPMM_NT"); nt = e ? atoi(e) : 0; }
-  if (nt)
-    PA_LAUNCH((k_spmm<TS, true>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
-                       pl->blk_win, order, nlist, win_cap, X, Xh, Y);
-  else
-    PA_LAUNCH((k_spmm<TS, false>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                       pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
-                       pl->blk_win, order, nlist, win_cap, X, Xh, Y);
+  PA_LAUNCH((k_spmm<TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                     pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col, pl->val, pl->blk_slice,
+                     pl->blk_win, order, nlist, win_cap, X, Xh, Y);
   return kfail("k_spmm");
 }
 

@@ -626,7 +626,7 @@ part2, P2 = gen.box_partition(12, (4, 4, 4))
 rp, ci, v = O.as_csr(A2)
 prob2 = prealps_amd.EcgProblem(rp, ci, v, P2, part2, scale=True, device=0)
 B2, perm2, rowpos2 = O.permute_by_part(O.symrac_scale(A2), part2, P2)
-for t in (2, 4, 8, 16):      # (8 and 16: the matrix-core kernels, or -- PREALPS_BJ_SPLIT -- column groups of 4 on the paired records)
+for t in (2, 4, 8, 16):      # (8 and 16: the matrix-core kernels, or -- PREALPS_BJ_MFMA=0 -- the register recurrence)
     X = np.random.default_rng(t).standard_normal((B2.shape[0], t))
     zr = O.BlockJacobi(B2, rowpos2).apply(X)
     np.testing.assert_allclose(prob2.block_jacobi_apply(X, t), zr, rtol=1e-9, atol=1e-10 * np.abs(zr).max())
@@ -634,17 +634,17 @@ print("variant ok", prob.stat("spmm_staged"), prob.stat("bj_max_bandwidth"), pro
 """
 
 
-@pytest.mark.parametrize("env", [{"PREALPS_SPMM_NT": "1", "PREALPS_SPMM_STAGED": "0"},
-                                 {"PREALPS_BJ_SPLIT": "1", "PREALPS_BJ_MFMA": "0", "PREALPS_BJ_WIDE_FROM": "448"},
+@pytest.mark.parametrize("env", [{"PREALPS_SPMM_STAGED": "0"},
+                                 {"PREALPS_BJ_MFMA": "0", "PREALPS_BJ_WIDE_FROM": "448"},
                                  {"PREALPS_BJ_MFMA": "2", "PREALPS_BJ_WIDE_FROM": "448", "PREALPS_TRSM_MFMA": "0"},
-                                 {"PREALPS_BJ_SPLIT4": "0", "PREALPS_ECG_FUSE": "0"},
+                                 {"PREALPS_ECG_FUSE": "0"},
                                  {"PREALPS_BJ_PAIRS": "0"},
                                  {"PREALPS_ECG_POLL": "1", "PREALPS_SPMM_GRAM": "1"},
                                  {"PREALPS_ECG_LAZY_STOP": "0"}])
 def test_opt_in_kernel_variants(env):
-    """Non-temporal SpMM loads (k_spmm<TS,true>), the column-split block solve (PREALPS_BJ_SPLIT),
-    the matrix-core block solve at every width, the unsplit 4-column sweep, the four-pass first
-    half, the narrow-band sweep on plain instead of paired records, and the host polling for the residual norm
+    """The window SpMM kernel on a matrix that would get the staged plan, the register recurrence of the
+    block solve at 8 and 16 columns (PREALPS_BJ_MFMA=0), the matrix-core block solve at every width, the four-pass
+    first half, the narrow-band sweep on plain instead of paired records, and the host polling for the residual norm
     (the default of multi-process runs) in one process, and the stopping test right after the update
     (PREALPS_ECG_LAZY_STOP=0) instead of one half-step later: same answers as the oracle
     (Poisson 16^3, 16 slabs, band 256 -> register-set class 5; Poisson 12^3 in 27 boxes, class 2)."""
@@ -768,7 +768,12 @@ for shard in (None, (0, 3)):
         ref = O.ECG(Bs, rps, 4, O.ORTHODIR, O.NO_BS_RED, 1e-5, 400).solve(rhs)
         assert len(hist) == ref["iters"], (len(hist), ref["iters"])
         np.testing.assert_allclose(hist[:20], ref["res"][:20], rtol=1e-8)
-        assert prob.stat("spmm_gram_launches") == g0 and prob.stat("bj_gram_applies") == b0
+        if os.environ.get("PREALPS_RCI_FUSE") == "1" and on:
+            # the caller has promised to call nothing but the library's two routines between the solver's steps
+            # (INTEGRATION.md section 1): the same blocks as in the library's own loops, the same residuals
+            assert prob.stat("spmm_gram_launches") - g0 >= len(hist) - 1 and prob.stat("bj_gram_applies") - b0 >= len(hist) - 2
+        else:
+            assert prob.stat("spmm_gram_launches") == g0 and prob.stat("bj_gram_applies") == b0
     assert (prob.stat("spmm_gram_launches") - before >= 16) if on else (prob.stat("spmm_gram_launches") == before)
     # the block solve leaves beta = [AP | AP_prev]^T Z behind in the Orthodir solve (every block in one bj_g4 class)
     assert (prob.stat("bj_gram_applies") - before_bj >= 8) if on else (prob.stat("bj_gram_applies") == before_bj)
@@ -777,15 +782,17 @@ print("spmm gram ok")
 """
 
 
-@pytest.mark.parametrize("on", ["1", "0"])
+@pytest.mark.parametrize("on", ["1", "0", "1+rci"])
 def test_spmm_and_block_solve_leave_the_gram_blocks_behind(on):
     """The defaults at 4 columns: k_spmm_runs_gram forms [AP | R]^T P while it computes AP (one partial block per
     workgroup) and k_bj_g4 forms [AP | AP_prev]^T Z while Z is in its registers (one per subdomain), k_finish32
     sums them: Orthodir and Orthomin, in one process and in the one-shard rehearsal, where the interior and the
     halo-reading halves of the SpMM each leave their share.  "0": both switched off (PREALPS_SPMM_GRAM,
     PREALPS_BJ_GRAM), the separate Gram kernels give the same answers."""
-    r = subprocess.run([sys.executable, "-c", _SPMM_GRAM_SNIPPET % ROOT], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, PREALPS_SPMM_GRAM=on, PREALPS_BJ_GRAM=on))
+    env = dict(os.environ, PREALPS_SPMM_GRAM=on[0], PREALPS_BJ_GRAM=on[0])
+    if on == "1+rci":        # PREALPS_RCI_FUSE=1: the same hand-over for a caller that drives the RCI loop itself
+        env["PREALPS_RCI_FUSE"] = "1"
+    r = subprocess.run([sys.executable, "-c", _SPMM_GRAM_SNIPPET % ROOT], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "spmm gram ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
 
 

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MPIEXEC = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
 MPI_INC, MPI_LIB = "/opt/conda/include", "/opt/conda/lib"
 have_mpi = os.path.exists(MPIEXEC) and os.path.exists(os.path.join(MPI_INC, "mpi.h"))
-REF_BIN = os.path.join(ROOT, "oracle", "_ref", "test_ecg_prealps_op_mpi")
+REF_BIN = os.path.join(ROOT, "tests", "_build", "test_ecg_prealps_op_mpi")
 
 
 def _problem(n, nparts):
@@ -157,7 +157,7 @@ def test_rccl_binding_three_ranks_one_gpu_through_a_stand_in(tmp_path, alg):
 @pytest.mark.skipif(not (have_mpi and os.path.exists(REF_BIN)), reason="needs MPI and the prebuilt reference driver (oracle/Makefile)")
 def test_unmodified_reference_driver_two_ranks_one_gpu(tmp_path):
     """The reference's examples/test_ecg_prealps_op.c, compiled unchanged where the reference tree
-    was present (oracle/_ref/, built by oracle/Makefile) and started with two ranks on this GPU."""
+    was present (tests/_build/, built by oracle/Makefile) and started with two ranks on this GPU."""
     from oracle import oracle as O
     n, nparts, world, t = 12, 8, 2, 4
     (rp, ci, v), B, perm, rowpos = _problem(n, nparts)

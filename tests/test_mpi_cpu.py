@@ -183,3 +183,37 @@ print("rc", rc, L.preAlps_hip_last_error().decode()[:60])
     r = subprocess.run([os.sys.executable, "-c", code], env=dict(os.environ, OMPI_COMM_WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.startswith("rc 1 ") and "Open MPI" in r.stdout, r.stdout
+
+
+@pytest.mark.skipif(not have_mpi, reason="no MPI launcher in this image")
+def test_prealps_mpi_off_leaves_the_process_group_to_the_caller(tmp_path):
+    """PREALPS_MPI=0: the library never looks for an MPI -- for a caller that starts its ranks with an MPI launcher
+    but describes the process group itself (preAlps_hip_set_world / set_comm).  Under mpiexec -n 2 and without
+    such a description every rank is then a process group of one and holds all the rows."""
+    n = 6
+    rp, ci, v = gen.poisson3d_csr(n)
+    mtx = str(tmp_path / "a.mtx")
+    write_mtx(mtx, rp, ci, v)
+    exe = str(tmp_path / "mpi_plan_dump")
+    _cc(os.path.join(ROOT, "tests", "c", "mpi_plan_dump.c"), exe)
+    env = dict(os.environ, PREALPS_NPARTS="4", OMP_NUM_THREADS="2", PREALPS_MPI="0")
+    r = subprocess.run([MPIEXEC, "-n", "2", exe, mtx, str(tmp_path / "dump")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for rank in range(2):
+        head = _read_dump(str(tmp_path / "dump") + ".%d" % rank)[0]
+        assert head[2] == head[3] == n ** 3            # M == m: the whole matrix
+
+
+def test_partition_file_is_taken_as_it_is(tmp_path):
+    """PREALPS_PARTITION_FILE (one part id per line, e.g. METIS output -- the reference calls METIS_PartGraphKway
+    at utils/cplm_core/cplm_matcsr_core.c:394-457): preAlps_OperatorBuild orders the rows by exactly those parts."""
+    n, nparts = 6, 5
+    rp, ci, v = gen.poisson3d_csr(n)
+    mtx = str(tmp_path / "a.mtx")
+    write_mtx(mtx, rp, ci, v)
+    part = (np.arange(n ** 3) * 7 + 3) % nparts                      # nothing a partitioner would produce
+    pf = str(tmp_path / "parts.txt")
+    np.savetxt(pf, part, fmt="%d")
+    ref = _replicated(mtx, 0, 1, dict(os.environ, PREALPS_NPARTS=str(nparts), PREALPS_PARTITION_FILE=pf, OMP_NUM_THREADS="2"))
+    np.testing.assert_array_equal(np.diff(ref["rowPos"]), np.bincount(part, minlength=nparts))
+    np.testing.assert_array_equal(part[ref["perm"]], np.repeat(np.arange(nparts), np.bincount(part, minlength=nparts)))

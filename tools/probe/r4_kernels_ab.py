@@ -2,7 +2,8 @@
 """Round-4 kernel timings in ONE process (the only comparison the process-to-process spread allows): the
 SpMM and the block solve of the headline problem in the solver's cache state (each timed launch behind the
 other kernel), the block solve plain and with the Gram block armed (pa_k_bj_gram_arm, what the solver's
-launch does), then 800-iteration solves.  HIP events on the library stream.
+launch does), then 800-iteration solves.  HIP events on the library stream.  (The commit "SpMM: batched X staging ..."
+of round 4 still carried the round-3 SpMM behind a dev switch: profiles/r04_spmm_variants_ab.txt was taken there.)
 usage: r4_kernels_ab.py [rounds]   (R4_AB_WORKLOAD=poisson: BASELINE configs[1]; R4_AB_T=8: eight columns)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -51,21 +52,14 @@ def bj_gram():
     check(L.preAlps_BlockJacobiApply(C.byref(dx), C.byref(dz)), "bj")
 
 for rnd in range(rounds):
-    out = []
-    for old in ("0", "1"):
-        os.environ["PREALPS_SPMM_OLD"] = old
-        out.append(timed(spmm, bj))
-    os.environ.pop("PREALPS_SPMM_OLD")
+    sp_ = timed(spmm, bj)
     a = timed(bj, spmm)
     b = timed(bj_gram, spmm) if (t == 4 and cap > 0) else float("nan")
-    print("round %d: SpMM %.1f us (round-3 kernel %.1f) | block solve %.1f us, with the Gram block %.1f" % (rnd, out[0], out[1], a, b), flush=True)
+    print("round %d: SpMM %.1f us | block solve %.1f us, with the Gram block %.1f" % (rnd, sp_, a, b), flush=True)
 
 rhs = prob.reference_rhs()
 prob.solve(rhs, t, tol=1e-30, max_iter=50)
 for rnd in range(rounds):
-    for old in ("0", "1"):
-        os.environ["PREALPS_SPMM_OLD"] = old
-        r = prob.solve(rhs, t, tol=1e-30, max_iter=800)
-        print("solve, SpMM %s: %d iterations, %.1f us per iteration" % ("round 3" if old == "1" else "new    ", r.iters, 1e6 * r.seconds / r.iters), flush=True)
-os.environ.pop("PREALPS_SPMM_OLD")
+    r = prob.solve(rhs, t, tol=1e-30, max_iter=800)
+    print("solve: %d iterations, %.1f us per iteration" % (r.iters, 1e6 * r.seconds / r.iters), flush=True)
 prob.close()
