@@ -172,6 +172,69 @@ class MklEcg:
         return dict(x=X.sum(axis=1), iters=it, res=np.array(res_hist), normb=normb, t_total=total,
                     t_op=tm["op"], t_prec=tm["prec"], t_dense=tm["dense"], threads=self.threads)
 
+    def solve_dodir(self, rhs):
+        """Orthodir with the dynamic reduction of the search directions (-o 0 -r 1: src/solvers/ecg.c:445-497 of the
+        reference, restated in oracle/ecg_oracle.c: odir_reduce / iterate_odir) on this path's kernels -- mkl_dcsrmm,
+        PARDISO and LAPACK through numpy instead of the oracle's own loops.  A CONTROL, not an oracle: a second
+        fp64 implementation of the same recurrence, to see how far two CPU paths drift apart in WHEN the
+        reduction fires (tools/history_control.py --dodir).  Same memory layout as the reference: V = [T current
+        slots | T previous slots], the rotated-away columns stay in the basis for one more step."""
+        n, T = self.n, self.t
+        normb = float(np.sqrt(sum(np.sum(rhs[self.rowpos[p]:self.rowpos[p + 1]] ** 2)
+                                  for p in range(len(self.rowpos) - 1))))
+        R = np.zeros((n, T), order="F")
+        for p in range(len(self.rowpos) - 1):
+            R[self.rowpos[p]:self.rowpos[p + 1], p % T] = rhs[self.rowpos[p]:self.rowpos[p + 1]]
+        X = np.zeros((n, T), order="F")
+        V = np.zeros((n, 2 * T), order="F")
+        AV = np.zeros((n, 2 * T), order="F")
+        t, kbs = T, 2 * T
+        V[:, :T] = self.precond(R)
+        AV[:, :T] = self.spmm(np.asfortranarray(V[:, :T]))
+        thresh = self.tol * normb / np.sqrt(float(T))
+        res_hist, bs_hist, it = [], [], 0
+        while True:
+            P, AP = V[:, :t], AV[:, :t]
+            W = AP.T @ P
+            try:
+                U = sla.cholesky(W, lower=False, check_finite=False)
+            except np.linalg.LinAlgError:
+                break
+            P[:] = sla.solve_triangular(U, P.T, trans="T", lower=False, check_finite=False).T
+            AP[:] = sla.solve_triangular(U, AP.T, trans="T", lower=False, check_finite=False).T
+            alpha = P.T @ R                                   # t x T
+            Us, sig, _ = np.linalg.svd(alpha, full_matrices=True)
+            t1 = 0
+            for sv in sig[:t]:
+                if sv > thresh:
+                    t1 += 1
+                else:
+                    break
+            if 0 < t1 < T and t1 < t:
+                Q, _ = np.linalg.qr(Us[:, :t])                # Householder Q of the left singular vectors
+                alpha = (Q.T @ alpha)[:t1]
+                P[:] = P @ Q
+                AP[:] = AP @ Q
+                kbs = t + T
+                t = t1
+            nb = t1 if t1 > 0 else t
+            X += V[:, :t] @ alpha[:t]
+            R -= AV[:, :t] @ alpha[:t]
+            it += 1
+            res = float(np.sqrt(np.sum(R * R)))
+            res_hist.append(res)
+            bs_hist.append(t)
+            if not (res > normb * self.tol and it < self.max_iter and t > 0):
+                break
+            Z = self.precond(np.asfortranarray(AV[:, :t]))
+            beta = AV[:, :kbs].T @ Z[:, :nb]
+            Z[:, :nb] -= V[:, :kbs] @ beta
+            V[:, T:T + t] = V[:, :t]
+            AV[:, T:T + t] = AV[:, :t]
+            V[:, :t] = Z[:, :t]
+            AV[:, :t] = self.spmm(np.asfortranarray(V[:, :t]))
+        return dict(x=X.sum(axis=1), iters=it, res=np.array(res_hist), bs=np.array(bs_hist), normb=normb)
+
     def __del__(self):
         try:
             self._pardiso(-1, None, None)

@@ -365,50 +365,76 @@ __device__ __forceinline__ void finish_sum(const double* partials, int nblk, int
   }
 }
 
+// The lanes of ONE wavefront see each other's LDS stores once both of these have been passed (DS operations of
+// a wavefront execute in order; this keeps the compiler from moving them and drains the counter).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // In-place upper Cholesky of the t x t column-major W in LDS (LAPACK dpotf2 'U': on failure
 // the failing pivot is stored and the rest of W is left untouched), called by a whole
-// workgroup.  One wavefront: columns one after the other, the entries of a column in parallel;
-// larger workgroups (where a barrier costs more than a 8 x 8 factorisation): one thread.
-// Both orders perform the same operations per entry, so the factor is bitwise the same.
+// workgroup; t <= 16.  The first wavefront does the work, right looking: pivot j, row j of U in
+// parallel over the lanes, then the rank-1 update of the trailing triangle, t^2 / 64 entries per lane --
+// three LDS round trips per pivot instead of the t^3 / 3 dependent LDS reads of one thread walking
+// dpotf2's loops (21 us per iteration at 8 columns, round 3).  Every entry sees the same operations in
+// the same order as in dpotf2 (the terms u_kj u_ki are taken off one k after the other, then one
+// division), so the factor is bitwise the same; a pivot that is not positive -- rare, and by then the
+// trailing entries are no longer dpotf2's -- sends one thread through dpotf2's own loops on a copy.
 __device__ __forceinline__ void potrf_upper_wg(double* W, int t, int* info) {
-  const int nt = blockDim.x;
-  if (nt <= 64) {
-    __shared__ int s_fail;
-    if (threadIdx.x == 0) s_fail = 0;
-    __syncthreads();
-    for (int j = 0; j < t; ++j) {
-      if (threadIdx.x == 0 && s_fail == 0) {
-        double d = W[j + t * j];
-        for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
-        if (!(d > 0.0)) { W[j + t * j] = d; s_fail = j + 1; }
-        else W[j + t * j] = sqrt(d);
-      }
-      __syncthreads();
-      if (s_fail) break;
-      const int i = j + 1 + threadIdx.x;
-      if (i < t) {
-        double sv = W[j + t * i];
-        for (int k = 0; k < j; ++k) sv -= W[k + t * j] * W[k + t * i];
-        W[j + t * i] = sv / W[j + t * j];
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0 && info) *info = s_fail;
-  } else if (threadIdx.x == 0) {
+  __shared__ double keep[256];
+  __shared__ int s_fail;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    for (int e = lane; e < t * t; e += 64) keep[e] = W[e];
     int fail = 0;
+    // the lane's (up to four) entries of the upper triangle: row / column worked out once (a division by the
+    // run-time t costs more than a pivot step)
+    int er[4], ec[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane + 64 * q;
+      ec[q] = e / t; er[q] = e - ec[q] * t;
+      if (e >= t * t || er[q] > ec[q]) er[q] = -1;      // (below the diagonal or beyond the block: never touched)
+    }
+    wave_lds_sync();
     for (int j = 0; j < t; ++j) {
       double d = W[j + t * j];
-      for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
-      if (!(d > 0.0)) { W[j + t * j] = d; fail = j + 1; break; }
+      if (!(d > 0.0)) { fail = j + 1; break; }       // (the same value in every lane)
       d = sqrt(d);
-      W[j + t * j] = d;
-      for (int i = j + 1; i < t; ++i) {
-        double s = W[j + t * i];
-        for (int k = 0; k < j; ++k) s -= W[k + t * j] * W[k + t * i];
-        W[j + t * i] = s / d;
-      }
+      double u = 0.0;
+      if (lane > j && lane < t) u = W[j + t * lane] / d;
+      wave_lds_sync();
+      if (lane == j) W[j + t * j] = d;
+      if (lane > j && lane < t) W[j + t * lane] = u;
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (er[q] > j) W[lane + 64 * q] -= W[j + t * er[q]] * W[j + t * ec[q]];
+      wave_lds_sync();
     }
-    if (info) *info = fail;
+    if (fail) {
+      for (int e = lane; e < t * t; e += 64) W[e] = keep[e];
+      wave_lds_sync();
+      if (lane == 0) {
+        fail = 0;
+        for (int j = 0; j < t; ++j) {
+          double d = W[j + t * j];
+          for (int k = 0; k < j; ++k) d -= W[k + t * j] * W[k + t * j];
+          if (!(d > 0.0)) { W[j + t * j] = d; fail = j + 1; break; }
+          d = sqrt(d);
+          W[j + t * j] = d;
+          for (int i = j + 1; i < t; ++i) {
+            double sv = W[j + t * i];
+            for (int k = 0; k < j; ++k) sv -= W[k + t * j] * W[k + t * i];
+            W[j + t * i] = sv / d;
+          }
+        }
+        s_fail = fail;
+      }
+    } else if (lane == 0) s_fail = 0;
+    if (lane == 0 && info) *info = s_fail;
   }
   __syncthreads();
 }
@@ -423,12 +449,26 @@ __device__ __forceinline__ void potrf_alpha_wg(const double* buf, int t, int T, 
   for (int e = threadIdx.x; e < t * T; e += nt) { const int i = e % t, c = e / t; G[e] = buf[(t + c) + ld * i]; }
   __syncthreads();
   potrf_upper_wg(W, t, info);
-  if (threadIdx.x < T) {            // one column of alpha per lane: forward substitution with U^T
-    const int c = threadIdx.x;
+  // forward substitution with U^T on the T columns of G at once, by the first wavefront: row i is divided by
+  // its pivot, then taken off the rows below (t T / 64 entries per lane) -- per entry the operations and the
+  // order of one lane walking its column (g_i - u_0i a_0 - u_1i a_1 ... , then the division)
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int gk[4], gc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane + 64 * q;
+      gc[q] = e / t; gk[q] = e - gc[q] * t;
+      if (e >= t * T) gk[q] = -1;
+    }
     for (int i = 0; i < t; ++i) {
-      double s = G[i + t * c];
-      for (int k = 0; k < i; ++k) s -= W[k + t * i] * G[k + t * c];
-      G[i + t * c] = s / W[i + t * i];
+      const double d = W[i + t * i];
+      if (lane < T) G[i + t * lane] = G[i + t * lane] / d;
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (gk[q] > i) G[lane + 64 * q] -= W[i + t * gk[q]] * G[i + t * gc[q]];
+      wave_lds_sync();
     }
   }
   __syncthreads();

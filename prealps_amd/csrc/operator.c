@@ -1243,13 +1243,13 @@ int pa_operator_gram_blocks(int ts) {
   if (!o->info.built || g_plan_only || ts != 4) return 0;
   if (o->plan_ts != ts && build_plan(o, ts)) return 0;
   if (o->plan.staged && !o->plan.runs) return 0;            /* (the staged plan has no such kernel) */
-  /* Default, from absolute times of 800-iteration solves alternating in one process (tools/probe/abs_ab.py):
-   * the window kernel (k_spmm_gram; Poisson 100^3) 245.3 -> 236.9 us per iteration with the block: on.  The run
-   * kernel (k_spmm_runs_gram; elasticity 70^3): 397.0 -> 399.0 us with it in one process -- its epilogue and
-   * the rows of R cost what k_gram and its sum cost -- so off there; with several processes (small shards,
-   * every launch at its latency floor) it saves a launch, 113 -> 107 us on the one-shard rehearsal: on.
-   * PREALPS_SPMM_GRAM=0 / 1 forces. */
-  int dflt = !o->plan.runs || pa_world_size() > 1;
+  /* Default: on, from absolute times of 800-iteration solves alternating in one process.  The window kernel
+   * (k_spmm_gram; Poisson 100^3): 245.3 -> 236.9 us per iteration with the block (round 3, tools/probe/abs_ab.py).
+   * The run kernel (k_spmm_runs_gram; elasticity 70^3): no gain in round 3 (397.0 -> 399.0 us: its epilogue and
+   * the rows of R cost what k_gram and its sum cost); with round 4's kernel -- the matrix groups double-buffered,
+   * so the epilogue of one wavefront runs beside the stream of the others -- 407.5 -> 398.1 us
+   * (tools/probe/r4_solve_env_ab.py, profiles/r04_spmm_gram_ab.txt).  PREALPS_SPMM_GRAM=0 / 1 forces. */
+  int dflt = 1;
   if (!env_int("PREALPS_SPMM_GRAM", dflt)) return 0;
   return o->plan.nblk;
 }

@@ -487,7 +487,10 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
     if (g_sg.armed && X == g_sg.X && Y == g_sg.Y) g_sg.count = -1;    // this product leaves no Gram block
   }
   if (pl->runs) {
-    // a plan cut for half the panel stride (16 columns): two workgroups per block, 8 of the 16 columns each
+    // a plan cut for half the panel stride (16 columns): two workgroups per block, 8 of the 16 columns each.
+    // (Round 4 measured the alternative the round-3 review proposed -- ONE workgroup that stages and computes
+    // the two halves one after the other, so that the second pass over the block's matrix slice comes from
+    // the caches: 410-414 us against 372-375 us for the two workgroups, same process, profiles/r04_t16_spmm_seq_ab.txt.)
     constexpr int TC = TS >= 16 ? TS / 2 : TS;
     const int ns = TS / TC;
     const size_t lds = (size_t)pl->stage_cap * TC * 8;

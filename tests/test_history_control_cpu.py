@@ -47,3 +47,37 @@ def test_cpu_vs_cpu_drift_matches_the_recorded_gpu_vs_oracle_drift():
     # and the HIP path is not the outlier while the growth is regular: its distance to the oracle stays
     # below 10 x the distance between the two CPU paths
     assert gpu[3] <= 10.0 * max(rel[19], 1e-13) and gpu[4] <= 10.0 * rel[39]
+
+
+def test_two_cpu_paths_reduce_their_directions_at_about_the_same_iterations():
+    """D-Odir (-o 0 -r 1, src/solvers/ecg.c:445-497) at t = 8 on elasticity 30^3: the oracle and the MKL-kernel path
+    start from the same rhs, are 2 % apart in the residual by iteration 100 (the drift above) -- and still drop
+    every direction within two iterations of each other: the reduction rule is robust against that drift at
+    this size.  (At 70^3 the HIP path and the oracle drop their FIRST direction 28 iterations apart and every
+    later one within one iteration, profiles/r03_dodir_fullsize.txt; profiles/r04_dodir_control.txt holds this
+    control at 30^3 and 40^3.)"""
+    from oracle import mkl_path as M
+    if M.load_mkl() is None:
+        pytest.skip("libmkl_rt is not on this host")
+    import history_control as H
+    r = H.dodir_control(30, 8, out=open(os.devnull, "w"))
+    da, db = r["drops"]
+    assert [b for _, b in da] == [b for _, b in db] == [7, 6, 5, 4, 3, 2, 1]
+    assert max(abs(ia - ib) for (ia, _), (ib, _) in zip(da, db)) <= 2
+    assert abs(r["iters"][0] - r["iters"][1]) <= 2
+    assert r["rel"][19] < 1e-9 and r["rel"][99] > 1e-4          # together at the start, apart long before the reductions
+
+
+def test_rank_deficient_end_of_the_eight_column_poisson_case_is_rounding():
+    """tests/test_gpu_configs.py pins the last two residuals of its t = 8 Poisson case (8 directions on 16 slabs
+    lose rank as the solve converges) at 1e-6 instead of 1e-8.  Two CPU paths of the same recurrence are 1e-7
+    apart there and 1e-8 before: the HIP path's 2e-8 (bj_g4) / 5e-9 (k_bj_mfma) at the end is inside what
+    rounding alone does."""
+    from oracle import mkl_path as M
+    if M.load_mkl() is None:
+        pytest.skip("libmkl_rt is not on this host")
+    import history_control as H
+    r = H.tail_control(out=open(os.devnull, "w"))
+    assert r["iters"][0] == r["iters"][1]
+    assert 1e-9 < r["rel"][-2:].max() < 1e-5        # CPU-vs-CPU at the end: well above 1e-8, well inside 1e-6
+    assert r["rel"][:-2].max() < 1e-6
