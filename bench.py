@@ -65,7 +65,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-ROUND = "r03"
+ROUND = "r04"
 
 
 def parse():
@@ -234,9 +234,11 @@ def main():
     run_iterations(prob, e, rhs, L, a.warmup, state)
     barrier()
     dev_s = C.c_double()
+    gram_timed0 = prob.stat("spmm_gram_launches")
     check(L.preAlps_hip_timer_start(), "timer_start")      # hipEvents on the library stream around the same region
     t0 = time.perf_counter()
     run_iterations(prob, e, rhs, L, a.steps, state)
+    solver_forms_gram = prob.stat("spmm_gram_launches") - gram_timed0 >= a.steps - 1
     check(L.preAlps_hip_timer_stop(C.byref(dev_s)), "timer_stop")
     barrier()
     dt = time.perf_counter() - t0
@@ -288,22 +290,18 @@ def main():
         check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
         tot += sec.value
     spmm_s = tot / a.spmm_reps
-    # the product P -> AP of the solver also leaves the Gram block [AP | R]^T P behind (k_spmm_runs_gram, the
-    # default at t = 4): it reads the m x t rows of R on top of the product's bytes; the plain product
-    # (k_spmm_runs, other panels) is timed next to it for comparison
-    with_gram = prob.stat("spmm_gram_launches") > gram0
+    # The product P -> AP of the solver also leaves the Gram block [AP | R]^T P behind (k_spmm_runs_gram, the
+    # default at t = 4): it reads the m x t rows of R on top of the product's bytes.  The request is made by the
+    # solver's own loop (preAlps_ECGIterate), so the stand-alone launches above are the PLAIN product; the
+    # solver's launch is timed where it happens -- the hipEvent pair of the library's `operator` phase, one pair
+    # per iteration of the phase-by-phase pass, same stream, same cache state by construction.
+    with_gram = bool(solver_forms_gram) and phases.get("operator", 0.0) > 0.0 and a.phase_iters > 0
     plain_s = None
     dx, dy = prob.panel(a.t, a.t), prob.panel(a.t, a.t)
     prob.to_device(dx, np.random.default_rng(1).standard_normal((m_loc, a.t)), a.t)
     if with_gram:
-        tot = 0.0
-        for _ in range(a.spmm_reps):
-            check(L.preAlps_BlockJacobiApply(e.AP, e.Z), "BlockJacobiApply")
-            check(L.preAlps_hip_timer_start(), "timer_start")
-            check(L.preAlps_BlockOperator(C.byref(dx), C.byref(dy)), "BlockOperator")
-            check(L.preAlps_hip_timer_stop(C.byref(sec)), "timer_stop")
-            tot += sec.value
-        plain_s = tot / a.spmm_reps
+        plain_s = spmm_s
+        spmm_s = phases["operator"] / a.phase_iters
     # (b) back to back (matrix partly resident in the Infinity Cache): reported for comparison only
     check(L.preAlps_hip_timer_start(), "timer_start")
     for _ in range(a.spmm_reps):
@@ -343,7 +341,7 @@ def main():
                 ("poisson", 100, 4, "5,5,10"): "pmc_hbm_traffic_poisson.json"}
     pmc = profiled.get((a.workload, a.n, a.t, a.box)) if a.nparts == 0 else None
     if world == 1 and pmc:
-        for rnd in (ROUND, "r01"):
+        for rnd in (ROUND, "r03", "r01"):
             path = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, pmc))
             if os.path.exists(path):
                 with open(path) as f:
@@ -377,13 +375,19 @@ def main():
                      "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s,
                      "back_to_back_launch_us": 1e6 * spmm_b2b_s,
                      "measured_copy_ceiling_GBs": copy_gbs.value, "measured_read_ceiling_GBs": read_gbs.value,
-                     "frac_of_measured_read_ceiling": spmm_gbs / read_gbs.value,
+                     # what the kernel really moves (PMC traffic of the committed profile) over this launch's time, against
+                     # what a plain read kernel streams on this very device: the honest distance to the ceiling.  (The
+                     # algorithmic bytes count 12 B per nonzero where the kernel reads 8.67, so they may exceed it.)
+                     "traffic_GBs": None if traffic is None else traffic / spmm_s / 1e9,
+                     "traffic_frac_of_measured_read_ceiling": None if traffic is None else traffic / spmm_s / 1e9 / read_gbs.value,
+                     "algorithmic_over_measured_read_ceiling": spmm_gbs / read_gbs.value,
                      "plain_product": None if plain_s is None else {
                          "kernel": "k_spmm_runs", "avg_launch_us": 1e6 * plain_s, "algorithmic_bytes_per_launch": plain_bytes,
                          "achieved": plain_bytes / plain_s / 1e9, "frac": plain_bytes / plain_s / 1e9 / HBM_PEAK_GBS,
-                         "note": "the same product on other panels, without the Gram block (what rounds 1-2 reported)"},
-                     "note": "each timed launch follows one preconditioner apply (cache state of the solver loop)"
-                             + ("; the solver's product also forms [AP | R]^T P (rows of R counted in the bytes)" if with_gram else "")},
+                         "note": "the same product without the Gram block, stand-alone launches behind one block solve each (what rounds 1-2 reported)"},
+                     "note": ("the solver's own launches: hipEvent pair of the `operator` phase, one per iteration of the phase-by-phase pass; "
+                              "the product also forms [AP | R]^T P (rows of R counted in the bytes; `traffic` is the PMC figure of this kernel)"
+                              if with_gram else "each timed launch follows one preconditioner apply (cache state of the solver loop)")},
         "block_jacobi": {"avg_apply_us": 1e6 * bj_s, "solver_apply_us": 1e6 * bj_solver_s, "solver_apply_forms_gram_block": bool(bj_with_gram),
                          "factor_bytes": prob.stat("bj_factor_bytes"),
                          "traffic": bj_traffic, "frac": bj_bytes / bj_s / 1e9 / HBM_PEAK_GBS,
@@ -517,7 +521,7 @@ def main():
             fbytes = prob2.stat("bj_factor_bytes")
             # fetched bytes per apply from the committed two-pass PMC run of this configuration
             fetched, fsrc = None, None
-            for rnd in (ROUND, "r02"):
+            for rnd in (ROUND, "r03", "r02"):
                 path = os.path.join(ROOT, "profiles", "%s_nd_apply_pmc.txt" % rnd)
                 if a.workload == "elasticity" and a.n == 70 and a.t == 4 and os.path.exists(path):
                     import re

@@ -14,8 +14,12 @@
 //     the exact transpose, from the same record -- 8 N (w + 4) bytes stored for BOTH sweeps instead of
 //     16 N (w + 1).  Same arithmetic as the classic sweeps, other summation order.
 //     (A first version stored the group in selective-inversion form, [Lt(g,g)^-1 - I ; -Lt(below,g)
-//     Lt(g,g)^-1], which needs no substitution at all; on the elasticity matrix, whose scaled factors
-//     have |Lt| up to 1e5, it lost 7 digits -- 2.5e-8 against 1.3e-15 -- and was dropped.)
+//     Lt(g,g)^-1], which needs no substitution at all.  It was 2.5e-8 off on 2 of 5670 blocks of the
+//     elasticity problem (1.3e-15 elsewhere) and was dropped -- at a time when the kernel still issued its DS
+//     lane moves by hand behind matrix instructions, a hazard that was found later and that produced exactly
+//     such isolated, run-to-run different errors.  So the inversion was not shown to be
+//     at fault; it was not taken up again because an explicit inverse of a corner whose entries reach 1e5 has
+//     no error bound of the substitution's kind, and parity with an exact solve is what this kernel is for.)
 //   * v_mfma_f64_4x4x4 computes four independent 4 x 4 x 4 products; on gfx950 the operands sit as
 //         A[i][k] of block q: lane 16 k + 4 q + i     B[k][j]: lane 16 k + 4 q + j
 //         D[i][j] of block q: lane 16 i + 4 q + j     (tools/probe/mfma_f64_4x4x4.hip)
@@ -34,7 +38,8 @@
 //     one ds_read_b64 (rows outside the record are clamped onto its all-zero row).
 //
 // Stored: 8 N (w + 4) bytes.  HBM bytes per apply: each sweep streams them once, 16 N (w + 4) + 16 N t
-// (measured: 705.6 MB on the headline problem, 5.85 TB/s = 0.93 of the device's read ceiling).
+// (PMC: 702-713 MB per launch on the headline problem = 1.08-1.09 x the algorithmic bytes, 6.1-6.3 TB/s,
+// 0.97-0.99 of what a plain read kernel streams on the same device; profiles/r0*_pmc_hbm_traffic_elasticity.json).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

@@ -29,7 +29,7 @@ def find(d, pattern):
 
 # 1. kernel statistics: copy the rocprofv3 summary as it is (names shortened)
 rows = list(csv.reader(open(find("prof_stats", "*kernel_stats.csv"))))
-dst = os.path.join(root, "profiles", "r03_bench_%s_kernel_stats.csv" % workload)
+dst = os.path.join(root, "profiles", "r04_bench_%s_kernel_stats.csv" % workload)
 with open(dst, "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(rows[0])
@@ -57,6 +57,7 @@ for k in raw["FETCH_SIZE"]:
     summary[k] = {"traffic_bytes_per_launch": (2.0 * fe + wr) * 1024.0,
                   "read_bytes_per_launch": 2.0 * fe * 1024.0, "write_bytes_per_launch": wr * 1024.0}
 spmm = [k for k in summary if k.startswith("k_spmm")]
+spmm_pick = next((k for k in spmm if "gram" in k), spmm[0] if spmm else None)
 bench = json.loads(open(os.path.join(out, "prof_stats_bench.json")).read().strip().splitlines()[-1])
 doc = {
     "command": "tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace "
@@ -66,14 +67,18 @@ doc = {
              "reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE is exact",
     "calibration": "k_probe_copy moves 1 GiB in and 1 GiB out per launch, k_update_z reads 3 panels and writes 1: "
                    "compare their rows below with those byte counts",
-    "k_spmm": summary[spmm[0]] if spmm else None,
-    "k_spmm_name": spmm[0] if spmm else None,
-    "k_bj": next((dict(summary[k], name=k) for k in summary if k.startswith("k_bj_g4<") or k.startswith("k_bj_apply")), None),
+    # the solver's product (with the Gram block when the run formed it) is the one bench.py's roofline block times
+    "k_spmm": summary[spmm_pick] if spmm else None,
+    "k_spmm_name": spmm_pick if spmm else None,
+    "k_spmm_plain": next((dict(summary[k], name=k) for k in spmm if k != spmm_pick), None),
+    # the two kinds of block-solve launch separately: plain, and the solver's (which also forms [AP | AP_prev]^T Z)
+    "k_bj": next((dict(summary[k], name=k) for k in summary if (k.startswith("k_bj_g4<") and "true" not in k) or k.startswith("k_bj_apply")), None),
+    "k_bj_gram": next((dict(summary[k], name=k) for k in summary if k.startswith("k_bj_g4<") and "true" in k), None),
     "per_kernel": summary,
     "raw": raw,
     "bench_line_of_the_profiled_run": bench,
 }
-dst = os.path.join(root, "profiles", "r03_pmc_hbm_traffic_%s.json" % workload)
+dst = os.path.join(root, "profiles", "r04_pmc_hbm_traffic_%s.json" % workload)
 with open(dst, "w") as f:
     json.dump(doc, f, indent=1)
 print("wrote", dst)
