@@ -6,16 +6,25 @@ namespace {
 
 // The Gram epilogue of one slice (see k_spmm_runs_gram): acc = the lane's row of Y, xrow(r) = where row r of the
 // slice's X lies (LDS or memory), R rows from memory; gw / gg = the wavefront's two accumulators.
+// the lane's four entries of R for spmm_gram_slice: step st = row g4 + st of the slice, column c
+__device__ __forceinline__ void spmm_gram_load_r(double (&rv)[4], int nr, int row_s, int lane, const double* __restrict__ Rg) {
+  const int g4 = lane & ~3, c = lane & 3;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int rr = min(g4 + st, nr - 1);          // (rows beyond the slice: clamped here, masked in the slice step)
+    rv[st] = Rg[(size_t)(row_s + rr) * 4 + c];
+  }
+}
 template <typename XROW>
 __device__ __forceinline__ void spmm_gram_slice(const double (&acc)[4], int nr, int row_s, int lane,
-                                                const double* __restrict__ Rg, XROW xrow, double& gw, double& gg) {
+                                                const double (&rin)[4], XROW xrow, double& gw, double& gg) {
   const int g4 = lane & ~3, c = lane & 3;
   double rv[4], xv[4];
 #pragma unroll
   for (int st = 0; st < 4; ++st) {         // step st: the quad stands for row g4 + st of the slice
     const int rr = g4 + st;
     const bool on = rr < nr;
-    rv[st] = on ? Rg[(size_t)(row_s + rr) * 4 + c] : 0.0;
+    rv[st] = on ? rin[st] : 0.0;
     xv[st] = on ? xrow(rr)[c] : 0.0;
   }
   double ty[4] = {acc[0], acc[1], acc[2], acc[3]};
@@ -115,7 +124,9 @@ __device__ __forceinline__ void spmm_body(
     if (lane < nr) store_row<TS>(Y, (size_t)(row_s + lane), acc);
     if constexpr (GRAM) {
       // a row of the slice's own X: in the window, or (a window cut short by win_cap) in memory
-      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) {
+      double rin[4];
+      spmm_gram_load_r(rin, nr, row_s, lane, Rg);
+      spmm_gram_slice(acc, nr, row_s, lane, rin, [&](int rr) {
         const unsigned wi = (unsigned)(row_s + rr - w0);
         return wi < (unsigned)wlen ? (const double*)(sx + (size_t)wi * 4) : X + (size_t)(row_s + rr) * 4;
       }, gw, gg);
@@ -362,9 +373,11 @@ __device__ __forceinline__ void spmm_runs_block(
     double acc[TS];
 #pragma unroll
     for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-    int touch = 0;
-    if constexpr (GRAM)       // the slice's rows of R on their way into the L2 while the matrix streams
-      touch = reinterpret_cast<const int*>(Rg)[((size_t)sl_row0[s] + min(lane, sl_nrows[s] - 1)) * 8];
+    // GRAM: the slice's rows of R are requested here, in the operand layout, and consumed behind the matrix
+    // loop (round 3 touched them here and read them again in the epilogue: the PMC counters showed the
+    // 33 MB fetched twice -- a line does not survive the slice's 45 KB of matrix stream in the L2)
+    double rin[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (GRAM) spmm_gram_load_r(rin, sl_nrows[s], sl_row0[s], lane, Rg);
     if (len > 0) {
       // two register sets: while one group is summed up the next one is in flight
       const int ngt = (len + RU - 1) / RU;
@@ -389,9 +402,8 @@ __device__ __forceinline__ void spmm_runs_block(
       for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
     }
     if constexpr (GRAM) {
-      asm volatile("" ::"v"(touch));
       const double* own = sx + (size_t)(nlow + row_s - r0) * 4;
-      spmm_gram_slice(acc, nr, row_s, lane, Rg, [&](int rr) { return own + (size_t)rr * 4; }, gw, gg);
+      spmm_gram_slice(acc, nr, row_s, lane, rin, [&](int rr) { return own + (size_t)rr * 4; }, gw, gg);
     }
     if (s + WG / 64 < s1) {       // (a block of more than four slices: the wavefront's next one)
       const int sn = s + WG / 64;
