@@ -48,7 +48,7 @@ int preAlps_hip_panel_update(CPLM_Mat_Dense_t* Z, const CPLM_Mat_Dense_t* V0, co
   if (ldb < na) return PA_FAIL("leading dimension %d below %d rows", ldb, na);
   double* d_beta = (double*)pa_rt_malloc((size_t)(ldb * nc > 0 ? ldb * nc : 1) * sizeof(double));
   int rc = !d_beta || pa_rt_h2d(d_beta, host_beta, (size_t)ldb * nc * sizeof(double));
-  rc = rc || pa_k_update_z(m, ts, a_lo, a_hi, nc, d_beta, ldb, V0->val, V1 ? V1->val : V0->val, Z->val, NULL, NULL);
+  rc = rc || pa_k_update_z(m, ts, a_lo, a_hi, nc, d_beta, ldb, V0->val, V1 ? V1->val : V0->val, Z->val, NULL, NULL, NULL, NULL);
   rc = rc || pa_rt_sync();
   pa_rt_free(d_beta);
   if (rc) return PA_FAIL("panel update failed: %s", pa_rt_error());
@@ -74,7 +74,7 @@ int preAlps_hip_panel_trsm_update(CPLM_Mat_Dense_t* P, CPLM_Mat_Dense_t* AP, CPL
   rc = rc || pa_rt_memset(d_info, 0, 8 * sizeof(int));
   double* d_res2 = d_small + (size_t)t * t + (size_t)t * nc;
   rc = rc || pa_k_trsm_update(m, ts, t, nc, d_small, d_small + (size_t)t * t, P->val, AP->val, X->val, R->val,
-                              d_rtr, &nblk, nc, d_res2, d_info, NULL, NULL);
+                              d_rtr, &nblk, nc, d_res2, d_info, NULL, NULL, NULL);
   double res2[2] = {0.0, 0.0};
   rc = rc || pa_rt_d2h(res2, d_res2, 2 * sizeof(double));
   if (host_res2) *host_res2 = res2[0];

@@ -74,6 +74,14 @@ typedef struct {
   int rotate;         /* NO_BS_RED: rotate pointers instead of copying */
   void* ev_res;       /* recorded after the residual norm has been copied to the host */
   int fuse;           /* NO_BS_RED: two-pass first half (PREALPS_ECG_FUSE=0 keeps the four-pass one) */
+  /* Lazy normalisation (Orthodir, NO_BS_RED, panels of up to 4 columns; PREALPS_ECG_LAZY_NORM=0 switches it off):
+   * P <- P U^-1 and AP <- AP U^-1 (ecg.c:434-435 of the reference) are never written.  X and R get the same update
+   * from rows normalised in registers; the block solve runs on AP_raw; the Gram blocks are formed on the raw
+   * panels; and the update kernel of the second half applies U^-1 (this iteration's for P and Z, the previous
+   * one's for P_prev) where the reference's panels would carry it -- the same algebra, two panel writes and
+   * their 66 MB per iteration less on the headline problem.  d_uu: the two factors, uu_cur: this iteration's. */
+  int lazy_norm, uu_cur;
+  double* d_uu;
   int poll;           /* the host polls the word a kernel writes behind the norm instead of waiting for an event */
   double seq, sent_seq, wait_seq;   /* last number handed out / the one travelling with the current norm / awaited */
   int lazy_stop;      /* several processes: the residual norm rides on the beta all-reduce (see below) */
@@ -136,7 +144,7 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
    * Orthomin needs no P_prev / AP_prev slots (ecg.c:55-61) */
   size_t panel = (size_t)(m > 0 ? m : 1) * ts;
   int nv = (ecg->ortho_alg == ORTHOMIN) ? 1 : 2;
-  size_t small = 5 * (size_t)T * T + 2 * (size_t)T * T /* q, scratch */ + 8;
+  size_t small = 5 * (size_t)T * T + 2 * (size_t)T * T /* q, scratch */ + 8 + 2 * (size_t)T * T /* uu */;
   size_t parts = (size_t)pa_gram_max_blocks() * (2 * (size_t)ts * ts + ts);
   /* T = 4: the library's SpMM can form [AP | R]^T P while it computes AP (one block per workgroup) */
   pv->spmm_cap = (T == 4 && ts == 4) ? pa_operator_gram_blocks(ts) : 0;
@@ -159,6 +167,7 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
   pv->d_rtr = w + 4 * (size_t)T * T; w += 5 * (size_t)T * T;
   pv->d_q = w; w += 2 * (size_t)T * T;
   pv->d_res2 = w; w += 8;
+  pv->d_uu = w; w += 2 * (size_t)T * T;
   pv->d_partials = w; w += (size_t)pa_gram_max_blocks() * 2 * ts * ts;
   pv->d_rtr_part = w; w += (size_t)pa_gram_max_blocks() * ts;
   pv->d_spmm_parts = pv->spmm_cap ? w : NULL;
@@ -209,6 +218,8 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
   publish_pointers(ecg, pv);
   pv->rotate = (ecg->bs_red == NO_BS_RED);
   { const char* f = getenv("PREALPS_ECG_FUSE"); pv->fuse = f ? atoi(f) : 1; }
+  pv->lazy_norm = pv->fuse && ecg->ortho_alg == ORTHODIR && ecg->bs_red == NO_BS_RED && pv->ts <= 4 && pa_env_flag("PREALPS_ECG_LAZY_NORM", 1);
+  pv->uu_cur = 0;
   /* With more than one process every collective costs tens of microseconds.  The norm of the
    * new residual is only needed for the stopping decision, so the driver loops of this library
    * (preAlps_ECGSolve / ECGAdvance) let it travel with the beta all-reduce of the same
@@ -262,6 +273,12 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
   pa_set_desc(ecg->P, M, t, m, t, ts);
   pa_set_desc(ecg->AP, M, t, m, t, ts);
   PA_CHECK(pa_rt_memset(ecg->work, 0, pv->pool_doubles * sizeof(double)));
+  if (pv->lazy_norm) {        /* (the first update meets an empty P_prev: any factor will do, the identity is one) */
+    double eye[2 * 16 * 16];
+    memset(eye, 0, sizeof(eye));
+    for (int k = 0; k < 2; ++k) for (int i = 0; i < t; ++i) eye[(size_t)k * t * t + i + (size_t)t * i] = 1.0;
+    PA_CHECK(pa_rt_h2d(pv->d_uu, eye, 2 * (size_t)t * t * sizeof(double)));
+  }
   /* normb and R0: column (rank % t) of every reference rank = part */
   double nb2 = 0.0;
   double* r0 = (double*)calloc((size_t)(m > 0 ? m : 1) * ts, sizeof(double));
@@ -522,7 +539,7 @@ static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
   PA_CHECK(pa_k_trsm_update(m, ts, t, ecg->X->info.n, pv->d_mu, pv->d_alpha, ecg->P->val, ecg->AP->val,
                             pv->d_X, pv->d_R, pv->d_rtr_part, &nb, defer ? 0 : T,
                             pv->lazy_ptr ? pv->lazy_ptr : pv->d_res2, pv->d_info, single ? pv->h_pin : NULL,
-                            single ? NULL : buf));
+                            single ? NULL : buf, pv->lazy_norm ? pv->d_uu + (size_t)pv->uu_cur * T * T : NULL));
   pv->rtr_nblk = nb;
   TAC(PA_T_UPDATE, trsm_t);
   pv->rtr_valid = defer ? 1 : 2;
@@ -636,7 +653,10 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   int polled = note && pv->poll && ecg->Z->info.n > 0;
   if (polled) { pv->wait_seq = (pv->seq += 1.0); pa_k_note_seq(pv->wait_seq); }
   PA_CHECK(pa_k_update_z(pv->m, pv->ts, v_lo, v_hi, ecg->Z->info.n, pv->d_beta, ecg->beta->info.lda,
-                         pv->buf_v[0], pv->buf_v[1], pv->buf_z, note, note ? pv->h_pin : NULL));
+                         pv->buf_v[0], pv->buf_v[1], pv->buf_z, note, note ? pv->h_pin : NULL,
+                         pv->lazy_norm ? pv->d_uu + (size_t)pv->uu_cur * T * T : NULL,
+                         pv->lazy_norm ? pv->d_uu + (size_t)(1 - pv->uu_cur) * T * T : NULL));
+  if (pv->lazy_norm) pv->uu_cur ^= 1;
   if (note && ecg->Z->info.n <= 0) PA_CHECK(pa_rt_d2h_async(pv->h_pin, note, 2 * sizeof(double)));   /* (no launch above) */
   if (note && !polled) { pv->wait_seq = 0.0; PA_CHECK(pa_rt_event_record(pv->ev_res)); }
   TAC(PA_T_UPDATE, gemm_t);
@@ -821,7 +841,7 @@ int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
   {
     int vn = ecg->V->info.n, v_lo = vn < nrhs ? vn : nrhs, v_hi = vn - v_lo;
     PA_CHECK(pa_k_update_z(m, ts, v_lo, v_hi, ecg->Z->info.n, pv->d_beta, ecg->beta->info.lda,
-                           pv->buf_v[0], pv->buf_v[1], pv->buf_z, NULL, NULL));
+                           pv->buf_v[0], pv->buf_v[1], pv->buf_z, NULL, NULL, NULL, NULL));
   }
   TAC(PA_T_UPDATE, gemm_t);
   if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 1)) return 1;

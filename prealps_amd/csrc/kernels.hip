@@ -868,7 +868,8 @@ template <int TS>
 __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, double* U, double* alpha,
                                                     double* __restrict__ P, double* __restrict__ AP,
                                                     double* __restrict__ X, double* __restrict__ R,
-                                                    double* __restrict__ rtr, const double* gram, int* info) {
+                                                    double* __restrict__ rtr, const double* gram, int* info,
+                                                    double* __restrict__ ukeep) {
   __shared__ double su[TS * TS];
   __shared__ double sd[TS];
   __shared__ double sa[TS * TS];
@@ -881,6 +882,9 @@ __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, double
   }
   __syncthreads();
   if (threadIdx.x < t) sd[threadIdx.x] = 1.0 / su[threadIdx.x + t * threadIdx.x];
+  // ukeep (lazy normalisation, ecg.c): P and AP stay as they are -- the rows below are normalised in
+  // registers for X and R only -- and the factor is kept for the kernels that meet the raw panels later
+  if (ukeep && blockIdx.x == 0) for (int e = threadIdx.x; e < t * t; e += WG) ukeep[e] = su[e];
   __syncthreads();
   double rr[TS];
 #pragma unroll
@@ -919,8 +923,10 @@ __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, double
         rr[c] = fma(r[c], r[c], rr[c]);
       }
     }
-    store_row<TS>(P, row, p);
-    store_row<TS>(AP, row, ap);
+    if (!ukeep) {
+      store_row<TS>(P, row, p);
+      store_row<TS>(AP, row, ap);
+    }
     store_row<TS>(X, row, x);
     store_row<TS>(R, row, r);
   }
@@ -1113,8 +1119,10 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
                                                  const double* __restrict__ V0,
                                                  const double* __restrict__ V1,
                                                  double* __restrict__ Z,
-    const double* note_src, double* note_host, double note_seq) {
+    const double* note_src, double* note_host, double note_seq,
+    const double* __restrict__ ucur, const double* __restrict__ uprev) {
   __shared__ double sb[2 * TS * TS];
+  __shared__ double sc[7 * TS * TS];
   // (note_host: two words the host is waiting for -- the all-reduced residual norm and the
   // factorisation status next to beta -- go out to pinned memory from here: no copy, no extra launch)
   if (note_host && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1127,6 +1135,78 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
   for (int e = threadIdx.x; e < na * nc; e += WG) sb[e] = beta[(e % na) + ldb * (e / na)];
   __syncthreads();
   const size_t stride = (size_t)gridDim.x * WG;
+  if (ucur) {
+    // Lazy normalisation (ecg.c: Orthodir without block-size reduction, panels of up to 4 columns): the panels
+    // were never multiplied by U^-1 -- V0 = P_raw and Z = M^-1 AP_raw belong to the factor U = ucur of this
+    // iteration, V1 = P_prev_raw to uprev -- and `beta` holds the RAW Gram blocks G1 = AP_raw^T Z_raw, G2 =
+    // AP_prev_raw^T Z_raw.  With Ui = U^-1, Up = uprev^-1 the reference's update Z_n - P_n beta1 - P_prev_n beta2
+    // (ecg.c:510-517 on the normalised panels) is  Z_raw C0 - P_raw C1 - P_prev_raw C2,  C0 = Ui,
+    // C1 = Ui (Ui^T G1 Ui), C2 = Up (Up^T G2 Ui): sixteen threads form the three t x t blocks in LDS.
+    const int t = a_lo, tt = t * t, tid = threadIdx.x;
+    double* Ui = sc; double* Up = sc + TS * TS; double* T1 = sc + 2 * TS * TS; double* T2 = sc + 3 * TS * TS;
+    double* C0 = sc + 4 * TS * TS; double* C1 = sc + 5 * TS * TS; double* C2 = sc + 6 * TS * TS;
+    if (tid < 64) {
+      if (tid < 2 * t) {          // column c of the inverse of an upper-triangular factor: back substitution on e_c
+        const double* __restrict__ Uf = tid < t ? ucur : uprev;
+        double* inv = tid < t ? Ui : Up;
+        const int c = tid < t ? tid : tid - t;
+        double x[TS];
+#pragma unroll
+        for (int i = TS - 1; i >= 0; --i) {
+          x[i] = 0.0;
+          if (i < t && i <= c) {
+            double sv = i == c ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = i + 1; k < TS; ++k) if (k < t && k <= c) sv = fma(-Uf[i + t * k], x[k], sv);
+            x[i] = sv / Uf[i + t * i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TS; ++i) if (i < t) inv[i + t * c] = x[i];
+      }
+      wave_lds_sync();
+      const int r = tid % (t > 0 ? t : 1), c = tid / (t > 0 ? t : 1);
+      const bool on = tid < tt;
+      if (on) {                     // T1 = G1 Ui, T2 = G2 Ui
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < t; ++k) { s1 = fma(sb[r + na * k], Ui[k + t * c], s1); if (a_hi > 0) s2 = fma(sb[a_lo + r + na * k], Ui[k + t * c], s2); }
+        T1[tid] = s1; T2[tid] = s2;
+      }
+      wave_lds_sync();
+      double b1 = 0.0, b2 = 0.0;
+      if (on) {                     // beta1 = Ui^T T1, beta2 = Up^T T2
+        for (int k = 0; k < t; ++k) { b1 = fma(Ui[k + t * r], T1[k + t * c], b1); b2 = fma(Up[k + t * r], T2[k + t * c], b2); }
+      }
+      wave_lds_sync();
+      if (on) { T1[tid] = b1; T2[tid] = b2; }
+      wave_lds_sync();
+      if (on) {                     // C1 = Ui beta1, C2 = Up beta2, C0 = Ui
+        double c1 = 0.0, c2 = 0.0;
+        for (int k = 0; k < t; ++k) { c1 = fma(Ui[r + t * k], T1[k + t * c], c1); c2 = fma(Up[r + t * k], T2[k + t * c], c2); }
+        C0[tid] = Ui[tid]; C1[tid] = c1; C2[tid] = c2;
+      }
+    }
+    __syncthreads();
+    for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+      double z[TS], v0[TS], v1[TS], o[TS];
+      load_row<TS>(Z, row, z);
+      load_row<TS>(V0, row, v0);
+      if (a_hi > 0) load_row<TS>(V1, row, v1);
+#pragma unroll
+      for (int c = 0; c < TS; ++c) {
+        o[c] = z[c];
+        if (c < nc) {
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < TS; ++k)
+            if (k < t) { s = fma(z[k], C0[k + t * c], s); s = fma(-v0[k], C1[k + t * c], s); if (a_hi > 0) s = fma(-v1[k], C2[k + t * c], s); }
+          o[c] = s;
+        }
+      }
+      store_row<TS>(Z, row, o);
+    }
+    return;
+  }
   for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
     double z[TS], v0[TS], v1[TS];
     load_row<TS>(Z, row, z);
@@ -2684,7 +2764,8 @@ int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha,
 
 int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, double* P,
                      double* AP, double* X, double* R, double* rtr_partials, int* nblk, int trace_nc,
-                     double* res2, int* info, double* host, const double* gram) {
+                     double* res2, int* info, double* host, const double* gram, double* ukeep) {
+  if (ukeep && ts > 4) { snprintf(g_kerr, sizeof(g_kerr), "pa_k_trsm_update: lazy normalisation is built for panels of up to 4 columns"); return 1; }
   int blocks = grid_rows(m, 2);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
@@ -2697,7 +2778,7 @@ int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, dou
     PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info);
   else {
     TS_DISPATCH(ts, PA_LAUNCH((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
-                                       t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info));
+                                       t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep));
   }
   if (kfail("k_trsm_update")) return 1;
   if (trace_nc <= 0) return 0;
@@ -2723,8 +2804,13 @@ int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, doub
 }
 
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
-                  const double* V0, const double* V1, double* Z, const double* note_src, double* note_host) {
+                  const double* V0, const double* V1, double* Z, const double* note_src, double* note_host,
+                  const double* ucur, const double* uprev) {
   if (nc <= 0) return 0;
+  if (ucur && (ts > 4 || !uprev || nc != a_lo || (a_hi != 0 && a_hi != a_lo))) {
+    snprintf(g_kerr, sizeof(g_kerr), "pa_k_update_z: lazy normalisation needs square blocks on panels of up to 4 columns");
+    return 1;
+  }
   const double seq_ = take_note_seq(note_host);
   if (ts == 16) {   // matrix cores (k_update_z_mfma16), one 16-row tile per wavefront and step
     PA_LAUNCH(k_update_z_mfma16, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
@@ -2737,7 +2823,7 @@ int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta,
     return kfail("k_update_z_mfma8");
   }
   TS_DISPATCH(ts, PA_LAUNCH((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
-                                     cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z, note_src, note_host, seq_));
+                                     cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z, note_src, note_host, seq_, ucur, uprev));
   return kfail("k_update_z");
 }
 

@@ -173,7 +173,9 @@ int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha,
  * (nc = T) and the first one stores them and *info. */
 int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, double* P,
                      double* AP, double* X, double* R, double* rtr_partials, int* nblk, int trace_nc,
-                     double* res2, int* info, double* host, const double* gram);
+                     double* res2, int* info, double* host, const double* gram, double* ukeep);
+/* ukeep != NULL (lazy normalisation, panels of up to 4 columns): P and AP are NOT overwritten -- X and R get the
+ * same update from rows normalised in registers -- and the t x t factor U is stored in ukeep for pa_k_update_z. */
 /* Standalone sums of R(:,c)^2 (same layout as above). */
 int pa_k_colnorm2(int m, int ts, const double* R, double* rtr_partials, int* nblk);
 /* res2[0] = sum over blocks and columns c < nc; res2[1] = *info (0 if info is NULL). */
@@ -182,7 +184,10 @@ int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, doub
 /* Z(:, :nc) -= [V0(:, :a_lo) | V1(:, :a_hi)] beta, beta is (a_lo+a_hi) x nc,
  * leading dimension ldb (ecg.c:354,517). */
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
-                  const double* V0, const double* V1, double* Z, const double* note_src, double* note_host);
+                  const double* V0, const double* V1, double* Z, const double* note_src, double* note_host,
+                  const double* ucur, const double* uprev);
+/* ucur != NULL (lazy normalisation): V0 / Z belong to the factor ucur, V1 to uprev, beta holds the raw Gram
+ * blocks [V0-side ; V1-side]^T Z; the kernel applies U^-1 where the reference's panels would carry it. */
 /* note_host != NULL: note_src[0..1] (device) are also written to note_host[0..1] (pinned, device-visible) */
 /* The next launch that writes two words to pinned host memory (pa_k_trsm_update / pa_k_update_xr with
  * `host`, pa_k_update_z with note_host) also writes host[2] = seq behind them (seq != 0; one-shot), for

@@ -640,13 +640,15 @@ print("variant ok", prob.stat("spmm_staged"), prob.stat("bj_max_bandwidth"), pro
                                  {"PREALPS_ECG_FUSE": "0"},
                                  {"PREALPS_BJ_PAIRS": "0"},
                                  {"PREALPS_ECG_POLL": "1", "PREALPS_SPMM_GRAM": "1"},
-                                 {"PREALPS_ECG_LAZY_STOP": "0"}])
+                                 {"PREALPS_ECG_LAZY_STOP": "0"},
+                                 {"PREALPS_ECG_LAZY_NORM": "0"}])
 def test_opt_in_kernel_variants(env):
     """The window SpMM kernel on a matrix that would get the staged plan, the register recurrence of the
     block solve at 8 and 16 columns (PREALPS_BJ_MFMA=0), the matrix-core block solve at every width, the four-pass
     first half, the narrow-band sweep on plain instead of paired records, and the host polling for the residual norm
     (the default of multi-process runs) in one process, and the stopping test right after the update
-    (PREALPS_ECG_LAZY_STOP=0) instead of one half-step later: same answers as the oracle
+    (PREALPS_ECG_LAZY_STOP=0) instead of one half-step later, and P / AP normalised in place as the reference does
+    (PREALPS_ECG_LAZY_NORM=0; the default leaves them raw and applies U^-1 downstream): same answers as the oracle
     (Poisson 16^3, 16 slabs, band 256 -> register-set class 5; Poisson 12^3 in 27 boxes, class 2)."""
     r = subprocess.run([sys.executable, "-c", _VARIANT_SNIPPET % ROOT], capture_output=True, text=True,
                        env=dict(os.environ, **env), timeout=600)
