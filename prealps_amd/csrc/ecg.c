@@ -74,7 +74,7 @@ typedef struct {
   int rotate;         /* NO_BS_RED: rotate pointers instead of copying */
   void* ev_res;       /* recorded after the residual norm has been copied to the host */
   int fuse;           /* NO_BS_RED: two-pass first half (PREALPS_ECG_FUSE=0 keeps the four-pass one) */
-  /* Lazy normalisation (Orthodir, NO_BS_RED, panels of up to 4 columns; PREALPS_ECG_LAZY_NORM=0 switches it off):
+  /* Lazy normalisation (Orthodir, NO_BS_RED; PREALPS_ECG_LAZY_NORM=0 switches it off):
    * P <- P U^-1 and AP <- AP U^-1 (ecg.c:434-435 of the reference) are never written.  X and R get the same update
    * from rows normalised in registers; the block solve runs on AP_raw; the Gram blocks are formed on the raw
    * panels; and the update kernel of the second half applies U^-1 (this iteration's for P and Z, the previous
@@ -218,7 +218,7 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
   publish_pointers(ecg, pv);
   pv->rotate = (ecg->bs_red == NO_BS_RED);
   { const char* f = getenv("PREALPS_ECG_FUSE"); pv->fuse = f ? atoi(f) : 1; }
-  pv->lazy_norm = pv->fuse && ecg->ortho_alg == ORTHODIR && ecg->bs_red == NO_BS_RED && pv->ts <= 4 && pa_env_flag("PREALPS_ECG_LAZY_NORM", 1);
+  pv->lazy_norm = pv->fuse && ecg->ortho_alg == ORTHODIR && ecg->bs_red == NO_BS_RED && pa_env_flag("PREALPS_ECG_LAZY_NORM", 1);
   pv->uu_cur = 0;
   /* With more than one process every collective costs tens of microseconds.  The norm of the
    * new residual is only needed for the stopping decision, so the driver loops of this library

@@ -946,7 +946,8 @@ template <int TS>
 __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, double* Ug, double* alphag,
                                                          double* __restrict__ P, double* __restrict__ AP,
                                                          double* __restrict__ X, double* __restrict__ R,
-                                                         double* __restrict__ rtr, const double* gram, int* info) {
+                                                         double* __restrict__ rtr, const double* gram, int* info,
+                                                         double* __restrict__ ukeep) {
   static_assert(TS == 8 || TS == 16, "matrix-core variant: panels of 8 or 16 columns");
   __shared__ double su[16 * 16];    // U (column major, leading dimension 16, identity beyond t)
   __shared__ double si[16 * 16];    // Ui = U^-1
@@ -968,6 +969,8 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
     su[e] = (i < t && j < t) ? U[i + t * j] : (i == j ? 1.0 : 0.0);
     sb[e] = 0.0;
   }
+  // ukeep (lazy normalisation): P and AP are left as they are, the factor is kept for pa_k_update_z
+  if (ukeep && blockIdx.x == 0) for (int e = tid; e < t * t; e += WG) ukeep[e] = U[e];
   __syncthreads();
   if (tid < 16) {
     // column tid of Ui by back substitution: U x = e_tid (upper triangular)
@@ -1028,8 +1031,10 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
       }
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
-        pn = __builtin_amdgcn_mfma_f64_16x16x4f64(ap_[s2], bu[s2], pn, 0, 0, 0);
-        apn = __builtin_amdgcn_mfma_f64_16x16x4f64(aap[s2], bu[s2], apn, 0, 0, 0);
+        if (!ukeep) {
+          pn = __builtin_amdgcn_mfma_f64_16x16x4f64(ap_[s2], bu[s2], pn, 0, 0, 0);
+          apn = __builtin_amdgcn_mfma_f64_16x16x4f64(aap[s2], bu[s2], apn, 0, 0, 0);
+        }
         x = __builtin_amdgcn_mfma_f64_16x16x4f64(ap_[s2], bb[s2], x, 0, 0, 0);
         r = __builtin_amdgcn_mfma_f64_16x16x4f64(aap[s2], -bb[s2], r, 0, 0, 0);
       }
@@ -1037,7 +1042,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
       for (int q = 0; q < 4; ++q) {
         const size_t row = r0 + hi + 4 * q;
         if (row < (size_t)m) {
-          P[row * 16 + lo] = pn[q]; AP[row * 16 + lo] = apn[q];
+          if (!ukeep) { P[row * 16 + lo] = pn[q]; AP[row * 16 + lo] = apn[q]; }
           X[row * 16 + lo] = x[q]; R[row * 16 + lo] = r[q];
           if (lo < nc) rr = fma(r[q], r[q], rr);
         }
@@ -1060,14 +1065,14 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
       }
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
-        pn = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bu[s2], pn, 0, 0, 0);
+        if (!ukeep) pn = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bu[s2], pn, 0, 0, 0);
         xr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bb[s2], xr, 0, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const size_t row = r0 + hi + 4 * q;
         if (row < (size_t)m) {
-          PA[row * 8 + cc] = pn[q];
+          if (!ukeep) PA[row * 8 + cc] = pn[q];
           XR[row * 8 + cc] = xr[q];
           if (lo >= 8 && cc < nc) rr = fma(xr[q], xr[q], rr);
         }
@@ -1235,13 +1240,69 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
 // holds Z[row (l>>4) + 4r][col l&15]: four fully coalesced 512-byte accesses), the rows of
 // [V0 | V1] are the A operand (A[row l&15][k = 4s + (l>>4)], 32-byte pieces of 16 rows per
 // load, every cache line used up over four loads) and -beta the B operand, a per-lane constant.
+// Lazy normalisation, panels of 8 / 16 columns (see k_update_z<TS>): C0 = Ui, C1 = Ui (Ui^T G1 Ui), C2 = Up (Up^T G2 Ui)
+// from the raw Gram blocks in `beta` and the two kept factors, as 16 x 16 blocks (leading dimension 16, zero
+// beyond t) in LDS; called by a whole workgroup of WG threads.  sc = 7 * 256 doubles.
+__device__ __forceinline__ void lazy_coeffs16(const double* __restrict__ beta, int ldb, int t, int a_hi,
+                                              const double* __restrict__ ucur, const double* __restrict__ uprev,
+                                              double* sc) {
+  double* Ui = sc; double* Up = sc + 256; double* T1 = sc + 512; double* T2 = sc + 768;
+  double* C0 = sc + 1024; double* C1 = sc + 1280; double* C2 = sc + 1536;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 256; e += WG) {       // the factors, identity beyond t (T1 / T2 serve as staging)
+    const int i = e & 15, j = e >> 4;
+    T1[e] = (i < t && j < t) ? ucur[i + t * j] : (i == j ? 1.0 : 0.0);
+    T2[e] = (i < t && j < t) ? uprev[i + t * j] : (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  if (tid < 32) {                             // column c of an inverse by back substitution on e_c
+    const double* Uf = tid < 16 ? T1 : T2;
+    double* inv = tid < 16 ? Ui : Up;
+    const int c = tid & 15;
+    double x[16];
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+      double sv = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = i + 1; k < 16; ++k) sv -= Uf[i + 16 * k] * x[k];
+      x[i] = sv / Uf[i + 16 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) inv[i + 16 * c] = x[i];
+  }
+  __syncthreads();
+  const int r = tid & 15, c = tid >> 4;       // WG = 256: one entry each
+  const bool on = r < t && c < t;
+  {
+    double s1 = 0.0, s2 = 0.0;                // T = G Ui
+    if (on) for (int k = 0; k < t; ++k) {
+      s1 = fma(beta[r + ldb * k], Ui[k + 16 * c], s1);
+      if (a_hi > 0) s2 = fma(beta[t + r + ldb * k], Ui[k + 16 * c], s2);
+    }
+    __syncthreads();
+    T1[tid] = s1; T2[tid] = s2;
+  }
+  __syncthreads();
+  double b1 = 0.0, b2 = 0.0;                  // beta1 = Ui^T T1, beta2 = Up^T T2
+  if (on) for (int k = 0; k < t; ++k) { b1 = fma(Ui[k + 16 * r], T1[k + 16 * c], b1); b2 = fma(Up[k + 16 * r], T2[k + 16 * c], b2); }
+  __syncthreads();
+  T1[tid] = b1; T2[tid] = b2;
+  __syncthreads();
+  double c1 = 0.0, c2 = 0.0;                  // C1 = Ui beta1, C2 = Up beta2
+  if (on) for (int k = 0; k < t; ++k) { c1 = fma(Ui[r + 16 * k], T1[k + 16 * c], c1); c2 = fma(Up[r + 16 * k], T2[k + 16 * c], c2); }
+  C0[tid] = on ? Ui[tid] : 0.0; C1[tid] = c1; C2[tid] = c2;
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_hi, int nc,
                                                         const double* __restrict__ beta, int ldb,
                                                         const double* __restrict__ V0,
                                                         const double* __restrict__ V1,
                                                         double* __restrict__ Z,
-    const double* note_src, double* note_host, double note_seq) {
+    const double* note_src, double* note_host, double note_seq,
+    const double* __restrict__ ucur, const double* __restrict__ uprev) {
   constexpr int TS = 16;
+  __shared__ double sc[7 * 256];
   // (note_host: two words the host is waiting for -- the all-reduced residual norm and the
   // factorisation status next to beta -- go out to pinned memory from here: no copy, no extra launch)
   if (note_host && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1263,6 +1324,44 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_h
   }
   const size_t ntile = ((size_t)m + 15) >> 4;
   const size_t tstride = (size_t)gridDim.x * (WG / 64);
+  if (ucur) {
+    // lazy normalisation: Z <- Z C0 - V0 C1 - V1 C2 (k_update_z<TS>); Z is an A operand like the other two
+    lazy_coeffs16(beta, ldb, a_lo, a_hi, ucur, uprev, sc);
+    double b0[4], b1[4], b2[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int k = 4 * s2 + hi;
+      b0[s2] = sc[1024 + k + 16 * lo]; b1[s2] = -sc[1280 + k + 16 * lo]; b2[s2] = -sc[1536 + k + 16 * lo];
+    }
+    for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
+      const size_t r0 = t << 4, arow = r0 + lo;
+      const bool aok = arow < (size_t)m;
+      double az[4], a0[4], a1[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        az[s2] = aok ? Z[arow * TS + 4 * s2 + hi] : 0.0;
+        a0[s2] = aok ? V0[arow * TS + 4 * s2 + hi] : 0.0;
+        a1[s2] = (aok && a_hi > 0) ? V1[arow * TS + 4 * s2 + hi] : 0.0;
+      }
+      mfma_d4 z = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        z = __builtin_amdgcn_mfma_f64_16x16x4f64(az[s2], b0[s2], z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s2], b1[s2], z, 0, 0, 0);
+      }
+      if (a_hi > 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) z = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s2], b2[s2], z, 0, 0, 0);
+      }
+      asm volatile("" ::: "memory");     // (every lane of the tile has read its rows of Z before any is overwritten)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = r0 + hi + 4 * r;
+        if (row < (size_t)m && lo < nc) Z[row * TS + lo] = z[r];
+      }
+    }
+    return;
+  }
   for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
     const size_t r0 = t << 4;
     mfma_d4 z;
@@ -1300,8 +1399,10 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma8(int m, int a_lo, int a_hi
                                                        const double* __restrict__ V0,
                                                        const double* __restrict__ V1,
                                                        double* __restrict__ Z,
-    const double* note_src, double* note_host, double note_seq) {
+    const double* note_src, double* note_host, double note_seq,
+    const double* __restrict__ ucur, const double* __restrict__ uprev) {
   constexpr int TS = 8;
+  __shared__ double sc[7 * 256];
   // (note_host: two words the host is waiting for -- the all-reduced residual norm and the
   // factorisation status next to beta -- go out to pinned memory from here: no copy, no extra launch)
   if (note_host && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1324,6 +1425,38 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma8(int m, int a_lo, int a_hi
   }
   const size_t ntile = ((size_t)m + 15) >> 4;
   const size_t tstride = (size_t)gridDim.x * (WG / 64);
+  if (ucur) {
+    // lazy normalisation: Z <- [V0 | V1 | Z] [-C1 ; -C2 ; C0], 24 columns in six steps of four
+    lazy_coeffs16(beta, ldb, a_lo, a_hi, ucur, uprev, sc);
+    double bb[6];
+#pragma unroll
+    for (int s2 = 0; s2 < 6; ++s2) {
+      const int k = 4 * s2 + hi, kk = k & 7;
+      const double v = s2 < 2 ? -sc[1280 + kk + 16 * (lo & 7)] : s2 < 4 ? -sc[1536 + kk + 16 * (lo & 7)] : sc[1024 + kk + 16 * (lo & 7)];
+      bb[s2] = lo < TS ? v : 0.0;
+    }
+    for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
+      const size_t r0 = t << 4, arow = r0 + lo;
+      const bool aok = arow < (size_t)m;
+      double a[6];
+#pragma unroll
+      for (int s2 = 0; s2 < 6; ++s2) {
+        const int kk = (4 * s2 + hi) & 7;
+        const double* __restrict__ src = s2 < 2 ? V0 : s2 < 4 ? V1 : Z;
+        a[s2] = (aok && (s2 < 2 || s2 >= 4 || a_hi > 0)) ? src[arow * TS + kk] : 0.0;
+      }
+      mfma_d4 z = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s2 = 0; s2 < 6; ++s2) z = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bb[s2], z, 0, 0, 0);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = r0 + hi + 4 * r;
+        if (row < (size_t)m && lo < nc) Z[row * TS + lo] = z[r];
+      }
+    }
+    return;
+  }
   for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
     const size_t r0 = t << 4;
     mfma_d4 z;
@@ -2765,7 +2898,6 @@ int pa_k_potrf_alpha(const double* buf, int t, int T, double* mu, double* alpha,
 int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, double* P,
                      double* AP, double* X, double* R, double* rtr_partials, int* nblk, int trace_nc,
                      double* res2, int* info, double* host, const double* gram, double* ukeep) {
-  if (ukeep && ts > 4) { snprintf(g_kerr, sizeof(g_kerr), "pa_k_trsm_update: lazy normalisation is built for panels of up to 4 columns"); return 1; }
   int blocks = grid_rows(m, 2);
   if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
   *nblk = blocks;
@@ -2773,9 +2905,9 @@ int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, dou
   static int use_mfma = -1;
   if (use_mfma < 0) { const char* e = getenv("PREALPS_TRSM_MFMA"); use_mfma = e ? atoi(e) : 1; }
   if (ts == 16 && use_mfma)
-    PA_LAUNCH((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info);
+    PA_LAUNCH((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep);
   else if (ts == 8 && use_mfma)
-    PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info);
+    PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep);
   else {
     TS_DISPATCH(ts, PA_LAUNCH((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                        t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep));
@@ -2807,19 +2939,19 @@ int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta,
                   const double* V0, const double* V1, double* Z, const double* note_src, double* note_host,
                   const double* ucur, const double* uprev) {
   if (nc <= 0) return 0;
-  if (ucur && (ts > 4 || !uprev || nc != a_lo || (a_hi != 0 && a_hi != a_lo))) {
-    snprintf(g_kerr, sizeof(g_kerr), "pa_k_update_z: lazy normalisation needs square blocks on panels of up to 4 columns");
+  if (ucur && (!uprev || nc != a_lo || (a_hi != 0 && a_hi != a_lo))) {
+    snprintf(g_kerr, sizeof(g_kerr), "pa_k_update_z: lazy normalisation needs square blocks");
     return 1;
   }
   const double seq_ = take_note_seq(note_host);
   if (ts == 16) {   // matrix cores (k_update_z_mfma16), one 16-row tile per wavefront and step
     PA_LAUNCH(k_update_z_mfma16, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
-                       beta, ldb, V0, V1, Z, note_src, note_host, seq_);
+                       beta, ldb, V0, V1, Z, note_src, note_host, seq_, ucur, uprev);
     return kfail("k_update_z_mfma16");
   }
   if (ts == 8) {
     PA_LAUNCH(k_update_z_mfma8, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
-                       beta, ldb, V0, V1, Z, note_src, note_host, seq_);
+                       beta, ldb, V0, V1, Z, note_src, note_host, seq_, ucur, uprev);
     return kfail("k_update_z_mfma8");
   }
   TS_DISPATCH(ts, PA_LAUNCH((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
