@@ -27,6 +27,7 @@ int preAlps_hip_panel_gram(const CPLM_Mat_Dense_t* A0, const CPLM_Mat_Dense_t* A
   double* d_out = (double*)pa_rt_malloc((size_t)(na * nb > 0 ? na * nb : 1) * sizeof(double));
   double* h = (double*)malloc((size_t)(na * nb > 0 ? na * nb : 1) * sizeof(double));
   int rc = !d_part || !d_out || !h;
+  rc = rc || pa_rt_memset(d_part, 0, pbytes);        /* (the ticket of the wide sum lives in this buffer) */
   rc = rc || pa_k_gram_finish(m, ts, A0->val, A1 ? A1->val : NULL, B->val, d_part, a_lo, a_hi, nb, d_out, na,
                               0, 0, NULL, NULL, NULL);
   rc = rc || pa_rt_d2h(h, d_out, (size_t)na * nb * sizeof(double));

@@ -619,6 +619,108 @@ __global__ __launch_bounds__(1024) void k_finish_potrf_alpha(const double* __res
   potrf_alpha_wg(out, t, T, mu, alpha, info, red, red + 256);
 }
 
+// Wide Gram blocks (panels of 8 / 16 columns: 128 / 512 doubles per partial block, 512 of them = 0.5 / 2 MB,
+// which ONE workgroup needs 9 / 36 us to read -- k_finish_potrf_alpha took 17-21 us per iteration at 8 columns,
+// k_finish x 2 + k_potrf_alpha + k_trace_finish 43 us at 16): FINW_WG workgroups sum a contiguous share of the
+// blocks each, element by element, coalesced; the share goes out with device-scope stores, a ticket elects the
+// last workgroup (k_finish32's protocol: no fence), which adds the shares in their fixed order, scatters the
+// active sub-block into `out` as finish_sum does and, as asked, factors it (t > 0: k_finish_potrf_alpha) and /
+// or sums the residual norm next to it (rtr: k_finish_trace).  The ticket lives behind the shares in `scratch`
+// (per buffer, zero when the buffer is made, set back to zero by the last workgroup).
+constexpr int FINW_WG = 32;
+constexpr int GRAM_SCRATCH_BLOCKS = FINW_WG + 1;
+__global__ __launch_bounds__(WG) void k_finish_wide(const double* __restrict__ partials, int nblk, int npan, int ts,
+                                                    int a_lo, int a_hi, int nb, double* out, int ld_out,
+                                                    double* scratch, int t, int T, double* __restrict__ mu,
+                                                    double* __restrict__ alpha, int* __restrict__ info,
+                                                    const double* __restrict__ rtr, int rtr_nblk, int rtr_nc,
+                                                    double* __restrict__ res2) {
+  __shared__ double red[512];
+  __shared__ int s_last;
+  const int NB = npan * ts * ts;                 // doubles per partial block (128, 256 or 512)
+  const int tid = threadIdx.x;
+  const int lpb = NB < WG ? NB : WG;             // lanes that cover one block side by side
+  const int nsl = WG / lpb, ept = NB / lpb;      // blocks side by side; elements per lane (1 or 2)
+  const int l = tid % lpb, sl = tid / lpb;
+  const int per = (nblk + FINW_WG - 1) / FINW_WG;
+  const int b0 = blockIdx.x * per, b1 = min(nblk, b0 + per);
+  double acc[2] = {0.0, 0.0};
+  for (int b = b0 + sl; b < b1; b += nsl) {
+    const double* __restrict__ q = partials + (size_t)b * NB + l;
+    acc[0] += q[0];
+    if (ept > 1) acc[1] += q[lpb];
+  }
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (size_t)FINW_WG * NB);
+  // the side-by-side slices of this workgroup (up to four), then the share
+  if (nsl > 1) {
+    if (sl > 0) red[(sl - 1) * lpb + l] = acc[0];
+    __syncthreads();
+    if (sl == 0) for (int k = 1; k < nsl; ++k) acc[0] += red[(k - 1) * lpb + l];
+  }
+  if (sl == 0) {
+    __hip_atomic_store(scratch + (size_t)blockIdx.x * NB + l, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ept > 1) __hip_atomic_store(scratch + (size_t)blockIdx.x * NB + lpb + l, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
+  __syncthreads();
+  if (!s_last) return;
+  {
+    // every share, in order: the two halves of the workgroup take 32 shares each when a block is 128 doubles
+    double tot[2] = {0.0, 0.0};
+    const int g0 = sl * (FINW_WG / nsl), g1 = g0 + FINW_WG / nsl;
+    // (sixteen / eight shares at a time, all loads of a round in flight: a device-scope load is a trip to memory)
+    int g = g0;
+    for (; g + 16 <= g1; g += 16) {
+      double v[16][2];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        v[u][0] = __hip_atomic_load(scratch + (size_t)(g + u) * NB + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[u][1] = ept > 1 ? __hip_atomic_load(scratch + (size_t)(g + u) * NB + lpb + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { tot[0] += v[u][0]; tot[1] += v[u][1]; }
+    }
+    for (; g < g1; g += 8) {
+      double v[8][2];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u][0] = __hip_atomic_load(scratch + (size_t)(g + u) * NB + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[u][1] = ept > 1 ? __hip_atomic_load(scratch + (size_t)(g + u) * NB + lpb + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { tot[0] += v[u][0]; tot[1] += v[u][1]; }
+    }
+    __syncthreads();
+    if (nsl > 1 && sl > 0) red[(sl - 1) * lpb + l] = tot[0];
+    __syncthreads();
+    if (sl == 0) {
+      for (int k = 1; k < nsl; ++k) tot[0] += red[(k - 1) * lpb + l];
+      // element e of the partial block = (row, column) of [panel 0 | panel 1]^T B: scatter the active part
+      const int ldp = npan * ts, na = a_lo + a_hi;
+#pragma unroll
+      for (int qx = 0; qx < 2; ++qx) {
+        if (qx < ept) {
+          const int e = l + qx * lpb, r = e % ldp, j = e / ldp;
+          const int i = r < ts ? (r < a_lo ? r : -1) : (r - ts < a_hi ? a_lo + (r - ts) : -1);
+          if (i >= 0 && j < nb && i < na) out[i + (size_t)ld_out * j] = tot[qx];
+        }
+      }
+    }
+  }
+  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t > 0) {
+    __threadfence_block();
+    __syncthreads();
+    potrf_alpha_wg(out, t, T, mu, alpha, info, red, red + 256);
+  }
+  if (rtr) {
+    __syncthreads();
+    trace_finish_wg(rtr, rtr_nblk, ts, rtr_nc, res2, info, nullptr, red);
+  }
+}
+
 // The [W ; G^T] block of 4-column panels (8 x 4) from many partial blocks (one per workgroup of
 // the SpMM that formed them; 1 MB on the headline problem, which one workgroup needs 24 us to
 // read): FIN32_WG workgroups sum a contiguous share each (32-byte loads, 32 blocks side by
@@ -1333,6 +1435,11 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_h
       const int k = 4 * s2 + hi;
       b0[s2] = sc[1024 + k + 16 * lo]; b1[s2] = -sc[1280 + k + 16 * lo]; b2[s2] = -sc[1536 + k + 16 * lo];
     }
+    // (Z is read in the A-operand layout like V0 / V1 -- lane = row, four columns 32 B apart: 16 lines per load --
+    // which makes this kernel 129 us against 94 us for the in-place form at 16 columns; bringing the tiles in as
+    // whole rows and turning them through a padded LDS tile per wavefront was measured at 193 us: the round trip
+    // serialises the tiles of a wavefront.  The lazy form still wins 34 us per iteration at 16 columns because
+    // k_trsm_update_mfma loses its two panel writes: 178 -> 137 us.)
     for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
       const size_t r0 = t << 4, arow = r0 + lo;
       const bool aok = arow < (size_t)m;
@@ -2758,7 +2865,8 @@ static int nd_launch_bwd(const nd_args& a, const int* cfront, const int* ccol0, 
 extern "C" {
 
 int pa_bj_max_R(void) { return 8; }
-int pa_gram_max_blocks(void) { return GRAM_MAX_BLOCKS; }
+/* partial blocks a Gram buffer must hold: the kernels' grid cap + the shares and the ticket of k_finish_wide */
+int pa_gram_max_blocks(void) { return GRAM_MAX_BLOCKS + GRAM_SCRATCH_BLOCKS; }
 
 void pa_k_note_seq(double seq) { g_note_seq = seq; }
 
@@ -2810,12 +2918,30 @@ int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B
   return kfail("k_gram");
 }
 
+/* The sum of wide partial blocks by FINW_WG workgroups (k_finish_wide); the shares and the ticket lie behind the
+ * GRAM_MAX_BLOCKS partial blocks of the buffer (pa_gram_max_blocks() counts them in). */
+static int finish_wide(const double* partials, int nblk, int npan, int ts, int a_lo, int a_hi, int nb, double* out,
+                       int ld_out, int t, int T, double* mu, double* alpha, int* info, const double* rtr, int rtr_nblk,
+                       int rtr_nc, double* res2) {
+  double* scratch = const_cast<double*>(partials) + (size_t)GRAM_MAX_BLOCKS * 2 * ts * ts;
+  PA_LAUNCH(k_finish_wide, dim3(FINW_WG), dim3(WG), 0, cur_stream(), partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out,
+            scratch, t, T, mu, alpha, info, rtr, rtr_nblk, rtr_nc, res2);
+  return kfail("k_finish_wide");
+}
+
 int pa_k_gram_finish(int m, int ts, const double* A0, const double* A1, const double* B,
                      double* partials, int a_lo, int a_hi, int nb, double* out, int ld_out, int t,
                      int T, double* mu, double* alpha, int* info) {
   int nblk = 0;
   if ((a_lo + a_hi) * nb <= 0) return 0;
   if (pa_k_gram(m, ts, A0, A1, B, partials, &nblk)) return 1;
+  if (ts >= 8) {
+    if (t > 0 && (a_lo != t || a_hi != T || nb != t || ld_out != t + T || !A1)) {
+      snprintf(g_kerr, sizeof(g_kerr), "pa_k_gram_finish: [W ; G^T] layout expected");
+      return 1;
+    }
+    return finish_wide(partials, nblk, A1 ? 2 : 1, ts, a_lo, a_hi, nb, out, ld_out, t, T, mu, alpha, info, nullptr, 0, 0, nullptr);
+  }
   if (t > 0) {
     if (a_lo != t || a_hi != T || nb != t || ld_out != t + T || !A1) {
       snprintf(g_kerr, sizeof(g_kerr), "pa_k_gram_finish: [W ; G^T] layout expected");
@@ -2837,6 +2963,11 @@ int pa_k_gram_finish_trace(int m, int ts, const double* A0, const double* A1, co
                            int rtr_nblk, int nc, double* res2, const int* info) {
   int nblk = 0;
   const int ne = (a_lo + a_hi) * nb;
+  if (ne > 0 && ts >= 8) {     /* wide blocks: several workgroups sum, the last one adds the norm */
+    if (pa_k_gram(m, ts, A0, A1, B, partials, &nblk)) return 1;
+    return finish_wide(partials, nblk, A1 ? 2 : 1, ts, a_lo, a_hi, nb, out, ld_out, 0, 0, nullptr, nullptr, const_cast<int*>(info),
+                       rtr_partials, rtr_nblk, nc, res2);
+  }
   if (ne <= 0 || ne > 128)     /* no Gram block, or one that several workgroups sum: the two launches */
     return pa_k_trace_finish(rtr_partials, rtr_nblk, ts, nc, res2, info, NULL) ||
            pa_k_gram_finish(m, ts, A0, A1, B, partials, a_lo, a_hi, nb, out, ld_out, 0, 0, NULL, NULL, NULL);
