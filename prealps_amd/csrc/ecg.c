@@ -193,7 +193,7 @@ static void request_gram_from_spmm(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
       ecg->ortho_alg != ORTHODIR_FUSED && ecg->enlFac == 4 && ecg->P->info.n == 4)
     pa_k_spmm_gram_arm(ecg->P->val, ecg->AP->val, pv->d_R, pv->d_spmm_parts, pv->spmm_cap);
   else
-    pa_k_spmm_gram_disarm();
+    pa_k_spmm_gram_disarm(pv->d_spmm_parts);
 }
 
 /* ------------------------------------------------------------- reset ---- */
@@ -719,7 +719,7 @@ int _preAlps_ECGIterateOdir(preAlps_ECG_t* ecg, int* rci_request) {
       if ((g_own_loop > 0 || rci_fuse()) && pv->bj_cap > 0 && t == 4 && ecg->beta->info.m == 8 &&
           ecg->beta->info.lda == 8 && ecg->beta->info.n == 4)
         pa_k_bj_gram_arm(pv->buf_av[0], pv->buf_z, pv->buf_av[1], pv->d_bj_parts, pv->bj_cap);
-      else pa_k_bj_gram_disarm();
+      else pa_k_bj_gram_disarm(pv->d_bj_parts);
     } else {
       if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
       if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0)) return 1;
@@ -879,8 +879,9 @@ int _preAlps_ECGWrapUp(preAlps_ECG_t* ecg, double* solution) {
 void _preAlps_ECGFree(preAlps_ECG_t* ecg) {
   ecg_priv_t* pv = priv_of(ecg);
   if (pv) {
-    pa_k_spmm_gram_disarm();
-    pa_k_bj_gram_disarm();
+    /* (only this object's requests: another solver's may be armed) */
+    if (pv->d_spmm_parts) pa_k_spmm_gram_disarm(pv->d_spmm_parts);
+    if (pv->d_bj_parts) pa_k_bj_gram_disarm(pv->d_bj_parts);
     pa_rt_sync();
     pa_rt_free(pv->d_info);
     pa_rt_host_free(pv->h_pin);
@@ -937,7 +938,7 @@ void preAlps_ECGPrint(preAlps_ECG_t* ecg, int verbosity) {
 static int ecg_solve_loop(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_hist, int* bs_hist,
                           int max_hist, int* n_hist);
 static void leave_own_loop(void) {
-  if (--g_own_loop == 0) { pa_k_spmm_gram_disarm(); pa_k_bj_gram_disarm(); }
+  if (--g_own_loop == 0) { pa_k_spmm_gram_disarm(NULL); pa_k_bj_gram_disarm(NULL); }
 }
 int preAlps_ECGSolve(preAlps_ECG_t* ecg, double* rhs, double* sol, double* res_hist, int* bs_hist,
                      int max_hist, int* n_hist) {

@@ -727,7 +727,6 @@ __global__ __launch_bounds__(WG) void k_finish_wide(const double* __restrict__ p
 // side, fixed order) into scratch; the last one to finish (ticket counter) adds
 // the shares in order and, t > 0, factors and forms alpha as k_finish_potrf_alpha does.
 constexpr int FIN32_WG = 64;
-__device__ unsigned g_fin32_ticket = 0;
 __global__ __launch_bounds__(WG) void k_finish32(const double* __restrict__ partials, int nblk,
                                                  double* scratch, int t, int T, double* out,
                                                  double* __restrict__ mu, double* __restrict__ alpha,
@@ -762,7 +761,10 @@ __global__ __launch_bounds__(WG) void k_finish32(const double* __restrict__ part
   // costs 10 us on gfx950 even when the L2 holds nothing dirty
   if (tid < 32) __hip_atomic_store(scratch + blockIdx.x * 32 + tid, red[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (tid == 0) s_last = (__hip_atomic_fetch_add(&g_fin32_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
+  // (the ticket lives behind the shares of THIS call's scratch -- zero when the buffer is made, set back by the
+  // last workgroup -- so that two solver objects, or two streams, never elect across each other's launches)
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch + FIN32_WG * 32);
+  if (tid == 0) s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
   __syncthreads();
   if (!s_last) return;
   {
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(WG) void k_finish32(const double* __restrict__ part
     for (int g = 1; g < 8; ++g) tot += red[g * 32 + tid];
     out[tid] = tot;
   }
-  if (tid == 0) __hip_atomic_store(&g_fin32_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (t > 0) {
     __threadfence_block();
     __syncthreads();
@@ -2870,7 +2872,7 @@ int pa_gram_max_blocks(void) { return GRAM_MAX_BLOCKS + GRAM_SCRATCH_BLOCKS; }
 
 void pa_k_note_seq(double seq) { g_note_seq = seq; }
 
-int pa_finish32_scratch_blocks(void) { return FIN32_WG; }
+int pa_finish32_scratch_blocks(void) { return FIN32_WG + 1; }     /* the shares + the block that holds the ticket */
 
 int pa_k_finish32(const double* partials, int nblk, double* scratch, int t, int T, double* out, double* mu,
                   double* alpha, int* info) {
@@ -3194,7 +3196,7 @@ void pa_k_bj_gram_arm(const double* in, const double* out, const double* prev, d
 }
 static long long g_bg_applies = 0;
 long long pa_k_bj_gram_applies(void) { return g_bg_applies; }
-void pa_k_bj_gram_disarm(void) { g_bg.armed = 0; g_bg.count = 0; }
+void pa_k_bj_gram_disarm(const double* owner) { if (!owner || owner == g_bg.partials) { g_bg.armed = 0; g_bg.count = 0; } }
 int pa_k_bj_gram_take(const double* in, const double* out) {
   if (!g_bg.armed || in != g_bg.in || out != g_bg.out) return 0;
   const int n = g_bg.count;

@@ -808,7 +808,7 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
       const char* le = nl ? nl : cut[t + 1];
       const char* q = p;
       while (q < le && (*q == ' ' || *q == '\t' || *q == '\r')) ++q;
-      if (q < le) ++n;
+      if (q < le && *q != '%') ++n;           /* (blank lines and comment lines inside the body do not count) */
       p = nl ? nl + 1 : cut[t + 1];
     }
     first[t + 1] = n;
@@ -827,6 +827,11 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
         while (q < cut[t + 1] && (*q == ' ' || *q == '\t' || *q == '\r')) ++q;
         if (q < cut[t + 1] && *q == '\n') { p = q + 1; continue; }
         if (q >= cut[t + 1]) break;
+        if (*q == '%') {                         /* a comment line in the body: skipped */
+          const char* nl = (const char*)memchr(q, '\n', (size_t)(cut[t + 1] - q));
+          p = nl ? nl + 1 : cut[t + 1];
+          continue;
+        }
         p = mm_parse_line(q, cut[t + 1], &I[k], &J[k], &V[k]);
         if (!p) {
 #pragma omp critical
@@ -890,6 +895,7 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
   /* sort every row by column (stable), sum repeated entries, compact */
   int* len = (int*)malloc((size_t)M * sizeof(int));
   if (!len) { free(ent); free(rp); return PA_FAIL("out of host memory"); }
+  int no_mem = 0;        /* a thread could not get its sort buffer: the rows it met stay unsorted, the build fails */
 #pragma omp parallel num_threads(pa_host_threads())
   {
     int cap = 256;
@@ -897,9 +903,13 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
 #pragma omp for schedule(dynamic, 1024)
     for (int i = 0; i < M; ++i) {
       int k0 = rp[i], n = rp[i + 1] - k0;
-      if (n / 2 + 1 > cap) { cap = n; free(tmp); tmp = (mm_ent_t*)malloc((size_t)cap * sizeof(mm_ent_t)); }
+      if (n / 2 + 1 > cap || !tmp) { cap = n > cap ? n : cap; free(tmp); tmp = (mm_ent_t*)malloc((size_t)cap * sizeof(mm_ent_t)); }
       int sorted = 1;
       for (int k = 1; k < n && sorted; ++k) sorted = ent[k0 + k - 1].c <= ent[k0 + k].c;
+      if (!sorted && !tmp) {
+#pragma omp atomic write
+        no_mem = 1;
+      }
       if (!sorted && tmp) mm_sort_row(ent + k0, n, tmp);
       int out = 0;
       for (int k = 0; k < n; ++k) {
@@ -910,6 +920,7 @@ static int load_mtx(const char* file, int* N_out, int** rp_out, int** ci_out, do
     }
     free(tmp);
   }
+  if (no_mem) { free(len); free(ent); free(rp); return PA_FAIL("out of host memory while sorting the rows of %s", file); }
   int* rp2 = (int*)malloc(((size_t)M + 1) * sizeof(int));
   long long out = 0;
   for (int i = 0; rp2 && i < M; ++i) { rp2[i] = (int)out; out += len[i]; }

@@ -105,7 +105,7 @@ int pa_k_spmm(const pa_spmm_plan_t* pl, int ts, const double* X, const double* X
  * without them) and ends the request; pa_k_finish32 sums them (t > 0: and factors, as
  * pa_k_gram_finish does). */
 void pa_k_spmm_gram_arm(const double* X, const double* Y, const double* R, double* partials, int cap);
-void pa_k_spmm_gram_disarm(void);
+void pa_k_spmm_gram_disarm(const double* owner);   /* owner: the request's partials (only that request ends); NULL: any */
 long long pa_k_spmm_gram_launches(void);   /* launches of the SpMM with the Gram block so far */
 int pa_k_spmm_gram_take(const double* X, const double* Y);
 int pa_k_finish32(const double* partials, int nblk, double* scratch, int t, int T, double* out, double* mu,
@@ -117,7 +117,7 @@ int pa_k_finish32_trace(const double* partials, int nblk, double* scratch, doubl
 /* Ask the next block solve in -> out on a 4-column panel (every block through bj_g4.hip) to leave the partial
  * blocks of [in | prev]^T out behind, one per block; pa_k_bj_gram_take: how many there are (0: none). */
 void pa_k_bj_gram_arm(const double* in, const double* out, const double* prev, double* partials, int cap);
-void pa_k_bj_gram_disarm(void);
+void pa_k_bj_gram_disarm(const double* owner);
 long long pa_k_bj_gram_applies(void);        /* block solves that left the Gram block behind so far */
 int pa_k_bj_gram_take(const double* in, const double* out);
 /* sendbuf[i*ts + c] = X[idx[i]*ts + c] */

@@ -554,7 +554,9 @@ void pa_k_spmm_gram_arm(const double* X, const double* Y, const double* R, doubl
 
 long long pa_k_spmm_gram_launches(void) { return g_sg_launches; }
 
-void pa_k_spmm_gram_disarm(void) { g_sg.armed = 0; g_sg.count = 0; }
+/* owner = the partial-block buffer of the request (every solver object has its own): only that object's request
+ * is ended; NULL ends whatever is armed */
+void pa_k_spmm_gram_disarm(const double* owner) { if (!owner || owner == g_sg.partials) { g_sg.armed = 0; g_sg.count = 0; } }
 
 /* The number of partial blocks the armed products X -> Y have left since the request (0: none,
  * or the operator was applied with another kernel); the request stays armed for the same pointers. */

@@ -49,7 +49,7 @@ def _spd(n, seed, density=0.01):
     return sp.csr_matrix(A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0))
 
 
-@pytest.mark.parametrize("style", ["general", "symmetric", "zero_based", "crlf_blank_no_final_newline", "duplicates"])
+@pytest.mark.parametrize("style", ["general", "symmetric", "zero_based", "crlf_blank_no_final_newline", "duplicates", "comments_in_body"])
 def test_reader_matches_scipy(tmp_path, style):
     A = _spd(300, 1)
     coo = sp.coo_matrix(A)
@@ -72,6 +72,10 @@ def test_reader_matches_scipy(tmp_path, style):
         f.write("% a comment" + eol)
         f.write("%d %d %d%s" % (A.shape[0], A.shape[1], len(vals), eol))
         lines = ["%d %d %.17g" % (r + base, c + base, x) for r, c, x in zip(rows, cols, vals)]
+        if style == "comments_in_body":            # '%' lines between the entries: skipped, not counted
+            lines.insert(3, "% a remark in the middle")
+            lines.insert(40, "  % and an indented one")
+            lines.append("% and one at the end")
         if style == "crlf_blank_no_final_newline":
             lines.insert(5, "")
             f.write(eol.join(lines))

@@ -28,7 +28,7 @@ def time_spmm(armed, reps=20):
     for i in range(reps + 3):
         check(L.preAlps_BlockJacobiApply(C.byref(dx), C.byref(dy)), "bj")
         if armed: lib.pa_k_spmm_gram_arm(px, py, pr, parts, nblk)
-        else: lib.pa_k_spmm_gram_disarm()
+        else: lib.pa_k_spmm_gram_disarm(None)
         check(L.preAlps_hip_timer_start(), "ts")
         check(L.preAlps_BlockOperator(C.byref(dx), C.byref(dy)), "op")
         check(L.preAlps_hip_timer_stop(C.byref(sec)), "te")
@@ -37,5 +37,5 @@ def time_spmm(armed, reps=20):
 for rnd in range(4):
     a, b = time_spmm(False), time_spmm(True)
     print("round %d: plain %.1f us, with the Gram block %.1f us (+%.1f)" % (rnd, a, b, b - a), flush=True)
-lib.pa_k_spmm_gram_disarm()
+lib.pa_k_spmm_gram_disarm(None)
 prob.close()
