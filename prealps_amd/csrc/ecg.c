@@ -192,7 +192,7 @@ static void request_gram_from_spmm(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   if ((g_own_loop > 0 || rci_fuse()) && pv->spmm_cap > 0 && pv->fuse && ecg->bs_red == NO_BS_RED &&
       ecg->ortho_alg != ORTHODIR_FUSED && ecg->enlFac == 4 && ecg->P->info.n == 4)
     pa_k_spmm_gram_arm(ecg->P->val, ecg->AP->val, pv->d_R, pv->d_spmm_parts, pv->spmm_cap);
-  else
+  else if (pv->d_spmm_parts)
     pa_k_spmm_gram_disarm(pv->d_spmm_parts);
 }
 
@@ -719,7 +719,7 @@ int _preAlps_ECGIterateOdir(preAlps_ECG_t* ecg, int* rci_request) {
       if ((g_own_loop > 0 || rci_fuse()) && pv->bj_cap > 0 && t == 4 && ecg->beta->info.m == 8 &&
           ecg->beta->info.lda == 8 && ecg->beta->info.n == 4)
         pa_k_bj_gram_arm(pv->buf_av[0], pv->buf_z, pv->buf_av[1], pv->d_bj_parts, pv->bj_cap);
-      else pa_k_bj_gram_disarm(pv->d_bj_parts);
+      else if (pv->d_bj_parts) pa_k_bj_gram_disarm(pv->d_bj_parts);
     } else {
       if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
       if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0)) return 1;
