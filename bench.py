@@ -377,7 +377,7 @@ def main():
                    "setup_breakdown_s": {k: prob.stat("setup_" + k + "_s") for k in ("build", "plan", "bj_factor", "bj_layout")},
                    "bj_max_bandwidth": int(prob.stat("bj_max_bandwidth")),
                    "spmm_blocks": int(prob.stat("spmm_blocks"))},
-        "roofline": {"kernel": "k_spmm_runs_gram" if with_gram else ("k_spmm_runs" if prob.stat("spmm_runs") else ("k_spmm_staged" if prob.stat("spmm_staged") else "k_spmm")), "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": ("k_spmm_runs_gram" if prob.stat("spmm_runs") else "k_spmm_gram") if with_gram else ("k_spmm_runs" if prob.stat("spmm_runs") else ("k_spmm_staged" if prob.stat("spmm_staged") else "k_spmm")), "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": spmm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s,
                      "back_to_back_launch_us": 1e6 * spmm_b2b_s,
