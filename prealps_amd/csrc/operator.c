@@ -177,7 +177,12 @@ static int build_plan(pa_operator_t* o, int ts) {
     if (rc < 0) return 1;
     if (rc == 0) {
       double ext_bytes = (o->stream_bytes - 10.0 * o->sell_entries) / 4.0 * ts * 8.0;
-      if (want > 0 || ext_bytes < 0.25 * 10.0 * o->sell_entries) { o->plan_ts = ts; return 0; }
+      /* round 4: at up to 4 columns the staged kernel (batched staging, its Gram block in the epilogue) is worth
+       * it up to external rows of half the matrix slice: 7-point Poisson 100^3 (38 %) 226.6 -> 221.6 us per
+       * iteration against the window kernel, although the plain product alone is 3 us slower
+       * (tools/probe/r4_poisson_plan_ab.py); wider panels keep the quarter */
+      const double thr = ts <= 4 ? 0.5 : 0.25;
+      if (want > 0 || ext_bytes < thr * 10.0 * o->sell_entries) { o->plan_ts = ts; return 0; }
     }
     free_plan(o); /* too many rows to stage, or not worth it: use the general kernel */
   }
@@ -1253,7 +1258,6 @@ int pa_operator_gram_blocks(int ts) {
   pa_operator_t* o = &g_op;
   if (!o->info.built || g_plan_only || ts != 4) return 0;
   if (o->plan_ts != ts && build_plan(o, ts)) return 0;
-  if (o->plan.staged && !o->plan.runs) return 0;            /* (the staged plan has no such kernel) */
   /* Default: on, from absolute times of 800-iteration solves alternating in one process.  The window kernel
    * (k_spmm_gram; Poisson 100^3): 245.3 -> 236.9 us per iteration with the block (round 3, tools/probe/abs_ab.py).
    * The run kernel (k_spmm_runs_gram; elasticity 70^3): no gain in round 3 (397.0 -> 399.0 us: its epilogue and

@@ -160,62 +160,6 @@ __global__ __launch_bounds__(WG) void k_spmm_gram(
                             X, Xh, Y, Rg, gpart, gbase);
 }
 
-// Staged SELL-64 SpMM: the block first copies every X row it will touch into
-// LDS (own rows as one coalesced range, then the listed neighbour / halo rows,
-// 16 B per lane), so the inner loop is branch-free: one coalesced 8-B value,
-// one coalesced 2-B LDS slot, TS/2 ds_read_b128 and TS FMAs per nonzero, and
-// the matrix stream shrinks from 12 to 10 bytes per nonzero.
-template <int TS>
-__global__ __launch_bounds__(WG) void k_spmm_staged(
-    int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
-    const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
-    const unsigned short* __restrict__ col16, const double* __restrict__ val,
-    const int* __restrict__ blk_slice, const int* __restrict__ blk_ext_off,
-    const int* __restrict__ ext_rows, const int* __restrict__ order, int nlist,
-    const double* __restrict__ X, const double* __restrict__ Xh, double* __restrict__ Y) {
-  extern __shared__ double sx[];
-  const int cpx = (nlist + 7) >> 3;
-  const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-  if (logical >= nlist) return;
-  const int b = order[logical];
-  const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
-  const int r0 = sl_row0[s0];
-  const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
-  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0;
-  const int tid = threadIdx.x;
-  constexpr int H = TS / 2;  // double2 per row
-  {
-    const double2* xsrc = reinterpret_cast<const double2*>(X + (size_t)r0 * TS);
-    double2* dst = reinterpret_cast<double2*>(sx);
-    for (int i = tid; i < nown * H; i += WG) dst[i] = xsrc[i];
-    for (int q = tid; q < next * H; q += WG) {
-      const int i = q / H, j = q - i * H;
-      const int id = ext_rows[e0 + i];
-      const double2* src = reinterpret_cast<const double2*>(id < m ? X + (size_t)id * TS
-                                                                     : Xh + (size_t)(id - m) * TS);
-      dst[(size_t)(nown + i) * H + j] = src[j];
-    }
-  }
-  __syncthreads();
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  for (int s = s0 + wave; s < s1; s += WG / 64) {
-    const long long off = sl_off[s];
-    const int len = sl_len[s];
-    const unsigned short* __restrict__ cp = col16 + off + lane;
-    const double* __restrict__ vp = val + off + lane;
-    double acc[TS];
-#pragma unroll
-    for (int c = 0; c < TS; ++c) acc[c] = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < len; ++k) {
-      const double v = vp[(size_t)k * 64];
-      const int slot = cp[(size_t)k * 64];
-      spmm_fma_row<TS>(acc, v, sx + (size_t)slot * TS);
-    }
-    if (lane < sl_nrows[s]) store_row<TS>(Y, (size_t)(sl_row0[s] + lane), acc);
-  }
-}
-
 // Staged SpMM over runs of three consecutive LDS slots (rows whose nonzeros sit in groups
 // of neighbouring columns, e.g. the 3 dofs of a node): per run one coalesced 2-B slot, three
 // coalesced 8-B values and 3*TS/2 ds_read_b128 off one address -- 8.67 B of matrix stream
@@ -232,42 +176,45 @@ __global__ __launch_bounds__(WG) void k_spmm_staged(
 // staging area: a 4 x 4 transpose inside each quad of lanes puts 16 rows x 4 columns into the
 // operand layout of v_mfma_f64_4x4x4 (lane 4g + c = column c of row g), four of which cover the
 // 64 rows of a slice; R is read in that layout directly.
-// One group of RU runs of a slice: RU slots and 3 RU values per lane, all coalesced.  `g` is clamped by the
-// caller, so that the loads are unconditional (a conditional load makes the compiler's wait-count
-// bookkeeping join two histories at the next use, and the join waits for everything in flight); a run
-// beyond the slice's last one takes that one's slot and its values from a block of zeros -- the choice is
-// between two scalar addresses, the vector code is the same for every group.
-constexpr int RU = 3;     // runs per group: 12 loads; 1, 2 and 4 measured the same (profiles/r04_spmm_variants_ab.txt)
+// One group of a slice's entries: RU(RL) slots and RL values per slot for every lane, all coalesced (RL = 3: runs of
+// three consecutive staged rows; RL = 1: one staged row per slot -- the staged plan of matrices without such
+// runs).  `g` is clamped by the caller, so that the loads are unconditional (a conditional load makes the
+// compiler's wait-count bookkeeping join two histories at the next use, and the join waits for everything in
+// flight); an entry beyond the slice's last one takes that one's slot and its values from a block of zeros -- the
+// choice is between two scalar addresses, the vector code is the same for every group.
+template <int RL> struct spmm_ru { static constexpr int n = RL == 3 ? 3 : 6; };     // 12 loads per group either way
+// (1, 2 and 4 runs per group measured the same as 3: profiles/r04_spmm_variants_ab.txt)
 __device__ const double g_zero_run[192] = {0.0};
+template <int RL>
 __device__ __forceinline__ void spmm_runs_load(const unsigned short* __restrict__ cp, const double* __restrict__ vp,
-                                               unsigned lane, int g, int len, int (&sl)[RU], double (&vv)[3 * RU]) {
-  // cp / vp: the slice's slots and values, wavefront-uniform; the run index is uniform too, so every address
+                                               unsigned lane, int g, int len, int (&sl)[spmm_ru<RL>::n],
+                                               double (&vv)[RL * spmm_ru<RL>::n]) {
+  constexpr int RU = spmm_ru<RL>::n;
+  // cp / vp: the slice's slots and values, wavefront-uniform; the entry index is uniform too, so every address
   // is a scalar base plus the lane
 #pragma unroll
   for (int j = 0; j < RU; ++j) {
     const int k = g * RU + j, kc = min(k, len - 1);
     const unsigned short* __restrict__ ck = cp + (size_t)kc * 64;
     typedef const __attribute__((address_space(1))) double* gdp;     // (a select of two pointers would go flat)
-    const gdp vk = k < len ? (gdp)(vp + (size_t)(3 * k) * 64) : (gdp)g_zero_run;
+    const gdp vk = k < len ? (gdp)(vp + (size_t)(RL * k) * 64) : (gdp)g_zero_run;
     sl[j] = ck[lane];
-    vv[3 * j] = vk[lane];
-    vv[3 * j + 1] = vk[64 + lane];
-    vv[3 * j + 2] = vk[128 + lane];
+#pragma unroll
+    for (int i = 0; i < RL; ++i) vv[RL * j + i] = vk[64 * i + lane];
   }
 }
-template <int TS>
-__device__ __forceinline__ void spmm_runs_fma(const double* sx, const int (&sl)[RU], const double (&vv)[3 * RU],
-                                              double (&acc)[TS]) {
+template <int TS, int RL>
+__device__ __forceinline__ void spmm_runs_fma(const double* sx, const int (&sl)[spmm_ru<RL>::n],
+                                              const double (&vv)[RL * spmm_ru<RL>::n], double (&acc)[TS]) {
 #pragma unroll
-  for (int j = 0; j < RU; ++j) {
+  for (int j = 0; j < spmm_ru<RL>::n; ++j) {
     const double* __restrict__ xr = sx + (size_t)sl[j] * TS;
-    spmm_fma_row<TS>(acc, vv[3 * j], xr);
-    spmm_fma_row<TS>(acc, vv[3 * j + 1], xr + TS);
-    spmm_fma_row<TS>(acc, vv[3 * j + 2], xr + 2 * TS);
+#pragma unroll
+    for (int i = 0; i < RL; ++i) spmm_fma_row<TS>(acc, vv[RL * j + i], xr + i * TS);
   }
 }
 
-template <int TS, int XS, bool GRAM>
+template <int TS, int XS, bool GRAM, int RL>
 __device__ __forceinline__ void spmm_runs_block(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -278,7 +225,7 @@ __device__ __forceinline__ void spmm_runs_block(
     const double* __restrict__ Xh, double* __restrict__ Y,
     const double* __restrict__ Rg, double* __restrict__ gpart, int gbase, int logical, int coff);
 
-template <int TS, int XS, bool GRAM>
+template <int TS, int XS, bool GRAM, int RL = 3>
 __device__ __forceinline__ void spmm_runs_body(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -293,12 +240,12 @@ __device__ __forceinline__ void spmm_runs_body(
   const int idx = blockIdx.x >> 3;
   const int logical = (blockIdx.x & 7) * cpx + idx / NS;
   if (logical >= nlist) return;
-  spmm_runs_block<TS, XS, GRAM>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+  spmm_runs_block<TS, XS, GRAM, RL>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
                                          ext_rows, order, X, Xh, Y, Rg, gpart, gbase, logical, (idx % NS) * TS);
 }
 
 // One block of slices: `logical` = its place in the launch's list, `coff` = first of the TS columns.
-template <int TS, int XS, bool GRAM>
+template <int TS, int XS, bool GRAM, int RL>
 __device__ __forceinline__ void spmm_runs_block(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -314,7 +261,7 @@ __device__ __forceinline__ void spmm_runs_block(
   const int s0 = blk_slice[b], s1 = blk_slice[b + 1];
   const int r0 = sl_row0[s0];
   const int nown = sl_row0[s1 - 1] + sl_nrows[s1 - 1] - r0;
-  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0, nlow = blk_nlow[b];
+  const int e0 = blk_ext_off[b], next = blk_ext_off[b + 1] - e0, nlow = blk_nlow ? blk_nlow[b] : 0;
   const int tid = threadIdx.x;
   // (the wavefront's number as a scalar: the slice loop and everything indexed by it stay in SGPRs)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -323,8 +270,9 @@ __device__ __forceinline__ void spmm_runs_block(
   // The matrix stream of the wavefront's first slice is requested BEFORE the staging of X: its first group
   // is on its way while the rows are gathered (two dependent memory latencies) and the workgroup meets at
   // the barrier.
+  constexpr int RU = spmm_ru<RL>::n;
   int slA[RU], slB[RU];
-  double vA[3 * RU], vB[3 * RU];
+  double vA[RL * RU], vB[RL * RU];
   int s = s0 + wave;
   int len = 0;
   const unsigned short* __restrict__ cp = slot16;
@@ -333,8 +281,8 @@ __device__ __forceinline__ void spmm_runs_block(
     const long long off = sl_off[s];
     len = sl_len[s];
     cp = slot16 + off;
-    vp = val + 3 * off;
-    if (len > 0) spmm_runs_load(cp, vp, lane, 0, len, slA, vA);
+    vp = val + RL * off;
+    if (len > 0) spmm_runs_load<RL>(cp, vp, lane, 0, len, slA, vA);
   }
 
   // Staging: LDS row L of [external rows below | own rows | external rows above] comes from global row
@@ -365,7 +313,7 @@ __device__ __forceinline__ void spmm_runs_block(
 #pragma unroll
       for (int it = 0; it < SB; ++it) dst[(size_t)L[it] * H + j] = v[it];
     }
-    if (tid < 2 * H) dst[(size_t)nst * H + tid] = make_double2(0.0, 0.0);
+    if constexpr (RL == 3) { if (tid < 2 * H) dst[(size_t)nst * H + tid] = make_double2(0.0, 0.0); }    // (a run may reach two rows past the last one)
   }
   __syncthreads();
   double gw = 0.0, gg = 0.0;      // GRAM: D[i][j] of the lane's 4 x 4 block (lane = 16 i + 4 q + j)
@@ -384,16 +332,16 @@ __device__ __forceinline__ void spmm_runs_block(
       // (one exit at the bottom and the odd group behind the loop: with an exit in the middle the register
       // allocator copies the set that is in flight at the end of every round, behind a full wait)
       for (int i = 0; i < (ngt >> 1); ++i) {
-        spmm_runs_load(cp, vp, lane, 2 * i + 1, len, slB, vB);
+        spmm_runs_load<RL>(cp, vp, lane, 2 * i + 1, len, slB, vB);
         __builtin_amdgcn_sched_barrier(0);      // (keeps the requests in front of the sums of the group before)
-        spmm_runs_fma<TS>(sx, slA, vA, acc);
+        spmm_runs_fma<TS, RL>(sx, slA, vA, acc);
         __builtin_amdgcn_sched_barrier(0);
-        spmm_runs_load(cp, vp, lane, min(2 * i + 2, ngt - 1), len, slA, vA);
+        spmm_runs_load<RL>(cp, vp, lane, min(2 * i + 2, ngt - 1), len, slA, vA);
         __builtin_amdgcn_sched_barrier(0);
-        spmm_runs_fma<TS>(sx, slB, vB, acc);
+        spmm_runs_fma<TS, RL>(sx, slB, vB, acc);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (ngt & 1) spmm_runs_fma<TS>(sx, slA, vA, acc);
+      if (ngt & 1) spmm_runs_fma<TS, RL>(sx, slA, vA, acc);
     }
     const int nr = sl_nrows[s], row_s = sl_row0[s];
     if (lane < nr) {
@@ -410,8 +358,8 @@ __device__ __forceinline__ void spmm_runs_block(
       const long long off = sl_off[sn];
       len = sl_len[sn];
       cp = slot16 + off;
-      vp = val + 3 * off;
-      if (len > 0) spmm_runs_load(cp, vp, lane, 0, len, slA, vA);
+      vp = val + RL * off;
+      if (len > 0) spmm_runs_load<RL>(cp, vp, lane, 0, len, slA, vA);
     }
   }
   if constexpr (GRAM) spmm_gram_tail(gw, gg, sx, wave, lane, tid, gpart + (size_t)(gbase + logical) * 32);
@@ -419,7 +367,7 @@ __device__ __forceinline__ void spmm_runs_block(
 
 // (registers: five wavefronts per SIMD is what 32 KiB of staging per workgroup allow at 4 columns -- 96
 // VGPRs; the wider panels stage 48 KiB, three workgroups per CU)
-template <int TS, int XS>
+template <int TS, int XS, int RL = 3>
 __global__ __launch_bounds__(WG, (TS <= 4 ? 5 : 3)) void k_spmm_runs(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -428,11 +376,12 @@ __global__ __launch_bounds__(WG, (TS <= 4 ? 5 : 3)) void k_spmm_runs(
     const int* __restrict__ blk_nlow, const int* __restrict__ ext_rows,
     const int* __restrict__ order, int nlist, const double* __restrict__ X,
     const double* __restrict__ Xh, double* __restrict__ Y) {
-  spmm_runs_body<TS, XS, false>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
-                                ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
+  spmm_runs_body<TS, XS, false, RL>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+                                    ext_rows, order, nlist, X, Xh, Y, nullptr, nullptr, 0);
 }
 
 // 4 columns with the Gram block; five wavefronts per SIMD as k_spmm_runs<4, 4> (32 KiB of staging each)
+template <int RL>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_spmm_runs_gram(
     int m, const long long* __restrict__ sl_off, const int* __restrict__ sl_len,
     const int* __restrict__ sl_row0, const int* __restrict__ sl_nrows,
@@ -442,7 +391,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
     const int* __restrict__ order, int nlist, const double* __restrict__ X,
     const double* __restrict__ Xh, double* __restrict__ Y,
     const double* __restrict__ Rg, double* __restrict__ gpart, int gbase) {
-  spmm_runs_body<4, 4, true>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
+  spmm_runs_body<4, 4, true, RL>(m, sl_off, sl_len, sl_row0, sl_nrows, slot16, val, blk_slice, blk_ext_off, blk_nlow,
                              ext_rows, order, nlist, X, Xh, Y, Rg, gpart, gbase);
 }
 
@@ -471,12 +420,17 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
   if (nlist <= 0) return 0;
   if constexpr (TS == 4) {
     const size_t lds = (size_t)pl->stage_cap * TS * 8;
-    if (g_sg.armed && pl->runs && lds <= 64 * 1024 && X == g_sg.X && Y == g_sg.Y && g_sg.count >= 0 &&
+    if (g_sg.armed && (pl->runs || pl->staged) && lds <= 64 * 1024 && X == g_sg.X && Y == g_sg.Y && g_sg.count >= 0 &&
         g_sg.count + nlist <= g_sg.cap) {
       const int cpx = (nlist + 7) / 8;
-      PA_LAUNCH(k_spmm_runs_gram, dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
-                pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice, pl->blk_ext_off,
-                pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y, g_sg.R, g_sg.partials, g_sg.count);
+      if (pl->runs)
+        PA_LAUNCH(k_spmm_runs_gram<3>, dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                  pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice, pl->blk_ext_off,
+                  pl->blk_nlow, pl->ext_rows, order, nlist, X, Xh, Y, g_sg.R, g_sg.partials, g_sg.count);
+      else         // one staged row per slot (matrices without runs of three): no low / high split, no zero rows
+        PA_LAUNCH(k_spmm_runs_gram<1>, dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+                  pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice, pl->blk_ext_off,
+                  (const int*)nullptr, pl->ext_rows, order, nlist, X, Xh, Y, g_sg.R, g_sg.partials, g_sg.count);
       g_sg.count += nlist;
       ++g_sg_launches;
       return kfail("k_spmm_runs");
@@ -520,19 +474,20 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
     return kfail("k_spmm_runs");
   }
   if (pl->staged) {
+    // one staged row per slot: the same kernel with run length 1 (batched staging, double-buffered groups)
     const size_t lds = (size_t)pl->stage_cap * TS * 8;
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_staged<TS>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TS, TS, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return kfail("hipFuncSetAttribute(k_spmm_staged)");
+        return kfail("hipFuncSetAttribute(k_spmm_runs)");
       configured = lds;
     }
     const int cpx = (nlist + 7) / 8;
-    PA_LAUNCH((k_spmm_staged<TS>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
+    PA_LAUNCH((k_spmm_runs<TS, TS, 1>), dim3(cpx * 8), dim3(WG), lds, cur_stream(), pl->m, pl->sl_off,
                        pl->sl_len, pl->sl_row0, pl->sl_nrows, pl->col16, pl->val, pl->blk_slice,
-                       pl->blk_ext_off, pl->ext_rows, order, nlist, X, Xh, Y);
-    return kfail("k_spmm_staged");
+                       pl->blk_ext_off, (const int*)nullptr, pl->ext_rows, order, nlist, X, Xh, Y);
+    return kfail("k_spmm_runs");
   }
   // the X window shares the 160 KiB LDS of a CU with other workgroups: at most 32 KiB of rows
   int win_cap = pl->win_cap;
