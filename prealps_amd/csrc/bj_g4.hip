@@ -361,10 +361,152 @@ __device__ __forceinline__ void g4_bwd_tiles(double (&T)[NC * NT], int b, int w,
   }
 }
 
+// ---- few blocks: the group chain, software-pipelined -------------------------------------------------------
+// A GPU that holds fewer blocks than it has SIMDs (one of eight GPUs on the headline problem: 709) runs one
+// wavefront per SIMD, and the solve is a chain of 2 x b / 4 dependent group steps: operands from LDS (8 reads,
+// ~130 cycles), three dependent matrix instructions for the corner, a quad broadcast, the updates.  Here the
+// operands of the NEXT group are requested in front of the matrix instructions of the current one and waited for
+// behind them: inside a chunk that is free; across chunks the wait for the next chunk moves half a chunk forward
+// (it was requested ring - 1 >= 3 chunks ago: with the deep ring of this configuration it has long arrived),
+// while the request for the chunk ring - 1 ahead stays where it was, at the chunk's entry, when both groups of
+// the buffer it overwrites have their operands in registers.  Only instantiated for NC = 1 and used for ring
+// depths >= 4; the memory-bound launch (ring 2, six wavefronts per SIMD) keeps the plain chain: there the early
+// wait would delay the next request.
+template <int DQ> struct g4_ops { double a0, a1, a2; double cf[DQ]; };
+
+template <int DQ>
+__device__ __forceinline__ void g4_ops_wait(g4_ops<DQ>& o) { g4_wait_cf<DQ>(o.cf, o.a0, o.a1, o.a2); }
+
+template <int NT, int DQ, int Q, int GQ, bool FWD>
+__device__ __forceinline__ void g4_read_ops(unsigned cur, int w, g4_lane ln, g4_ops<DQ>& o) {
+  asm volatile("" : "+v"(ln.cX));
+  const unsigned zero_ad = cur + (unsigned)w * 32u, mine = zero_ad + ln.cg;
+  const bool here = ln.blk == GQ;
+  // forward: steps 0, 1, 2 = columns of the corner (lanes hi == k); backward: steps 3, 2, 1 = its rows, transposed
+  const unsigned adA = (here && ln.hi == (FWD ? 0 : 3)) ? mine : zero_ad;
+  const unsigned adB = (here && ln.hi == (FWD ? 1 : 2)) ? mine : zero_ad;
+  const unsigned adC = (here && ln.hi == (FWD ? 2 : 1)) ? mine : zero_ad;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(o.a0) : "v"(adA));
+  asm volatile("ds_read_b64 %0, %1" : "=v"(o.a1) : "v"(adB));
+  asm volatile("ds_read_b64 %0, %1" : "=v"(o.a2) : "v"(adC));
+#pragma unroll
+  for (int dq = 0; dq < DQ; ++dq) {
+    o.cf[dq] = 0.0;
+    if (Q + dq < NT) {
+      const unsigned s = min((unsigned)(ln.cX - (16 * dq - 4 * GQ)), (unsigned)w);
+      const unsigned ad = cur + s * 32u + ln.aX;
+      asm volatile("ds_read_b64 %0, %1" : "=v"(o.cf[dq]) : "v"(ad));
+    }
+  }
+}
+template <int NT, int DQ, int Q, int GQ>
+__device__ __forceinline__ void g4_fwd_math(double (&T)[NT], const g4_ops<DQ>& o) {
+  g4_corner_solve<1, NT, Q>(T, o.a0, o.a1, o.a2);
+  const double yg = g4_quad_bcast<GQ>(T[Q]);
+#pragma unroll
+  for (int dq = 0; dq < DQ; ++dq)
+    if (Q + dq < NT) T[Q + dq] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.cf[dq], yg, T[Q + dq], 0, 0, 0);
+}
+template <int NT, int DQ, int Q, int GQ>
+__device__ __forceinline__ void g4_bwd_math(double (&T)[NT], const g4_ops<DQ>& o, g4_lane ln) {
+  double acc = 0.0;
+#pragma unroll
+  for (int dq = 0; dq < DQ; ++dq)
+    if (Q + dq < NT) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.cf[dq], T[Q + dq], acc, 0, 0, 0);
+  acc += row_ror<4>(acc);
+  acc += row_ror<8>(acc);
+  T[Q] += (ln.blk == GQ) ? acc : 0.0;
+  g4_corner_solve<1, NT, Q>(T, o.a0, o.a1, o.a2);
+}
+
+// forward chunk C = 2 Q + H; on entry A holds the operands of its first group (waited for)
+template <int NT, int DQ, int Q, int H>
+__device__ __forceinline__ void g4_fwd_chunk_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+                                               int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
+                                               int ring, g4_ops<DQ>& A, g4_ops<DQ>& B) {
+  constexpr int C = 2 * Q + H;
+  const int nch = (b + 7) >> 3, nld = (chunk_doubles + 127) >> 7;
+  const int cn = C + ring - 1;
+  if (cn < nch) g4_issue_chunk(rec, chunk_doubles, cn, lds0 + (cn & (ring - 1)) * lstride, lane);
+  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (ring - 1)) * lstride);
+  g4_read_ops<NT, DQ, Q, 2 * H + 1, true>(cur + (unsigned)(w + 4) * 32u, w, ln, B);
+  g4_fwd_math<NT, DQ, Q, 2 * H>(T, A);
+  g4_ops_wait<DQ>(B);
+  if (C + 1 < nch) {
+    // the next chunk: everything but the ring - 2 youngest of the chunks in flight must have landed
+    g4_wait_vm(max(0, min(ring - 1, nch - 1 - C) - 1) * nld);
+    constexpr int Qn = H ? Q + 1 : Q, Gn = H ? 0 : 2;
+    if constexpr (Qn < NT) {
+      const unsigned nxt = (unsigned)(uintptr_t)(lds_ptr)(lds0 + ((C + 1) & (ring - 1)) * lstride);
+      g4_read_ops<NT, DQ, Qn, Gn, true>(nxt, w, ln, A);
+    }
+  }
+  g4_fwd_math<NT, DQ, Q, 2 * H + 1>(T, B);
+  if (C + 1 < nch) g4_ops_wait<DQ>(A);
+  asm volatile("" ::: "memory");
+}
+template <int NT, int DQ, int Q>
+__device__ __forceinline__ void g4_fwd_tiles_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+                                               int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
+                                               int ring, g4_ops<DQ>& A, g4_ops<DQ>& B) {
+  if constexpr (Q < NT) {
+    if (16 * Q < b) {
+      g4_fwd_chunk_p<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
+      if (16 * Q + 8 < b) g4_fwd_chunk_p<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
+      g4_fwd_tiles_p<NT, DQ, Q + 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
+    }
+  }
+}
+
+// backward chunk C: groups 2 H + 1, then 2 H; on entry A holds the operands of group 2 H + 1 -- loaded here when
+// C is the sweep's first chunk (its two buffers are still where the forward sweep left them)
+template <int NT, int DQ, int Q, int H>
+__device__ __forceinline__ void g4_bwd_chunk_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+                                               int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
+                                               int ring, g4_ops<DQ>& A, g4_ops<DQ>& B) {
+  constexpr int C = 2 * Q + H;
+  const int nch = (b + 7) >> 3, nld = (chunk_doubles + 127) >> 7;
+  const int cn = C - (ring - 1);
+  if (cn >= 0 && C < nch - 1) g4_issue_chunk(rec, chunk_doubles, cn, lds0 + (cn & (ring - 1)) * lstride, lane);
+  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (ring - 1)) * lstride);
+  if (C == nch - 1) {
+    g4_read_ops<NT, DQ, Q, 2 * H + 1, false>(cur + (unsigned)(w + 4) * 32u, w, ln, A);
+    g4_ops_wait<DQ>(A);
+  }
+  g4_read_ops<NT, DQ, Q, 2 * H, false>(cur, w, ln, B);
+  g4_bwd_math<NT, DQ, Q, 2 * H + 1>(T, A, ln);
+  g4_ops_wait<DQ>(B);
+  if (C > 0) {
+    // chunk C - 1: of the chunks this sweep has requested so far, those below it may still be in flight
+    const int lo = max(0, C - ring + 1), hi = min(C - 2, nch - ring - 1);
+    g4_wait_vm(max(0, hi - lo + 1) * nld);
+    constexpr int Qn = H ? Q : Q - 1, Gn = H ? 1 : 3;
+    if constexpr (Qn >= 0) {
+      const unsigned nxt = (unsigned)(uintptr_t)(lds_ptr)(lds0 + ((C - 1) & (ring - 1)) * lstride);
+      g4_read_ops<NT, DQ, Qn, Gn, false>(nxt + (unsigned)(w + 4) * 32u, w, ln, A);
+    }
+  }
+  g4_bwd_math<NT, DQ, Q, 2 * H>(T, B, ln);
+  if (C > 0) g4_ops_wait<DQ>(A);
+  asm volatile("" ::: "memory");
+}
+template <int NT, int DQ, int Q>
+__device__ __forceinline__ void g4_bwd_tiles_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
+                                               int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
+                                               int ring, g4_ops<DQ>& A, g4_ops<DQ>& B) {
+  if constexpr (Q >= 0) {
+    if (16 * Q < b) {
+      if (16 * Q + 8 < b) g4_bwd_chunk_p<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
+      g4_bwd_chunk_p<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
+    }
+    g4_bwd_tiles_p<NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
+  }
+}
+
 // One wavefront per block.  NT tiles of 16 rows (b <= 16 NT), DQ = tiles a group's record reaches
 // (w + 15 < 16 DQ).  `xs` = row stride of the panels in doubles (2, 4; 8 / 16 when the kernel is
 // launched on a 4-column slice of a wider panel), `ncol` <= 4 columns starting at `in` / `out`.
-template <int NC, int NT, int DQ, int OCC, bool GP>
+template <int NC, int NT, int DQ, int OCC, bool GP, bool PIPE = false>
 __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     const int* __restrict__ list, int count, const int* __restrict__ row0, const int* __restrict__ nrows,
     const int* __restrict__ bw, const long long* __restrict__ off2, const int* __restrict__ map_f,
@@ -434,7 +576,17 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
   // the rest of the ring behind the panel loads, so that the newest requests are all chunks
   for (int c = 1; c < ring - 1 && 8 * c < b; ++c) g4_issue_chunk(rec, chunk_doubles, c, lds0 + c * lstride, lane);
 
-  g4_fwd_tiles<NC, NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring);
+  g4_ops<DQ> opA, opB;       // PIPE: the operands of the group at hand and of the next one
+  if constexpr (PIPE) {
+    static_assert(NC == 1, "the pipelined chain is built for panels of up to 4 columns");
+    const int nch = (b + 7) >> 3, nld = (chunk_doubles + 127) >> 7;
+    g4_wait_vm(min(ring - 2, nch - 1) * nld);           // chunk 0 (requested first, the rest of the ring behind it)
+    g4_read_ops<NT, DQ, 0, 0, true>((unsigned)(uintptr_t)(lds_ptr)lds0, w, lf, opA);
+    g4_ops_wait<DQ>(opA);
+    g4_fwd_tiles_p<NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring, opA, opB);
+  } else {
+    g4_fwd_tiles<NC, NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring);
+  }
 
   // y = D^-2 a
   double ga_mid = 0.0;
@@ -472,7 +624,26 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     lb.hi = hi2;
     lb.blk = blk2;
     gr.base = (unsigned)r0 * (unsigned)xs + (unsigned)lo2;
-    g4_bwd_tiles<NC, NT, DQ, NT - 1, GP>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring, gr, 4 * blk2 + hi2, mpk);
+    if constexpr (PIPE) {
+      // (few blocks: nothing to gain from spreading the rows of gprev over the sweep -- one wavefront per SIMD,
+      // no burst -- so they are all requested here, in front of it, and multiplied in behind it)
+      double apv[NT];
+      if constexpr (GP) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) apv[q] = gprev[gr.base + ((mpk[q >> 2] >> (8 * (q & 3))) & 255u) * gr.xs];
+      }
+      g4_bwd_tiles_p<NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring, opA, opB);
+      if constexpr (GP) {
+#pragma unroll
+        for (int q = 1; q < NT; ++q) {
+          const double z = 16 * q + 4 * blk2 + hi2 < b ? T[q] : 0.0;
+          gr.gp = __builtin_amdgcn_mfma_f64_4x4x4f64(apv[q], z, gr.gp, 0, 0, 0);
+        }
+        gr.ap = apv[0];          // (tile 0 is taken below, like the spread-out variant's last request)
+      }
+    } else {
+      g4_bwd_tiles<NC, NT, DQ, NT - 1, GP>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring, gr, 4 * blk2 + hi2, mpk);
+    }
   }
 
   {
@@ -551,6 +722,29 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
     configured = lds;
   }
   const int blocks = (count + waves - 1) / waves;
+  if constexpr (NC == 1 && NT == 12 && DQ <= 5) {
+    // few blocks (deep ring): the software-pipelined group chain
+    if (ring >= 4) {
+      static size_t configured_p = 0;
+      if (lds > 64 * 1024 && lds > configured_p) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NC, NT, DQ, 1, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NC, NT, DQ, 1, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          return kfail("hipFuncSetAttribute(k_bj_g4, pipelined)");
+        configured_p = lds;
+      }
+      if (pa_g4_gram_part && xs == 4 && ncol == 4)
+        PA_LAUNCH((k_bj_g4<NC, NT, DQ, 1, true, true>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
+                  pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out,
+                  pa_g4_gram_prev, pa_g4_gram_part);
+      else
+        PA_LAUNCH((k_bj_g4<NC, NT, DQ, 1, false, true>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
+                  pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out,
+                  (const double*)nullptr, (double*)nullptr);
+      return kfail("k_bj_g4");
+    }
+  }
   if constexpr (NC == 1) {
     if (pa_g4_gram_part && xs == 4 && ncol == 4) {
       PA_LAUNCH((k_bj_g4<NC, NT, DQ, OCC, true>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
