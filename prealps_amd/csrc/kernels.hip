@@ -2868,7 +2868,7 @@ extern "C" {
 
 int pa_bj_max_R(void) { return 8; }
 /* partial blocks a Gram buffer must hold: the kernels' grid cap + the shares and the ticket of k_finish_wide */
-int pa_gram_max_blocks(void) { return GRAM_MAX_BLOCKS + GRAM_SCRATCH_BLOCKS; }
+int pa_gram_max_blocks(void) { return GRAM_WIDE_BLOCKS + GRAM_SCRATCH_BLOCKS; }
 
 void pa_k_note_seq(double seq) { g_note_seq = seq; }
 
@@ -2898,7 +2898,11 @@ int pa_k_probe(int which, size_t bytes, const double* src, double* dst) {
 int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B, double* partials,
               int* nblk) {
   int blocks = grid_rows(m, 4);
-  if (blocks > GRAM_MAX_BLOCKS) blocks = GRAM_MAX_BLOCKS;
+  // (8 columns: up to 1024 workgroups -- four wavefronts per SIMD keep more of the three panel streams in flight:
+  // 42.2 -> 38.2 us, the sum of the 1024 partial blocks +1.9 us.  k_gram<4, 2> measured best at 512 in round 2;
+  // 16 columns lose with 1024: 69.6 -> 72.5 us and +5 us in the sum.)
+  const int cap = ts == 8 ? GRAM_WIDE_BLOCKS : GRAM_MAX_BLOCKS;
+  if (blocks > cap) blocks = cap;
   *nblk = blocks;
   if (ts == 16) {   // matrix cores (k_gram_mfma16)
     if (A1) PA_LAUNCH((k_gram_mfma16<2>), dim3(blocks), dim3(WG), 0, cur_stream(), m, A0, A1, B, partials);
@@ -2921,11 +2925,11 @@ int pa_k_gram(int m, int ts, const double* A0, const double* A1, const double* B
 }
 
 /* The sum of wide partial blocks by FINW_WG workgroups (k_finish_wide); the shares and the ticket lie behind the
- * GRAM_MAX_BLOCKS partial blocks of the buffer (pa_gram_max_blocks() counts them in). */
+ * GRAM_WIDE_BLOCKS partial blocks of the buffer (pa_gram_max_blocks() counts them in). */
 static int finish_wide(const double* partials, int nblk, int npan, int ts, int a_lo, int a_hi, int nb, double* out,
                        int ld_out, int t, int T, double* mu, double* alpha, int* info, const double* rtr, int rtr_nblk,
                        int rtr_nc, double* res2) {
-  double* scratch = const_cast<double*>(partials) + (size_t)GRAM_MAX_BLOCKS * 2 * ts * ts;
+  double* scratch = const_cast<double*>(partials) + (size_t)GRAM_WIDE_BLOCKS * 2 * ts * ts;
   PA_LAUNCH(k_finish_wide, dim3(FINW_WG), dim3(WG), 0, cur_stream(), partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out,
             scratch, t, T, mu, alpha, info, rtr, rtr_nblk, rtr_nc, res2);
   return kfail("k_finish_wide");

@@ -15,6 +15,7 @@ namespace {
 
 constexpr int WG = 256;           // 4 wavefronts of 64
 constexpr int GRAM_MAX_BLOCKS = 512;
+constexpr int GRAM_WIDE_BLOCKS = 1024;    // Gram kernels of 8 / 16-column panels (their partial blocks are summed by k_finish_wide)
 
 inline hipStream_t cur_stream() { return (hipStream_t)pa_rt_stream(); }
 
