@@ -650,7 +650,9 @@ __global__ __launch_bounds__(WG) void k_finish_wide(const double* __restrict__ p
     acc[0] += q[0];
     if (ept > 1) acc[1] += q[lpb];
   }
-  unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (size_t)FINW_WG * NB);
+  // (behind the LARGEST shares this buffer can see, 2 ts^2 doubles each: a call with one panel must not look for
+  // its ticket where a call with two panels leaves share data)
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (size_t)FINW_WG * 2 * ts * ts);
   // the side-by-side slices of this workgroup (up to four), then the share
   if (nsl > 1) {
     if (sl > 0) red[(sl - 1) * lpb + l] = acc[0];

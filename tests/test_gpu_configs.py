@@ -655,6 +655,37 @@ def test_opt_in_kernel_variants(env):
     assert r.returncode == 0 and "variant ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+# ---- one solver after the other in one process, wide panels ---------------------------------------------------
+@pytest.mark.parametrize("t", [8, 16, 4])
+def test_variants_in_turn_share_the_gram_buffers(t):
+    """Orthodir, Orthomin, fused Orthodir and the reductions one after the other on the same problem object: the
+    sums of the wide Gram blocks (k_finish_wide) keep their shares and their ticket in the Gram buffer, two-panel
+    products ([AP | R]^T P, [AP | AP_prev]^T Z) and one-panel products (Orthomin's AP^T Z) in turn.  (Round 4 had
+    the ticket at an offset that depended on the block size: Orthomin behind Orthodir found share data where it
+    looked for its ticket and stopped after one iteration with a zero residual -- on a problem no test ran.)"""
+    import prealps_amd as pa
+    from oracle import oracle as O
+    A, part, nparts = _elasticity(12, (2, 3, 4))
+    prob, B, rowpos = _problem(A, nparts, part)
+    try:
+        rhs = prob.reference_rhs()
+        for name, red in (("odir", False), ("omin", False), ("odir", False), ("fused", False), ("omin", True), ("odir", True), ("omin", False)):
+            a = _algs(name)
+            try:
+                ref = O.ECG(B, rowpos, t, a[1], O.ADAPT_BS if red else O.NO_BS_RED, 1e-5, 40).solve(rhs)
+            except RuntimeError:
+                # (16 directions on this small problem: P^T A P loses rank and Orthomin gives up, in the reference
+                # -- src/solvers/ecg.c:318-322 -- in the oracle and here alike)
+                with pytest.raises(pa.PreAlpsError):
+                    prob.solve(rhs, t, ortho_alg=a[0], bs_red=pa.ADAPT_BS if red else pa.NO_BS_RED, max_iter=40)
+                continue
+            got = prob.solve(rhs, t, ortho_alg=a[0], bs_red=pa.ADAPT_BS if red else pa.NO_BS_RED, max_iter=40)
+            assert got.iters == ref["iters"], (name, red, got.iters, ref["iters"])
+            np.testing.assert_allclose(got.res[:12], ref["res"][:12], rtol=RTOL_HIST, err_msg="%s red=%s" % (name, red))
+    finally:
+        prob.close()
+
+
 # ---- opt-in: HIP-graph replay of the iteration halves; the one-shard rehearsal ----------------------------
 _GRAPH_SNIPPET = r"""
 import sys, numpy as np
