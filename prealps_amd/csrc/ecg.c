@@ -501,8 +501,16 @@ static int a_orthonormalise_and_alpha(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t)
  * then U = chol(W), alpha = U^-T G on one wave, then P U^-1, AP U^-1, X += P alpha,
  * R -= AP alpha and the residual column norms in a single kernel.  Algebraically
  * ecg.c:425-443 + :500-501; alpha is formed from the Gram of the un-normalised P. */
+static int fused_update(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t, const double* gram);
+static int fused_gram(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t, int factor_now);
 static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
-  int nb = 0, m = pv->m, ts = pv->ts, T = ecg->enlFac;
+  if (fused_gram(ecg, pv, t, 0)) return 1;
+  return fused_update(ecg, pv, t, pa_world_size() == 1 ? NULL : pv->d_q);
+}
+/* first pass: [W ; G^T] summed over the processes in d_q; one process (or factor_now): U = chol(W) in d_mu and
+ * alpha = U^-T G in d_alpha as well, so that the host can look at alpha before the panels are touched (D-Odir) */
+static int fused_gram(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t, int factor_now) {
+  int m = pv->m, ts = pv->ts, T = ecg->enlFac;
   int single = pa_world_size() == 1;
   double* buf = pv->d_q; /* (t+T) x t */
   double t0;
@@ -527,7 +535,20 @@ static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
     if (pa_allreduce(buf, (t + T) * t)) return 1;
     TAC(PA_T_COMM, comm_t);
     /* (the factorisation of the reduced block and alpha: in the update kernel's prologue) */
+    if (factor_now) {
+      TIC(PA_T_SMALL);
+      PA_CHECK(pa_k_potrf_alpha(buf, t, T, pv->d_mu, pv->d_alpha, pv->d_info));
+      TAC(PA_T_SMALL, potrf_t);
+    }
   }
+  return 0;
+}
+/* second pass: P U^-1, AP U^-1, X += P alpha, R -= AP alpha and the residual column norms; gram != NULL: the
+ * kernel's prologue factors the summed block first */
+static int fused_update(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t, const double* gram) {
+  int nb = 0, m = pv->m, ts = pv->ts, T = ecg->enlFac;
+  int single = pa_world_size() == 1;
+  double t0;
   TIC(PA_T_UPDATE);
   /* the slot right behind beta: free once the kernel has read U from it (Odir: d_mu) */
   pv->lazy_ptr = pv->lazy_stop ? pv->d_beta + (size_t)ecg->beta->info.lda * ecg->beta->info.n : NULL;
@@ -539,7 +560,7 @@ static int fused_first_half(preAlps_ECG_t* ecg, ecg_priv_t* pv, int t) {
   PA_CHECK(pa_k_trsm_update(m, ts, t, ecg->X->info.n, pv->d_mu, pv->d_alpha, ecg->P->val, ecg->AP->val,
                             pv->d_X, pv->d_R, pv->d_rtr_part, &nb, defer ? 0 : T,
                             pv->lazy_ptr ? pv->lazy_ptr : pv->d_res2, pv->d_info, single ? pv->h_pin : NULL,
-                            single ? NULL : buf, pv->lazy_norm ? pv->d_uu + (size_t)pv->uu_cur * T * T : NULL));
+                            gram, pv->lazy_norm ? pv->d_uu + (size_t)pv->uu_cur * T * T : NULL));
   pv->rtr_nblk = nb;
   TAC(PA_T_UPDATE, trsm_t);
   pv->rtr_valid = defer ? 1 : 2;
@@ -568,7 +589,9 @@ static int shift_directions(preAlps_ECG_t* ecg, ecg_priv_t* pv, int ncopy) {
   if (ecg->ortho_alg == ORTHOMIN) {
     if (pv->rotate) { double* p = pv->buf_v[0]; pv->buf_v[0] = pv->buf_z; pv->buf_z = p; }
     else PA_CHECK(pa_k_copy_cols(pv->m, pv->ts, ncopy, pv->buf_z, pv->buf_v[0]));
-  } else if (pv->rotate) {
+  } else if (pv->rotate || ncopy == ecg->enlFac) {
+    /* (with block-size reduction too while every column is still live: the columns a reduction rotates away
+     * stay behind in P / AP, and from then on ncopy < enlFac and the copies below keep them where they are) */
     double* oldprev = pv->buf_v[1];
     pv->buf_v[1] = pv->buf_v[0]; pv->buf_v[0] = pv->buf_z; pv->buf_z = oldprev;
     double* oldaprev = pv->buf_av[1];
@@ -664,7 +687,7 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
 }
 
 /* ---- D-Odir: reduction of the search directions (ecg.c:445-497, :593-637) -- */
-static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z) {
+static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z, int* pending_trsm) {
   int M = ecg->globPbSize, m = pv->m, ts = pv->ts, nrhs = ecg->enlFac;
   int t = ecg->P->info.n, t1 = 0;
   double tol = ecg->tol * ecg->normb / sqrt((double)nrhs), t0;
@@ -690,6 +713,10 @@ static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z
     for (int j = 0; j < nrhs; ++j) for (int i = 0; i < t1; ++i) packed[i + (size_t)t1 * j] = ha[i + (size_t)t * j];
     PA_CHECK(pa_rt_h2d(pv->d_alpha, packed, (size_t)t1 * nrhs * sizeof(double)));
     PA_CHECK(pa_rt_h2d(pv->d_q, hq, (size_t)t * t * sizeof(double)));
+    if (pending_trsm && *pending_trsm) {       /* the caller held P U^-1, AP U^-1 back for its fused update */
+      PA_CHECK(pa_k_trsm(m, ts, t, pv->d_mu, ecg->P->val, ecg->AP->val));
+      *pending_trsm = 0;
+    }
     PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->P->val));
     PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->AP->val));
     if (with_Z) PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->Z->val));
@@ -720,9 +747,16 @@ int _preAlps_ECGIterateOdir(preAlps_ECG_t* ecg, int* rci_request) {
           ecg->beta->info.lda == 8 && ecg->beta->info.n == 4)
         pa_k_bj_gram_arm(pv->buf_av[0], pv->buf_z, pv->buf_av[1], pv->d_bj_parts, pv->bj_cap);
       else if (pv->d_bj_parts) pa_k_bj_gram_disarm(pv->d_bj_parts);
+    } else if (pv->fuse && t == ecg->enlFac) {
+      /* D-Odir while every direction is still live: the same two passes, with the look at alpha in between
+       * (alpha = U^-T G needs no normalised panel); a reduction decided there goes the four-pass way */
+      int pending = 1;
+      if (fused_gram(ecg, pv, t, 1)) return 1;
+      if (reduce_directions_odir(ecg, pv, 0, &pending)) return 1;
+      if (pending ? fused_update(ecg, pv, t, NULL) : update_iterate(ecg, pv)) return 1;
     } else {
       if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
-      if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0)) return 1;
+      if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0, NULL)) return 1;
       if (update_iterate(ecg, pv)) return 1;
     }
     ecg->iter++;
@@ -743,8 +777,8 @@ int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
   int M = ecg->globPbSize, m = pv->m, ts = pv->ts, nrhs = ecg->enlFac;
   int t = ecg->P->info.n;
   if (*rci_request == 0) {
-    if (ecg->bs_red == NO_BS_RED && pv->fuse) {
-      if (fused_first_half(ecg, pv, t)) return 1;
+    if (pv->fuse && (ecg->bs_red == NO_BS_RED || t == nrhs)) {
+      if (fused_first_half(ecg, pv, t)) return 1;   /* (BF-Omin: while the panel still has its full rank) */
     } else {
       if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
       if (update_iterate(ecg, pv)) return 1;
@@ -844,7 +878,7 @@ int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
                            pv->buf_v[0], pv->buf_v[1], pv->buf_z, NULL, NULL, NULL, NULL));
   }
   TAC(PA_T_UPDATE, gemm_t);
-  if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 1)) return 1;
+  if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 1, NULL)) return 1;
   if (update_iterate(ecg, pv)) return 1;
   ecg->iter++;
   return shift_directions(ecg, pv, ecg->bs);
