@@ -377,7 +377,7 @@ def main():
                    "setup_breakdown_s": {k: prob.stat("setup_" + k + "_s") for k in ("build", "plan", "bj_factor", "bj_layout")},
                    "bj_max_bandwidth": int(prob.stat("bj_max_bandwidth")),
                    "spmm_blocks": int(prob.stat("spmm_blocks"))},
-        "roofline": {"kernel": ("k_spmm_runs_gram" if prob.stat("spmm_runs") else "k_spmm_gram") if with_gram else ("k_spmm_runs" if prob.stat("spmm_runs") else ("k_spmm_staged" if prob.stat("spmm_staged") else "k_spmm")), "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": ("k_spmm_runs_gram<3>" if prob.stat("spmm_runs") else ("k_spmm_runs_gram<1>" if prob.stat("spmm_staged") else "k_spmm_gram")) if with_gram else ("k_spmm_runs<.,.,3>" if prob.stat("spmm_runs") else ("k_spmm_runs<.,.,1>" if prob.stat("spmm_staged") else "k_spmm")), "bound": "hbm", "achieved": spmm_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": spmm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": spmm_bytes, "avg_launch_us": 1e6 * spmm_s,
                      "back_to_back_launch_us": 1e6 * spmm_b2b_s,
@@ -389,7 +389,7 @@ def main():
                      "traffic_frac_of_measured_read_ceiling": None if traffic is None else traffic / spmm_s / 1e9 / read_gbs.value,
                      "algorithmic_over_measured_read_ceiling": spmm_gbs / read_gbs.value,
                      "plain_product": None if plain_s is None else {
-                         "kernel": "k_spmm_runs", "avg_launch_us": 1e6 * plain_s, "algorithmic_bytes_per_launch": plain_bytes,
+                         "kernel": "k_spmm_runs" if (prob.stat("spmm_runs") or prob.stat("spmm_staged")) else "k_spmm", "avg_launch_us": 1e6 * plain_s, "algorithmic_bytes_per_launch": plain_bytes,
                          "achieved": plain_bytes / plain_s / 1e9, "frac": plain_bytes / plain_s / 1e9 / HBM_PEAK_GBS,
                          "note": "the same product without the Gram block, stand-alone launches behind one block solve each (what rounds 1-2 reported)"},
                      "note": ("the solver's own launches: hipEvent pair of the `operator` phase, one per iteration of the phase-by-phase pass; "

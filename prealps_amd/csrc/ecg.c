@@ -81,6 +81,13 @@ typedef struct {
    * one's for P_prev) where the reference's panels would carry it -- the same algebra, two panel writes and
    * their 66 MB per iteration less on the headline problem.  d_uu: the two factors, uu_cur: this iteration's. */
   int lazy_norm, uu_cur;
+  /* D-Odir rides the same path while every direction is live (ecg->P->info.n == enlFac); the first reduction
+   * writes the normalised panels (P, AP with this iteration's factor, P_prev, AP_prev with the previous one's)
+   * and ends it for the rest of the solve.  z_ready: the library's own loops queue the block solve Z = M^-1 AP
+   * (AP is the raw panel, which nothing rewrites) BEFORE the host waits for alpha and decides about a reduction,
+   * so the wait and the SVD are hidden behind it; the loop then skips its own apply.  ev_alpha: alpha is on the host. */
+  int z_ready;
+  void* ev_alpha;
   double* d_uu;
   int poll;           /* the host polls the word a kernel writes behind the norm instead of waiting for an event */
   double seq, sent_seq, wait_seq;   /* last number handed out / the one travelling with the current norm / awaited */
@@ -180,7 +187,8 @@ int _preAlps_ECGMalloc(preAlps_ECG_t* ecg) {
   pv->h_pin_i = (int*)pa_rt_host_alloc((8 + T) * sizeof(int));
   if (!pv->h_pin || !pv->h_pin_i) return PA_FAIL("pinned allocation failed: %s", pa_rt_error());
   pv->ev_res = pa_rt_event_create();
-  if (!pv->ev_res) return PA_FAIL("hipEventCreate failed");
+  pv->ev_alpha = pa_rt_event_create();
+  if (!pv->ev_res || !pv->ev_alpha) return PA_FAIL("hipEventCreate failed");
   publish_pointers(ecg, pv);
   return 0;
 }
@@ -218,8 +226,9 @@ int _preAlps_ECGReset(preAlps_ECG_t* ecg, double* rhs, int* rci_request) {
   publish_pointers(ecg, pv);
   pv->rotate = (ecg->bs_red == NO_BS_RED);
   { const char* f = getenv("PREALPS_ECG_FUSE"); pv->fuse = f ? atoi(f) : 1; }
-  pv->lazy_norm = pv->fuse && ecg->ortho_alg == ORTHODIR && ecg->bs_red == NO_BS_RED && pa_env_flag("PREALPS_ECG_LAZY_NORM", 1);
+  pv->lazy_norm = pv->fuse && ecg->ortho_alg == ORTHODIR && pa_env_flag("PREALPS_ECG_LAZY_NORM", 1);
   pv->uu_cur = 0;
+  pv->z_ready = 0;
   /* With more than one process every collective costs tens of microseconds.  The norm of the
    * new residual is only needed for the stopping decision, so the driver loops of this library
    * (preAlps_ECGSolve / ECGAdvance) let it travel with the beta all-reduce of the same
@@ -687,7 +696,12 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
 }
 
 /* ---- D-Odir: reduction of the search directions (ecg.c:445-497, :593-637) -- */
-static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z, int* pending_trsm) {
+static int fetch_alpha(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
+  PA_CHECK(pa_rt_d2h_async(pv->h_pin + 16, pv->d_alpha, (size_t)ecg->P->info.n * ecg->enlFac * sizeof(double)));
+  PA_CHECK(pa_rt_event_record(pv->ev_alpha));
+  return 0;
+}
+static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z, int* pending_trsm, int fetched) {
   int M = ecg->globPbSize, m = pv->m, ts = pv->ts, nrhs = ecg->enlFac;
   int t = ecg->P->info.n, t1 = 0;
   double tol = ecg->tol * ecg->normb / sqrt((double)nrhs), t0;
@@ -695,8 +709,11 @@ static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z
   double* hq = ha + (size_t)nrhs * nrhs;       /* t x t */
   double sig[16];
   t0 = pa_wtime();
-  PA_CHECK(pa_rt_d2h_async(ha, pv->d_alpha, (size_t)t * nrhs * sizeof(double)));
-  PA_CHECK(pa_rt_sync());
+  if (fetched) PA_CHECK(pa_rt_event_wait(pv->ev_alpha));     /* (fetch_alpha queued the copy; more work may be queued behind it) */
+  else {
+    PA_CHECK(pa_rt_d2h_async(ha, pv->d_alpha, (size_t)t * nrhs * sizeof(double)));
+    PA_CHECK(pa_rt_sync());
+  }
   ecg->copy_t += pa_wtime() - t0;
   t0 = pa_wtime();
   pa_sd_left_singular(t, nrhs, ha, t, hq, sig); /* hq = U, sig decreasing */
@@ -715,11 +732,18 @@ static int reduce_directions_odir(preAlps_ECG_t* ecg, ecg_priv_t* pv, int with_Z
     PA_CHECK(pa_rt_h2d(pv->d_q, hq, (size_t)t * t * sizeof(double)));
     if (pending_trsm && *pending_trsm) {       /* the caller held P U^-1, AP U^-1 back for its fused update */
       PA_CHECK(pa_k_trsm(m, ts, t, pv->d_mu, ecg->P->val, ecg->AP->val));
+      if (pv->lazy_norm) {
+        /* the panels were never normalised so far: the previous directions now, with their own factor, and the
+         * block solve's result if it is already there (Z = M^-1 AP_raw: Z U^-1 is what the reference holds) */
+        PA_CHECK(pa_k_trsm(m, ts, nrhs, pv->d_uu + (size_t)(1 - pv->uu_cur) * nrhs * nrhs, pv->buf_v[1], pv->buf_av[1]));
+        if (pv->z_ready) PA_CHECK(pa_k_trsm(m, ts, t, pv->d_mu, ecg->Z->val, NULL));
+        pv->lazy_norm = 0;
+      }
       *pending_trsm = 0;
     }
     PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->P->val));
     PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->AP->val));
-    if (with_Z) PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->Z->val));
+    if (with_Z || pv->z_ready) PA_CHECK(pa_k_right_mult(m, ts, t, pv->d_q, ecg->Z->val));
     TAC(PA_T_UPDATE, ormqr_t);
     CPLM_MatDenseSetInfo(ecg->alpha, t1, nrhs, t1, nrhs, COL_MAJOR);
     pa_set_desc(ecg->P, M, t1, m, t1, ts);
@@ -752,11 +776,16 @@ int _preAlps_ECGIterateOdir(preAlps_ECG_t* ecg, int* rci_request) {
        * (alpha = U^-T G needs no normalised panel); a reduction decided there goes the four-pass way */
       int pending = 1;
       if (fused_gram(ecg, pv, t, 1)) return 1;
-      if (reduce_directions_odir(ecg, pv, 0, &pending)) return 1;
+      if (fetch_alpha(ecg, pv)) return 1;
+      if (g_own_loop > 0 && pv->lazy_norm) {
+        if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
+        pv->z_ready = 1;
+      }
+      if (reduce_directions_odir(ecg, pv, 0, &pending, 1)) return 1;
       if (pending ? fused_update(ecg, pv, t, NULL) : update_iterate(ecg, pv)) return 1;
     } else {
       if (a_orthonormalise_and_alpha(ecg, pv, t)) return 1;
-      if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0, NULL)) return 1;
+      if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 0, NULL, 0)) return 1;
       if (update_iterate(ecg, pv)) return 1;
     }
     ecg->iter++;
@@ -878,7 +907,7 @@ int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
                            pv->buf_v[0], pv->buf_v[1], pv->buf_z, NULL, NULL, NULL, NULL));
   }
   TAC(PA_T_UPDATE, gemm_t);
-  if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 1, NULL)) return 1;
+  if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 1, NULL, 0)) return 1;
   if (update_iterate(ecg, pv)) return 1;
   ecg->iter++;
   return shift_directions(ecg, pv, ecg->bs);
@@ -921,6 +950,7 @@ void _preAlps_ECGFree(preAlps_ECG_t* ecg) {
     pa_rt_host_free(pv->h_pin);
     pa_rt_host_free(pv->h_pin_i);
     pa_rt_event_destroy(pv->ev_res);
+    pa_rt_event_destroy(pv->ev_alpha);
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) pa_rt_graph_free(pv->graph[a][b]);
     pv->magic = 0;
   }
@@ -1005,7 +1035,14 @@ static int ecg_solve_loop(preAlps_ECG_t* ecg, double* rhs, double* sol, double* 
          * the residual norm (it does not depend on it and is simply unused after a stop) */
         ecg_priv_t* pv = priv_of(ecg);
         if (!pv) return PA_FAIL("solver not initialised");
-        if (pv->lazy_stop && pv->lazy_ptr) {
+        if (pv->z_ready) {
+          /* D-Odir at full width: the first half already queued the block solve (behind which the host looked at
+           * alpha); the second half and the product go out before the host waits for the norm, as below */
+          pv->z_ready = 0;
+          if (stopping_begin(ecg, pv)) return 1;
+          if (preAlps_ECGIterate(ecg, &rci)) return 1;
+          if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;
+        } else if (pv->lazy_stop && pv->lazy_ptr) {
           /* several processes: the norm travels with the beta all-reduce of the second half;
            * the half-step and the product queued before the decision are unused after a stop */
           if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
@@ -1098,9 +1135,11 @@ static int ecg_advance_loop(preAlps_ECG_t* ecg, double* rhs, int* rci_request, i
        * then wait for the norm: the apply does not depend on it and is discarded on stop */
       ecg_priv_t* pv = priv_of(ecg);
       if (!pv) return PA_FAIL("solver not initialised");
-      int lazy = pv->lazy_stop && pv->lazy_ptr;
+      int early = pv->z_ready;
+      int lazy = early || (pv->lazy_stop && pv->lazy_ptr);
       if (lazy) {   /* see preAlps_ECGSolve */
-        if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
+        if (early) { pv->z_ready = 0; if (stopping_begin(ecg, pv)) return 1; }
+        else if (ecg->ortho_alg == ORTHOMIN) { if (preAlps_BlockJacobiApply(ecg->R, ecg->Z)) return 1; }
         else if (preAlps_BlockJacobiApply(ecg->AP, ecg->Z)) return 1;
         if (preAlps_ECGIterate(ecg, rci_request)) return 1;
         if (preAlps_BlockOperator(ecg->P, ecg->AP)) return 1;

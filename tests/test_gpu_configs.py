@@ -193,6 +193,65 @@ def test_config3_elasticity_t8_with_block_size_reduction(alg):
         prob.close()
 
 
+_RCI_REDUCTION_SNIPPET = r"""
+import sys, os
+sys.path.insert(0, %r)
+import ctypes as C
+import numpy as np, scipy.sparse as sp
+import prealps_amd as pa
+import prealps_amd.lib as pl
+from prealps_amd import gen
+from prealps_amd.lib import check
+from oracle import oracle as O
+rp, ci, v = gen.elasticity3d_csr(9)
+part, P = gen.box_partition_nodes(9, (3, 3, 3))
+A = sp.csr_matrix((v, ci, rp), shape=(len(rp) - 1, len(rp) - 1))
+B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), part, P)
+prob = pa.EcgProblem(rp, ci, v, P, part, scale=True, device=0)
+rhs = prob.reference_rhs()
+L = prob.L
+for alg_g, alg_o in ((pl.ORTHODIR, O.ORTHODIR), (pl.ORTHOMIN, O.ORTHOMIN)):
+    ref = O.ECG(B, rowpos, 8, alg_o, O.ADAPT_BS, 1e-5, 600).solve(rhs)
+    own = prob.solve(rhs, 8, ortho_alg=alg_g, bs_red=pl.ADAPT_BS, max_iter=600)
+    e = prob.new_ecg(8, alg_g, pl.ADAPT_BS, 1e-5, 600)
+    rci, stop = C.c_int(0), C.c_int(0)
+    check(L.preAlps_ECGInitialize(C.byref(e), rhs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(rci)), "init")
+    check(L.preAlps_BlockJacobiApply(e.R, e.P), "bj")
+    hist, bs = [], []
+    while stop.value != 1:               # examples/test_ecg_prealps_op.c:203-223
+        if rci.value == 0:
+            check(L.preAlps_BlockOperator(e.P, e.AP), "op")
+        else:
+            check(L.preAlps_ECGStoppingCriterion(C.byref(e), C.byref(stop)), "stop")
+            hist.append(e.res); bs.append(e.bs)
+            if stop.value == 1: break
+            check(L.preAlps_BlockJacobiApply(e.R if alg_g == pl.ORTHOMIN else e.AP, e.Z), "bj")
+        check(L.preAlps_ECGIterate(C.byref(e), C.byref(rci)), "iterate")
+    sol = (C.c_double * prob.m)()
+    check(L.preAlps_ECGFinalize(C.byref(e), sol), "fin")
+    assert len(hist) == ref["iters"] == own.iters, (len(hist), ref["iters"], own.iters)
+    assert bs == list(ref["bs"]) == list(own.bs), (bs, list(ref["bs"]))
+    if alg_g == pl.ORTHODIR: assert bs[-1] < 8 and bs[0] == 8
+    np.testing.assert_allclose(hist, ref["res"], rtol=1e-6)
+    np.testing.assert_allclose(hist, own.res, rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(sol[:]), ref["x"], rtol=1e-5, atol=1e-7 * np.abs(ref["x"]).max())
+prob.close()
+print("rci reduction ok")
+"""
+
+
+@pytest.mark.parametrize("lazy", ["1", "0"])
+def test_block_size_reduction_through_the_callers_own_loop(lazy):
+    """D-Odir and BF-Omin at 8 columns driven by the caller (the loop of examples/test_ecg_prealps_op.c:203-223,
+    every step a separate call): residuals, block-size sequence and solution against the oracle and against the
+    library's own loop.  While every direction is live D-Odir keeps its panels un-normalised (ecg.c `lazy_norm`),
+    in the library's loop it also queues the block solve before the host looks at alpha; the first reduction writes
+    the normalised panels and goes on in the reference's order.  PREALPS_ECG_LAZY_NORM=0: normalised throughout."""
+    env = dict(os.environ, PREALPS_ECG_LAZY_NORM=lazy)
+    r = subprocess.run([sys.executable, "-c", _RCI_REDUCTION_SNIPPET % ROOT], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "rci reduction ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+
+
 @pytest.mark.parametrize("alg", ["odir", "omin"])
 def test_config3_elasticity_t8_no_reduction(alg):
     import prealps_amd as pa
