@@ -816,13 +816,17 @@ int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
     *rci_request = 1;
   } else if (*rci_request == 1) {
     if (orthogonalise_z(ecg, pv)) return 1;
-    if (shift_directions(ecg, pv, nrhs)) return 1;
+    /* BF-Omin, two passes instead of four: the copy Z -> P (ecg.c:358) waits for the pivots and is done by the
+     * kernel that permutes and solves; the Gram block is formed on Z, the very numbers P would hold */
+    const int one_pass = ecg->bs_red == ADAPT_BS && pv->fuse;
+    if (!one_pass && shift_directions(ecg, pv, nrhs)) return 1;
     if (ecg->bs_red == ADAPT_BS) {
       /* BF-Omin: G = P^T P -> pivoted Cholesky -> permute, P <- P U^-1 (ecg.c:361-393) */
       int nb = 0, rank = 0;
       double t0;
+      const double* newp = one_pass ? pv->buf_z : ecg->P->val;
       TIC(PA_T_GRAM);
-      PA_CHECK(pa_k_gram(m, ts, ecg->P->val, NULL, ecg->P->val, pv->d_partials, &nb));
+      PA_CHECK(pa_k_gram(m, ts, newp, NULL, newp, pv->d_partials, &nb));
       PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, nrhs, 0, nrhs, pv->d_mu, nrhs));
       TAC(PA_T_GRAM, gemm_t);
       TIC(PA_T_COMM);
@@ -837,14 +841,21 @@ int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
       TIC(PA_T_UPDATE);
       for (int j = 0; j < nrhs; ++j) pv->h_pin_i[j] = ecg->iwork[j] - 1;
       PA_CHECK(pa_rt_h2d(pv->d_piv, pv->h_pin_i, nrhs * sizeof(int)));
-      PA_CHECK(pa_k_permute_cols(m, ts, nrhs, pv->d_piv, ecg->P->val));
+      if (!one_pass) PA_CHECK(pa_k_permute_cols(m, ts, nrhs, pv->d_piv, ecg->P->val));
       TAC(PA_T_UPDATE, lapmt_t);
       /* leading rank x rank block, leading dimension rank for the kernel */
       double* hu = hg + (size_t)nrhs * nrhs;
       for (int j = 0; j < rank; ++j) for (int i = 0; i < rank; ++i) hu[i + (size_t)rank * j] = hg[i + (size_t)nrhs * j];
       PA_CHECK(pa_rt_h2d(pv->d_q, hu, (size_t)rank * rank * sizeof(double)));
       TIC(PA_T_TRSM);
-      PA_CHECK(pa_k_trsm(m, ts, rank, pv->d_q, ecg->P->val, NULL));
+      if (one_pass) {
+        double tc = pa_wtime();
+        PA_CHECK(pa_k_permute_trsm(m, ts, nrhs, pv->d_piv, rank, pv->d_q, pv->buf_z, pv->buf_v[0]));
+        publish_pointers(ecg, pv);
+        ecg->copy_t += pa_wtime() - tc;
+      } else {
+        PA_CHECK(pa_k_trsm(m, ts, rank, pv->d_q, ecg->P->val, NULL));
+      }
       TAC(PA_T_TRSM, trsm_t);
       t = rank;
       pa_set_desc(ecg->P, M, t, m, t, ts);

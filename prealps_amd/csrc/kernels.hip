@@ -1674,6 +1674,49 @@ __global__ __launch_bounds__(WG) void k_permute_cols(int m, int n, const int* __
   }
 }
 
+// BF-Omin (ecg.c:358-393 of the reference: copy Z -> P, dlapmt, dtrsm on the leading `t` columns) in one pass:
+// dst(:, c) = src(:, piv[c]) for c < n, then the first t columns times U^-1 -- the substitution of k_trsm, same
+// order of operations, so the result equals the three kernels' bit for bit.
+template <int TS>
+__global__ __launch_bounds__(WG) void k_permute_trsm(int m, int n, const int* __restrict__ piv, int t,
+                                                     const double* __restrict__ U, const double* __restrict__ src,
+                                                     double* __restrict__ dst) {
+  __shared__ double su[TS * TS];
+  __shared__ double sd[TS];
+  __shared__ int sp[TS];
+  for (int e = threadIdx.x; e < t * t; e += WG) su[e] = U[e];
+  if (threadIdx.x < n) sp[threadIdx.x] = piv[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x < t) sd[threadIdx.x] = 1.0 / su[threadIdx.x + t * threadIdx.x];
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * WG;
+  for (size_t row = (size_t)blockIdx.x * WG + threadIdx.x; row < (size_t)m; row += stride) {
+    double a[TS], p[TS];
+    load_row<TS>(src, row, a);
+    if (n < TS) load_row<TS>(dst, row, p);      // (columns beyond the panel's width stay what they are)
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      if (c < n) {
+        const int s_ = sp[c];
+        double v = a[0];
+#pragma unroll
+        for (int k = 1; k < TS; ++k) v = (s_ == k) ? a[k] : v;
+        p[c] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TS; ++j) {
+      if (j < t) {
+        double s_ = p[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s_ = fma(-p[k], su[k + t * j], s_);
+        p[j] = s_ * sd[j];
+      }
+    }
+    store_row<TS>(dst, row, p);
+  }
+}
+
 template <int TS>
 __global__ __launch_bounds__(WG) void k_rowsum(int m, int nc, const double* __restrict__ X,
                                                double* __restrict__ sol) {
@@ -3127,6 +3170,13 @@ int pa_k_right_mult(int m, int ts, int t, const double* Q, double* A) {
   TS_DISPATCH(ts, PA_LAUNCH((k_right_mult<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
                                      cur_stream(), m, t, Q, A));
   return kfail("k_right_mult");
+}
+
+int pa_k_permute_trsm(int m, int ts, int n, const int* piv, int t, const double* U, const double* src, double* dst) {
+  if (m <= 0) return 0;
+  TS_DISPATCH(ts, PA_LAUNCH((k_permute_trsm<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0, cur_stream(), m, n, piv, t, U,
+                            src, dst));
+  return kfail("k_permute_trsm");
 }
 
 int pa_k_permute_cols(int m, int ts, int n, const int* piv, double* A) {

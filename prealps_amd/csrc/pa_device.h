@@ -199,6 +199,7 @@ int pa_k_copy_cols(int m, int ts, int nc, const double* src, double* dst);
  * 'R','N' at ecg.c:476-479 with Q formed explicitly). */
 int pa_k_right_mult(int m, int ts, int t, const double* Q, double* A);
 /* A(:, j) <- A(:, piv[j]) for j < n (LAPACKE_dlapmt forward, ecg.c:380); piv 0-based, device. */
+int pa_k_permute_trsm(int m, int ts, int n, const int* piv, int t, const double* U, const double* src, double* dst);
 int pa_k_permute_cols(int m, int ts, int n, const int* piv, double* A);
 /* sol[i] = sum_j X[i][j], j < nc (ecg.c:674). */
 int pa_k_rowsum(int m, int ts, int nc, const double* X, double* sol);
