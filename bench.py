@@ -84,6 +84,8 @@ def parse():
                          "examples/test_ecg_bench_fused.c saves an all-reduce per iteration but costs 42-48 us more "
                          "device time per iteration on a 1/8 shard -- profiles/r03_shard8_*.json -- which is more than "
                          "a small all-reduce takes.)")
+    ap.add_argument("--reduce", action="store_true", help="dynamic reduction of the search directions (-r 1 of the "
+                    "reference driver: D-Odir with --alg odir, BF-Omin with --alg omin), BASELINE configs[3]")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="rehearse ONE rank of a G-GPU run on this one GPU (with --shard r): the rank's rows, plan, "
                          "kernels and stream choreography; sums are local, halo rows arrive as zeros")
@@ -215,7 +217,7 @@ def main():
                              % prob.comm_kind)
     rhs = prob.reference_rhs()
     alg = {"odir": pl.ORTHODIR, "omin": pl.ORTHOMIN, "fused": pl.ORTHODIR_FUSED}[a.alg]
-    e = prob.new_ecg(a.t, alg, pl.NO_BS_RED, 1e-5, 100000)
+    e = prob.new_ecg(a.t, alg, pl.ADAPT_BS if a.reduce else pl.NO_BS_RED, 1e-5, 100000)
     rci = C.c_int(0)
     prhs = rhs.ctypes.data_as(C.POINTER(C.c_double))
     check(L.preAlps_ECGInitialize(C.byref(e), prhs, C.byref(rci)), "ECGInitialize")
@@ -368,7 +370,7 @@ def main():
         "ms_per_step": 1e3 * dt / a.steps, "device_ms_per_step": 1e3 * dev_s.value / a.steps,
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s (N=%d, nnz=%d), ECG %s + block-Jacobi, t=%d, tol 1e-5" % (wname, N, nnz, a.alg, a.t),
+        "config": {"workload": "%s (N=%d, nnz=%d), ECG %s%s + block-Jacobi, t=%d, tol 1e-5" % (wname, N, nnz, a.alg, " with direction reduction (-r 1)" if a.reduce else "", a.t),
                    "nparts": int(nparts), "partition": "library k-way" if a.nparts > 0 else "boxes of %s nodes" % (list(box),),
                    "parallelism": "rows x%d" % world,
                    "comm": prob.comm_kind, "hip_graphs": bool(a.graphs), "halo_rows_per_rank": halo_rows,
@@ -444,13 +446,13 @@ def main():
         from oracle import mkl_path as M
         import scipy.sparse as sp
         # the first residuals of a fresh solve on the GPU (same rhs, same partition) for the parity line
-        gpu = prob.solve(rhs, a.t, ortho_alg=alg, max_iter=a.cpu_iters)
+        gpu = prob.solve(rhs, a.t, ortho_alg=alg, bs_red=pl.ADAPT_BS if a.reduce else pl.NO_BS_RED, max_iter=a.cpu_iters)
         A = sp.csr_matrix((val, colind.astype(np.int32), rowptr), shape=(N, N))
         B, perm, rowpos = O.permute_by_part(O.symrac_scale(A), prob.part_vector(), nparts)
         rhs_cpu = O.reference_rhs(rowpos)
         tf0 = time.perf_counter()
         ecg = O.ECG(B, rowpos, a.t, {"odir": O.ORTHODIR, "omin": O.ORTHOMIN, "fused": O.ORTHODIR_FUSED}[a.alg],
-                    O.NO_BS_RED, 1e-5, a.cpu_iters)
+                    O.ADAPT_BS if a.reduce else O.NO_BS_RED, 1e-5, a.cpu_iters)
         tfac = time.perf_counter() - tf0
         r = ecg.solve(rhs_cpu)
         k = min(len(gpu.res), len(r["res"]))

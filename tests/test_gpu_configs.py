@@ -240,14 +240,15 @@ print("rci reduction ok")
 """
 
 
-@pytest.mark.parametrize("lazy", ["1", "0"])
-def test_block_size_reduction_through_the_callers_own_loop(lazy):
+@pytest.mark.parametrize("knob", ["PREALPS_ECG_LAZY_NORM=1", "PREALPS_ECG_LAZY_NORM=0", "PREALPS_ECG_FUSE=0"])
+def test_block_size_reduction_through_the_callers_own_loop(knob):
     """D-Odir and BF-Omin at 8 columns driven by the caller (the loop of examples/test_ecg_prealps_op.c:203-223,
     every step a separate call): residuals, block-size sequence and solution against the oracle and against the
     library's own loop.  While every direction is live D-Odir keeps its panels un-normalised (ecg.c `lazy_norm`),
     in the library's loop it also queues the block solve before the host looks at alpha; the first reduction writes
-    the normalised panels and goes on in the reference's order.  PREALPS_ECG_LAZY_NORM=0: normalised throughout."""
-    env = dict(os.environ, PREALPS_ECG_LAZY_NORM=lazy)
+    the normalised panels and goes on in the reference's order.  PREALPS_ECG_LAZY_NORM=0: normalised throughout;
+    PREALPS_ECG_FUSE=0: the reference's four passes, BF-Omin's copy / permutation / solve as three kernels."""
+    env = dict(os.environ, **dict([knob.split("=")]))
     r = subprocess.run([sys.executable, "-c", _RCI_REDUCTION_SNIPPET % ROOT], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "rci reduction ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
 
