@@ -840,13 +840,15 @@ int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
       ecg->pstrf_t += pa_wtime() - t0;
       TIC(PA_T_UPDATE);
       for (int j = 0; j < nrhs; ++j) pv->h_pin_i[j] = ecg->iwork[j] - 1;
-      PA_CHECK(pa_rt_h2d(pv->d_piv, pv->h_pin_i, nrhs * sizeof(int)));
+      /* (both small copies from pinned memory without a host wait: the words are next written behind the next
+       * iteration's wait for its Gram block) */
+      PA_CHECK(pa_rt_h2d_async(pv->d_piv, pv->h_pin_i, nrhs * sizeof(int)));
       if (!one_pass) PA_CHECK(pa_k_permute_cols(m, ts, nrhs, pv->d_piv, ecg->P->val));
       TAC(PA_T_UPDATE, lapmt_t);
       /* leading rank x rank block, leading dimension rank for the kernel */
       double* hu = hg + (size_t)nrhs * nrhs;
       for (int j = 0; j < rank; ++j) for (int i = 0; i < rank; ++i) hu[i + (size_t)rank * j] = hg[i + (size_t)nrhs * j];
-      PA_CHECK(pa_rt_h2d(pv->d_q, hu, (size_t)rank * rank * sizeof(double)));
+      PA_CHECK(pa_rt_h2d_async(pv->d_q, hu, (size_t)rank * rank * sizeof(double)));
       TIC(PA_T_TRSM);
       if (one_pass) {
         double tc = pa_wtime();

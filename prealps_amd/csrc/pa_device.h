@@ -29,6 +29,7 @@ int pa_rt_memset(void* d, int v, size_t bytes);
 int pa_rt_h2d(void* d, const void* h, size_t bytes);
 int pa_rt_d2h(void* h, const void* d, size_t bytes);
 int pa_rt_d2d(void* dst, const void* src, size_t bytes);
+int pa_rt_h2d_async(void* d, const void* pinned, size_t bytes);
 int pa_rt_d2h_async(void* pinned, const void* d, size_t bytes);
 void* pa_rt_side_stream(void);
 int pa_rt_stream_wait_event(void* stream, void* event);

@@ -168,6 +168,12 @@ int pa_rt_d2d(void* dst, const void* src, size_t bytes) {
   if (bytes) RT(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_cur));
   return 0;
 }
+/* (the pinned source must stay as it is until the stream has passed the copy) */
+int pa_rt_h2d_async(void* d, const void* pinned, size_t bytes) {
+  if (g_skip) return 0;
+  if (bytes) RT(hipMemcpyAsync(d, pinned, bytes, hipMemcpyHostToDevice, g_cur));
+  return 0;
+}
 int pa_rt_d2h_async(void* pinned, const void* d, size_t bytes) {
   if (g_skip) return 0;
   if (bytes) RT(hipMemcpyAsync(pinned, d, bytes, hipMemcpyDeviceToHost, g_cur));
