@@ -7,10 +7,10 @@ set -e -o pipefail
 D=$(mktemp -d)
 cd prealps_amd/csrc
 make -s
-for f in context operator partition block_jacobi nd ecg dense_ops smalldense; do
+for f in context operator partition block_jacobi mpi_glue nd ecg dense_ops smalldense; do
   gcc -O1 -g -fPIC -std=gnu11 -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -I. -c $f.c -o $D/$f.o
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libprealps_hip.so build/kernels.o build/nd_factor.o build/runtime.o build/comm_rccl.o $D/*.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libprealps_hip.so build/kernels.o build/spmm.o build/bj_g4.o build/bj_g4_nt14.o build/bj_g4_nt16.o build/nd_factor.o build/runtime.o build/comm_rccl.o $D/*.o \
   -fopenmp -lgomp -lm -ldl -fsanitize=address,undefined
 cd ../..
 cp prealps_amd/libprealps_hip.so $D/orig.so
