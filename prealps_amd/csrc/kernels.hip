@@ -1417,7 +1417,7 @@ __device__ __forceinline__ void lazy_coeffs16(const double* __restrict__ beta, i
   __syncthreads();
 }
 
-__global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_hi, int nc,
+__global__ __launch_bounds__(WG, 4) void k_update_z_mfma16(int m, int a_lo, int a_hi, int nc,
                                                         const double* __restrict__ beta, int ldb,
                                                         const double* __restrict__ V0,
                                                         const double* __restrict__ V1,
@@ -1448,38 +1448,52 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_h
   const size_t ntile = ((size_t)m + 15) >> 4;
   const size_t tstride = (size_t)gridDim.x * (WG / 64);
   if (ucur) {
-    // lazy normalisation: Z <- Z C0 - V0 C1 - V1 C2 (k_update_z<TS>); Z is an A operand like the other two
+    // lazy normalisation: Z <- Z C0 - V0 C1 - V1 C2 (k_update_z<TS>); Z is an A operand like the other two.
+    // The k index of a matrix-core step is free as long as both operands agree on it: step s2 of lane (lo, hi)
+    // takes k = 8 (s2 >> 1) + 2 hi + (s2 & 1), so that the lane's four entries of a row are two 16-byte loads and
+    // the four lanes of a row read 64 contiguous bytes per load (k = 4 s2 + hi, one double per load and 32 B
+    // between the lanes of a row, touched 16 lines a quarter each per load: 129 us against 94 us for the in-place
+    // form at 16 columns; whole rows turned through a padded LDS tile per wavefront: 193 us).  The first tile is
+    // requested in front of the coefficient prologue (a 16 x 16 inverse and three products per workgroup), every
+    // further one in front of the stores of the tile before it.
+    const double* __restrict__ V1p = a_hi > 0 ? V1 : V0;       // (no second panel: its coefficients are zero)
     lazy_coeffs16(beta, ldb, a_lo, a_hi, ucur, uprev, sc);
     double b0[4], b1[4], b2[4];
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
-      const int k = 4 * s2 + hi;
-      b0[s2] = sc[1024 + k + 16 * lo]; b1[s2] = -sc[1280 + k + 16 * lo]; b2[s2] = -sc[1536 + k + 16 * lo];
+      const int k = 8 * (s2 >> 1) + 2 * hi + (s2 & 1);
+      b0[s2] = sc[1024 + k + 16 * lo]; b1[s2] = -sc[1280 + k + 16 * lo]; b2[s2] = a_hi > 0 ? -sc[1536 + k + 16 * lo] : 0.0;
     }
-    // (Z is read in the A-operand layout like V0 / V1 -- lane = row, four columns 32 B apart: 16 lines per load --
-    // which makes this kernel 129 us against 94 us for the in-place form at 16 columns; bringing the tiles in as
-    // whole rows and turning them through a padded LDS tile per wavefront was measured at 193 us: the round trip
-    // serialises the tiles of a wavefront.  The lazy form still wins 34 us per iteration at 16 columns because
-    // k_trsm_update_mfma loses its two panel writes: 178 -> 137 us.)
-    for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
-      const size_t r0 = t << 4, arow = r0 + lo;
-      const bool aok = arow < (size_t)m;
-      double az[4], a0[4], a1[4];
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        az[s2] = aok ? Z[arow * TS + 4 * s2 + hi] : 0.0;
-        a0[s2] = aok ? V0[arow * TS + 4 * s2 + hi] : 0.0;
-        a1[s2] = (aok && a_hi > 0) ? V1[arow * TS + 4 * s2 + hi] : 0.0;
-      }
+    double2 rg[6];
+    size_t t = (size_t)blockIdx.x * (WG / 64) + wave;
+    {
+      const size_t tl = t < ntile ? t : ntile - 1, arow = (tl << 4) + lo;
+      const size_t base = (arow < (size_t)m ? arow : 0) * TS + 2 * hi;
+      rg[0] = *reinterpret_cast<const double2*>(Z + base); rg[1] = *reinterpret_cast<const double2*>(Z + base + 8);
+      rg[2] = *reinterpret_cast<const double2*>(V0 + base); rg[3] = *reinterpret_cast<const double2*>(V0 + base + 8);
+      rg[4] = *reinterpret_cast<const double2*>(V1p + base); rg[5] = *reinterpret_cast<const double2*>(V1p + base + 8);
+    }
+    while (t < ntile) {
+      const size_t r0 = t << 4;
+      const bool aok = r0 + lo < (size_t)m;
+      const double az[4] = {aok ? rg[0].x : 0.0, aok ? rg[0].y : 0.0, aok ? rg[1].x : 0.0, aok ? rg[1].y : 0.0};
+      const double a0[4] = {aok ? rg[2].x : 0.0, aok ? rg[2].y : 0.0, aok ? rg[3].x : 0.0, aok ? rg[3].y : 0.0};
+      const double a1[4] = {aok ? rg[4].x : 0.0, aok ? rg[4].y : 0.0, aok ? rg[5].x : 0.0, aok ? rg[5].y : 0.0};
       mfma_d4 z = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
         z = __builtin_amdgcn_mfma_f64_16x16x4f64(az[s2], b0[s2], z, 0, 0, 0);
         z = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s2], b1[s2], z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s2], b2[s2], z, 0, 0, 0);
       }
-      if (a_hi > 0) {
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) z = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s2], b2[s2], z, 0, 0, 0);
+      const size_t tn = t + tstride;
+      {
+        // the next tile's rows (the last round asks for its own tile once more: no branch around a load)
+        const size_t tl = tn < ntile ? tn : t, arow = (tl << 4) + lo;
+        const size_t base = (arow < (size_t)m ? arow : 0) * TS + 2 * hi;
+        rg[0] = *reinterpret_cast<const double2*>(Z + base); rg[1] = *reinterpret_cast<const double2*>(Z + base + 8);
+        rg[2] = *reinterpret_cast<const double2*>(V0 + base); rg[3] = *reinterpret_cast<const double2*>(V0 + base + 8);
+        rg[4] = *reinterpret_cast<const double2*>(V1p + base); rg[5] = *reinterpret_cast<const double2*>(V1p + base + 8);
       }
       asm volatile("" ::: "memory");     // (every lane of the tile has read its rows of Z before any is overwritten)
 #pragma unroll
@@ -1487,6 +1501,7 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma16(int m, int a_lo, int a_h
         const size_t row = r0 + hi + 4 * r;
         if (row < (size_t)m && lo < nc) Z[row * TS + lo] = z[r];
       }
+      t = tn;
     }
     return;
   }
@@ -1554,34 +1569,51 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma8(int m, int a_lo, int a_hi
   const size_t ntile = ((size_t)m + 15) >> 4;
   const size_t tstride = (size_t)gridDim.x * (WG / 64);
   if (ucur) {
-    // lazy normalisation: Z <- [V0 | V1 | Z] [-C1 ; -C2 ; C0], 24 columns in six steps of four
+    // lazy normalisation: Z <- [V0 | V1 | Z] [-C1 ; -C2 ; C0], 24 columns in six steps of four.  As in
+    // k_update_z_mfma16: k = 2 hi + (s2 & 1) within the panel s2 >> 1, so a lane's two entries of a row are one
+    // 16-byte load and the four lanes of a row read its 64 bytes; every tile but the first is requested in front
+    // of the stores of the tile before it.
+    const double* __restrict__ V1p = a_hi > 0 ? V1 : V0;       // (no second panel: its coefficients are zero)
     lazy_coeffs16(beta, ldb, a_lo, a_hi, ucur, uprev, sc);
     double bb[6];
 #pragma unroll
     for (int s2 = 0; s2 < 6; ++s2) {
-      const int k = 4 * s2 + hi, kk = k & 7;
-      const double v = s2 < 2 ? -sc[1280 + kk + 16 * (lo & 7)] : s2 < 4 ? -sc[1536 + kk + 16 * (lo & 7)] : sc[1024 + kk + 16 * (lo & 7)];
+      const int kk = 2 * hi + (s2 & 1);
+      const double v = s2 < 2 ? -sc[1280 + kk + 16 * (lo & 7)] : s2 < 4 ? (a_hi > 0 ? -sc[1536 + kk + 16 * (lo & 7)] : 0.0) : sc[1024 + kk + 16 * (lo & 7)];
       bb[s2] = lo < TS ? v : 0.0;
     }
-    for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
-      const size_t r0 = t << 4, arow = r0 + lo;
-      const bool aok = arow < (size_t)m;
-      double a[6];
-#pragma unroll
-      for (int s2 = 0; s2 < 6; ++s2) {
-        const int kk = (4 * s2 + hi) & 7;
-        const double* __restrict__ src = s2 < 2 ? V0 : s2 < 4 ? V1 : Z;
-        a[s2] = (aok && (s2 < 2 || s2 >= 4 || a_hi > 0)) ? src[arow * TS + kk] : 0.0;
-      }
+    double2 rg[3];
+    size_t t = (size_t)blockIdx.x * (WG / 64) + wave;
+    {
+      const size_t tl = t < ntile ? t : ntile - 1, arow = (tl << 4) + lo;
+      const size_t base = (arow < (size_t)m ? arow : 0) * TS + 2 * hi;
+      rg[0] = *reinterpret_cast<const double2*>(V0 + base);
+      rg[1] = *reinterpret_cast<const double2*>(V1p + base);
+      rg[2] = *reinterpret_cast<const double2*>(Z + base);
+    }
+    while (t < ntile) {
+      const size_t r0 = t << 4;
+      const bool aok = r0 + lo < (size_t)m;
+      const double a[6] = {aok ? rg[0].x : 0.0, aok ? rg[0].y : 0.0, aok ? rg[1].x : 0.0, aok ? rg[1].y : 0.0,
+                           aok ? rg[2].x : 0.0, aok ? rg[2].y : 0.0};
       mfma_d4 z = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s2 = 0; s2 < 6; ++s2) z = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], bb[s2], z, 0, 0, 0);
+      const size_t tn = t + tstride;
+      {
+        const size_t tl = tn < ntile ? tn : t, arow = (tl << 4) + lo;
+        const size_t base = (arow < (size_t)m ? arow : 0) * TS + 2 * hi;
+        rg[0] = *reinterpret_cast<const double2*>(V0 + base);
+        rg[1] = *reinterpret_cast<const double2*>(V1p + base);
+        rg[2] = *reinterpret_cast<const double2*>(Z + base);
+      }
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const size_t row = r0 + hi + 4 * r;
         if (row < (size_t)m && lo < nc) Z[row * TS + lo] = z[r];
       }
+      t = tn;
     }
     return;
   }
