@@ -285,7 +285,14 @@ void preAlps_hip_timing_reset(void) { memset(g_times, 0, sizeof(g_times)); }
 void pa_time_begin(int key) {
   (void)key;
   if (!g_timing || !g_ev0) return;
-  if (g_time_depth++ == 0) pa_rt_event_record(g_ev0);
+  if (g_time_depth++ == 0) {
+    /* every region starts on an idle stream (pa_time_end waits for its stop event): a launch onto an idle stream
+     * begins 5-10 us after an event recorded in front of it, which the pair would count as kernel time -- the
+     * rocprofv3 trace of the same run showed k_spmm_runs_gram at 151 us where this pair read 162.  A spacer of
+     * 20 us in front of the start event gives the host the time to queue the region's first launch */
+    pa_k_spacer(20);
+    pa_rt_event_record(g_ev0);
+  }
 }
 /* Returns the device seconds of the region that just closed, or -1 when timing is off or the
  * region is nested inside another one (the outermost region owns the event pair). */

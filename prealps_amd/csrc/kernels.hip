@@ -2982,6 +2982,18 @@ int pa_k_finish32_trace(const double* partials, int nblk, double* scratch, doubl
   return kfail("k_finish32");
 }
 
+/* One wavefront that does nothing for `us` microseconds (phase timers, context.c: the launch of a timed region is
+ * already queued when the spacer ends, so the event pair around it measures the kernels and not the dispatch
+ * latency of a launch onto an idle stream). */
+__global__ void k_spacer(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+int pa_k_spacer(int us) {
+  PA_LAUNCH(k_spacer, dim3(1), dim3(64), 0, cur_stream(), (long long)us * 100);     /* (100 MHz counter) */
+  return kfail("k_spacer");
+}
+
 int pa_k_probe(int which, size_t bytes, const double* src, double* dst) {
   const size_t n2 = bytes / 16;
   if (which == 0) PA_LAUNCH(k_probe_copy, dim3(8192), dim3(WG), 0, cur_stream(), n2, (const double2*)src, (double2*)dst);

@@ -126,6 +126,7 @@ int pa_k_pack_rows(int n, int ts, const int* idx, const double* X, double* sendb
 
 /* HBM calibration: which = 0 copy src -> dst, 1 read src (dst receives nothing). */
 int pa_k_probe(int which, size_t bytes, const double* src, double* dst);
+int pa_k_spacer(int us);
 
 /* ---- tall-skinny kernels (ecg.c:250,311,330,347,425,438,510 K2; K3; K4) -- */
 /* Partial Gram blocks C = [A0 | A1]^T B over the local rows, one (npan*ts) x ts
