@@ -139,6 +139,11 @@ int preAlps_hip_panel_update(CPLM_Mat_Dense_t* Z, const CPLM_Mat_Dense_t* V0, co
 int preAlps_hip_panel_trsm_update(CPLM_Mat_Dense_t* P, CPLM_Mat_Dense_t* AP, CPLM_Mat_Dense_t* X,
                                   CPLM_Mat_Dense_t* R, const double* host_U, const double* host_alpha,
                                   double* host_res2);
+/* BF-Omin's second half on its own (ecg.c:358-393): P(:, c) = Z(:, piv[c]), c < Z.n, then the leading t columns
+ * times U^-1 (t x t upper triangular, host, column major, piv 0-based on the host); one_pass = the solver's single
+ * kernel, 0 = the three kernels it replaces (same bits). */
+int preAlps_hip_panel_permute_solve(const CPLM_Mat_Dense_t* Z, CPLM_Mat_Dense_t* P, const int* host_piv, int t,
+                                    const double* host_U, int one_pass);
 /* Numeric facts about the built operator / preconditioner, by name:
  * "nnz_local", "rows_local", "halo_rows", "spmm_blocks", "bj_factor_bytes",
  * "bj_max_bandwidth", "bj_parts_local", "bj_nd_blocks" (blocks with the sparse factor),

@@ -83,3 +83,27 @@ int preAlps_hip_panel_trsm_update(CPLM_Mat_Dense_t* P, CPLM_Mat_Dense_t* AP, CPL
   if (rc) return PA_FAIL("triangular solve + update failed: %s", pa_rt_error());
   return 0;
 }
+
+/* BF-Omin's second half on its own (src/solvers/ecg.c:358-393 of the reference): P(:, c) = Z(:, piv[c]) for the n
+ * columns of the panel, then the leading t columns times U^-1 (t x t upper triangular, host, column major).
+ * one_pass != 0: the solver's kernel (k_permute_trsm); 0: the three kernels it replaces (copy, permutation,
+ * triangular solve), whose result it reproduces bit for bit. */
+int preAlps_hip_panel_permute_solve(const CPLM_Mat_Dense_t* Z, CPLM_Mat_Dense_t* P, const int* host_piv, int t,
+                                    const double* host_U, int one_pass) {
+  PA_REQUIRE_GPU();
+  if (!Z || !P || !Z->val || !P->val || !host_piv || !host_U) return PA_FAIL(" wrong test 'Z, P, piv, U != NULL'");
+  int m = Z->info.m, ts = pa_desc_stride(Z), n = Z->info.n;
+  if (P->info.m != m || pa_desc_stride(P) != ts || P->info.n != n || t < 0 || t > n) return PA_FAIL("panel shapes do not match");
+  for (int c = 0; c < n; ++c) if (host_piv[c] < 0 || host_piv[c] >= n) return PA_FAIL("pivot %d outside the panel", host_piv[c]);
+  double* d_u = (double*)pa_rt_malloc(((size_t)t * t + 1) * sizeof(double));
+  int* d_piv = (int*)pa_rt_malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+  int rc = !d_u || !d_piv;
+  rc = rc || pa_rt_h2d(d_u, host_U, (size_t)t * t * sizeof(double)) || pa_rt_h2d(d_piv, host_piv, (size_t)n * sizeof(int));
+  if (one_pass) rc = rc || pa_k_permute_trsm(m, ts, n, d_piv, t, d_u, Z->val, P->val);
+  else rc = rc || pa_k_copy_cols(m, ts, n, Z->val, P->val) || pa_k_permute_cols(m, ts, n, d_piv, P->val) ||
+            pa_k_trsm(m, ts, t, d_u, P->val, NULL);
+  rc = rc || pa_rt_sync();
+  pa_rt_free(d_u); pa_rt_free(d_piv);
+  if (rc) return PA_FAIL("permutation + triangular solve failed: %s", pa_rt_error());
+  return 0;
+}

@@ -77,6 +77,7 @@ EXPORTS = [
     "preAlps_hip_timing_reset", "preAlps_hip_get_time",
     "preAlps_hip_partition_kway", "preAlps_hip_rccl_available",
     "preAlps_hip_panel_gram", "preAlps_hip_panel_update", "preAlps_hip_panel_trsm_update",
+    "preAlps_hip_panel_permute_solve",
     "preAlps_hip_nd_selfcheck", "preAlps_hip_loopback", "preAlps_hip_graphs",
 ]
 
@@ -143,6 +144,7 @@ def load():
     L.preAlps_hip_panel_gram.argtypes = [_PD, _PD, _PD, pd, C.c_int]
     L.preAlps_hip_panel_update.argtypes = [_PD, _PD, _PD, pd, C.c_int]
     L.preAlps_hip_panel_trsm_update.argtypes = [_PD, _PD, _PD, _PD, pd, pd, pd]
+    L.preAlps_hip_panel_permute_solve.argtypes = [_PD, _PD, C.POINTER(C.c_int), C.c_int, pd, C.c_int]
     L.preAlps_hip_nd_selfcheck.argtypes = [C.c_int, pi, pi, pd, C.c_int, pd]
     L.preAlps_hip_partition_kway.argtypes = [C.c_int, pi, pi, C.c_int, pi]
     L.preAlps_hip_timing.restype = None

@@ -104,3 +104,26 @@ def test_trsm_update(panels, m, t, nc):
                      (panels.down(dr, T), Rn)):
         np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max())
     assert abs(res2.value - (Rn ** 2).sum()) <= 1e-11 * (Rn ** 2).sum()
+
+
+@pytest.mark.parametrize("m", [7, 30011])
+@pytest.mark.parametrize("n,t", [(2, 2), (4, 4), (4, 3), (3, 1), (8, 8), (8, 5), (5, 5), (16, 16), (16, 9), (12, 0)])
+def test_permute_solve(panels, m, n, t):
+    """BF-Omin's copy + dlapmt + dtrsm (ecg.c:358-393) in one kernel: against numpy, and bit for bit against the
+    three kernels it replaces; the columns behind the rank keep the permuted copy."""
+    rng = np.random.default_rng(m + 13 * n + t)
+    Z, P0 = rng.standard_normal((m, n)), rng.standard_normal((m, n))
+    piv = rng.permutation(n).astype(np.int32)
+    U = np.asfortranarray(np.triu(rng.standard_normal((t, t))) + 3.0 * np.eye(t)) if t else np.zeros((1, 1))
+    outs = []
+    for one_pass in (1, 0):
+        dz, dp = panels.up(Z, n), panels.up(P0, n)
+        panels.check(panels.L.preAlps_hip_panel_permute_solve(C.byref(dz), C.byref(dp), piv.ctypes.data_as(C.POINTER(C.c_int)),
+                                                             t, _pd(U), one_pass), "permute_solve")
+        outs.append(panels.down(dp, n))
+        np.testing.assert_array_equal(panels.down(dz, n), Z)
+    ref = Z[:, piv].copy()
+    if t:
+        ref[:, :t] = ref[:, :t] @ np.linalg.inv(U)
+    np.testing.assert_allclose(outs[0], ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max())
+    np.testing.assert_array_equal(outs[0], outs[1])
