@@ -46,10 +46,11 @@ def _write_mtx(path, rp, ci, v):
 
 
 @pytest.mark.skipif(not have_mpi, reason="no MPI launcher in this image")
-@pytest.mark.parametrize("alg,t", [(0, 4), (1, 2)])
-def test_mpi_driver_two_ranks_one_gpu_matches_oracle(tmp_path, alg, t):
+@pytest.mark.parametrize("alg,t,red", [(0, 4, 0), (1, 2, 0), (0, 4, 1), (1, 4, 1)])
+def test_mpi_driver_two_ranks_one_gpu_matches_oracle(tmp_path, alg, t, red):
     """examples/ecg_driver.c built against the system MPI: nothing in it but MPI_Init/Finalize and the
-    reference's call sequence; iteration count, residual and the gathered solution against the oracle."""
+    reference's call sequence; iteration count, residual and the gathered solution against the oracle.
+    red = 1: `-r 1`, D-Odir / BF-Omin through the driver's own loop on two ranks."""
     from oracle import oracle as O
     n, nparts, world = 12, 8, 2
     (rp, ci, v), B, perm, rowpos = _problem(n, nparts)
@@ -62,13 +63,15 @@ def test_mpi_driver_two_ranks_one_gpu_matches_oracle(tmp_path, alg, t):
                            "-lprealps_hip", os.path.join(MPI_LIB, "libmpi.so.12"), "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu",
                            "-Wl,-rpath," + os.path.join(ROOT, "prealps_amd"), "-Wl,-rpath," + MPI_LIB, "-lm", "-o", exe])
     env = dict(os.environ, PREALPS_NPARTS=str(nparts), PREALPS_SETUP_TRACE="1", OMP_NUM_THREADS="4")
-    r = subprocess.run([MPIEXEC, "-n", str(world), exe, "-m", mtx, "-e", str(t), "-o", str(alg), "-x", str(tmp_path / "sol")],
-                       env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([MPIEXEC, "-n", str(world), exe, "-m", mtx, "-e", str(t), "-o", str(alg), "-r", str(red),
+                        "-x", str(tmp_path / "sol")], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "hooks: mpi-host-staged" in r.stderr          # two ranks on one device: RCCL is not an option
     it = int(re.search(r"iter: (\d+)", r.stdout).group(1))
     res = float(re.search(r"res : (\S+)", r.stdout).group(1))
-    ref = O.ECG(B, rowpos, t, ortho_alg=O.ORTHODIR if alg == 0 else O.ORTHOMIN).solve(O.reference_rhs(rowpos))
+    ref = O.ECG(B, rowpos, t, O.ORTHODIR if alg == 0 else O.ORTHOMIN, O.ADAPT_BS if red else O.NO_BS_RED).solve(O.reference_rhs(rowpos))
+    if red:
+        assert int(re.search(r"bs  : (\d+)", r.stdout).group(1)) == ref["bs"][-1]
     assert it == ref["iters"], (it, ref["iters"])
     np.testing.assert_allclose(res, ref["final_res"], rtol=2e-6)      # (printed with 7 digits)
     x = np.concatenate([np.fromfile(str(tmp_path / "sol") + ".%d" % k) for k in range(world)])
