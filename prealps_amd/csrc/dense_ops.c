@@ -49,7 +49,7 @@ int preAlps_hip_panel_update(CPLM_Mat_Dense_t* Z, const CPLM_Mat_Dense_t* V0, co
   if (ldb < na) return PA_FAIL("leading dimension %d below %d rows", ldb, na);
   double* d_beta = (double*)pa_rt_malloc((size_t)(ldb * nc > 0 ? ldb * nc : 1) * sizeof(double));
   int rc = !d_beta || pa_rt_h2d(d_beta, host_beta, (size_t)ldb * nc * sizeof(double));
-  rc = rc || pa_k_update_z(m, ts, a_lo, a_hi, nc, d_beta, ldb, V0->val, V1 ? V1->val : V0->val, Z->val, NULL, NULL, NULL, NULL);
+  rc = rc || pa_k_update_z(m, ts, a_lo, a_hi, nc, d_beta, ldb, V0->val, V1 ? V1->val : V0->val, Z->val, NULL, NULL, NULL, NULL, NULL, 0, NULL);
   rc = rc || pa_rt_sync();
   pa_rt_free(d_beta);
   if (rc) return PA_FAIL("panel update failed: %s", pa_rt_error());

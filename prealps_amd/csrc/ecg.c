@@ -87,6 +87,7 @@ typedef struct {
    * (AP is the raw panel, which nothing rewrites) BEFORE the host waits for alpha and decides about a reduction,
    * so the wait and the SVD are hidden behind it; the loop then skips its own apply.  ev_alpha: alpha is on the host. */
   int z_ready;
+  int zz_nblk;        /* partial blocks of Z^T Z the last update kernel left in d_partials (BF-Omin), 0 = none */
   void* ev_alpha;
   double* d_uu;
   int poll;           /* the host polls the word a kernel writes behind the norm instead of waiting for an event */
@@ -687,7 +688,10 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   PA_CHECK(pa_k_update_z(pv->m, pv->ts, v_lo, v_hi, ecg->Z->info.n, pv->d_beta, ecg->beta->info.lda,
                          pv->buf_v[0], pv->buf_v[1], pv->buf_z, note, note ? pv->h_pin : NULL,
                          pv->lazy_norm ? pv->d_uu + (size_t)pv->uu_cur * T * T : NULL,
-                         pv->lazy_norm ? pv->d_uu + (size_t)(1 - pv->uu_cur) * T * T : NULL));
+                         pv->lazy_norm ? pv->d_uu + (size_t)(1 - pv->uu_cur) * T * T : NULL,
+                         /* BF-Omin forms Z^T Z next (8 / 16 columns: the update kernel leaves its partial blocks) */
+                         (ecg->ortho_alg == ORTHOMIN && ecg->bs_red == ADAPT_BS && pv->fuse) ? pv->d_partials : NULL,
+                         T, &pv->zz_nblk));
   if (pv->lazy_norm) pv->uu_cur ^= 1;
   if (note && ecg->Z->info.n <= 0) PA_CHECK(pa_rt_d2h_async(pv->h_pin, note, 2 * sizeof(double)));   /* (no launch above) */
   if (note && !polled) { pv->wait_seq = 0.0; PA_CHECK(pa_rt_event_record(pv->ev_res)); }
@@ -826,7 +830,8 @@ int _preAlps_ECGIterateOmin(preAlps_ECG_t* ecg, int* rci_request) {
       double t0;
       const double* newp = one_pass ? pv->buf_z : ecg->P->val;
       TIC(PA_T_GRAM);
-      PA_CHECK(pa_k_gram(m, ts, newp, NULL, newp, pv->d_partials, &nb));
+      if (one_pass && pv->zz_nblk > 0) nb = pv->zz_nblk;        /* (the update kernel formed the blocks of Z^T Z) */
+      else PA_CHECK(pa_k_gram(m, ts, newp, NULL, newp, pv->d_partials, &nb));
       PA_CHECK(pa_k_finish(pv->d_partials, nb, 1, ts, nrhs, 0, nrhs, pv->d_mu, nrhs));
       TAC(PA_T_GRAM, gemm_t);
       TIC(PA_T_COMM);
@@ -917,7 +922,7 @@ int _preAlps_ECGIterateOdirFused(preAlps_ECG_t* ecg, int* rci_request) {
   {
     int vn = ecg->V->info.n, v_lo = vn < nrhs ? vn : nrhs, v_hi = vn - v_lo;
     PA_CHECK(pa_k_update_z(m, ts, v_lo, v_hi, ecg->Z->info.n, pv->d_beta, ecg->beta->info.lda,
-                           pv->buf_v[0], pv->buf_v[1], pv->buf_z, NULL, NULL, NULL, NULL));
+                           pv->buf_v[0], pv->buf_v[1], pv->buf_z, NULL, NULL, NULL, NULL, NULL, 0, NULL));
   }
   TAC(PA_T_UPDATE, gemm_t);
   if (ecg->bs_red == ADAPT_BS && reduce_directions_odir(ecg, pv, 1, NULL, 0)) return 1;

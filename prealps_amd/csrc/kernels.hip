@@ -1417,13 +1417,39 @@ __device__ __forceinline__ void lazy_coeffs16(const double* __restrict__ beta, i
   __syncthreads();
 }
 
+// Z^T Z next to the update (BF-Omin forms it right behind, ecg.c:361 of the reference: G = P^T P with P = Z): a
+// tile of the new Z in the accumulator layout -- lane (lo, hi): row hi + 4 r, column lo -- is the A operand AND the
+// B operand of step r as it stands (A[i = lo][k = hi], B[k = hi][j = lo], k = the row), so the product costs four
+// matrix instructions per tile and no data movement.  zzc = columns that count (the rest of a 16-wide tile is 0).
+__device__ __forceinline__ void update_z_gram_step(const mfma_d4& z, mfma_d4& zz, size_t r0, int hi, int lo, int m, int zzc) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double zm = (r0 + hi + 4 * r < (size_t)m && lo < zzc) ? z[r] : 0.0;
+    zz = __builtin_amdgcn_mfma_f64_16x16x4f64(zm, zm, zz, 0, 0, 0);
+  }
+}
+// the four wavefronts' sums -> one TS x TS block per workgroup (column major, the layout of k_gram's partial blocks)
+template <int TS>
+__device__ __forceinline__ void update_z_gram_out(const mfma_d4& zz, double* sc, double* __restrict__ zzp, int wave, int lane) {
+  __syncthreads();                       // (sc may still hold the coefficient blocks of the prologue)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sc[wave * 256 + r * 64 + lane] = zz[r];
+  __syncthreads();
+  const int tid = threadIdx.x;           // WG = 256: entry (r, lane) of the tile each
+  const int r = tid >> 6, l = tid & 63, i = (l >> 4) + 4 * r, j = l & 15;
+  double sm = sc[tid];
+#pragma unroll
+  for (int w = 1; w < WG / 64; ++w) sm += sc[w * 256 + tid];
+  if (i < TS && j < TS) zzp[(size_t)blockIdx.x * TS * TS + i + TS * j] = sm;
+}
+
 __global__ __launch_bounds__(WG, 4) void k_update_z_mfma16(int m, int a_lo, int a_hi, int nc,
                                                         const double* __restrict__ beta, int ldb,
                                                         const double* __restrict__ V0,
                                                         const double* __restrict__ V1,
                                                         double* __restrict__ Z,
     const double* note_src, double* note_host, double note_seq,
-    const double* __restrict__ ucur, const double* __restrict__ uprev) {
+    const double* __restrict__ ucur, const double* __restrict__ uprev, double* __restrict__ zzp, int zzc) {
   constexpr int TS = 16;
   __shared__ double sc[7 * 256];
   // (note_host: two words the host is waiting for -- the all-reduced residual norm and the
@@ -1505,6 +1531,7 @@ __global__ __launch_bounds__(WG, 4) void k_update_z_mfma16(int m, int a_lo, int 
     }
     return;
   }
+  mfma_d4 zz = mfma_d4{0.0, 0.0, 0.0, 0.0};
   for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
     const size_t r0 = t << 4;
     mfma_d4 z;
@@ -1533,7 +1560,9 @@ __global__ __launch_bounds__(WG, 4) void k_update_z_mfma16(int m, int a_lo, int 
       const size_t row = r0 + hi + 4 * r;
       if (row < (size_t)m && lo < nc) Z[row * TS + lo] = z[r];
     }
+    if (zzp) update_z_gram_step(z, zz, r0, hi, lo, m, zzc);
   }
+  if (zzp) update_z_gram_out<TS>(zz, sc, zzp, wave, lane);
 }
 
 // 8-column panels: [V0 | V1] is one 16-wide A operand (four k-steps), Z uses half the tile.
@@ -1543,7 +1572,7 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma8(int m, int a_lo, int a_hi
                                                        const double* __restrict__ V1,
                                                        double* __restrict__ Z,
     const double* note_src, double* note_host, double note_seq,
-    const double* __restrict__ ucur, const double* __restrict__ uprev) {
+    const double* __restrict__ ucur, const double* __restrict__ uprev, double* __restrict__ zzp, int zzc) {
   constexpr int TS = 8;
   __shared__ double sc[7 * 256];
   // (note_host: two words the host is waiting for -- the all-reduced residual norm and the
@@ -1617,6 +1646,7 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma8(int m, int a_lo, int a_hi
     }
     return;
   }
+  mfma_d4 zz = mfma_d4{0.0, 0.0, 0.0, 0.0};
   for (size_t t = (size_t)blockIdx.x * (WG / 64) + wave; t < ntile; t += tstride) {
     const size_t r0 = t << 4;
     mfma_d4 z;
@@ -1640,7 +1670,9 @@ __global__ __launch_bounds__(WG) void k_update_z_mfma8(int m, int a_lo, int a_hi
       const size_t row = r0 + hi + 4 * r;
       if (row < (size_t)m && lo < nc) Z[row * TS + lo] = z[r];
     }
+    if (zzp) update_z_gram_step(z, zz, r0, hi, lo, m, zzc);
   }
+  if (zzp) update_z_gram_out<TS>(zz, sc, zzp, wave, lane);
 }
 
 template <int TS>
@@ -3093,6 +3125,10 @@ int pa_k_finish(const double* partials, int nblk, int npan, int ts, int a_lo, in
                 double* out, int ld_out) {
   const int ne = (a_lo + a_hi) * nb;
   if (ne <= 0) return 0;
+  // wide blocks in the Gram buffer of a solver (pa_gram_max_blocks() blocks: the shares and the ticket of
+  // k_finish_wide lie behind them) -- BF-Omin's Z^T Z, up to 2048 blocks from the update kernel
+  if (ts >= 8 && (long long)nblk * npan * ts * ts <= (long long)GRAM_WIDE_BLOCKS * 2 * ts * ts)
+    return finish_wide(partials, nblk, npan, ts, a_lo, a_hi, nb, out, ld_out, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr);
   const int groups = ne > 128 ? (ne + 63) / 64 : 1;    // one workgroup unless the block is large
   PA_LAUNCH(k_finish, dim3(groups), dim3(1024), 0, cur_stream(), partials, nblk, npan, ts, a_lo,
                      a_hi, nb, out, ld_out);
@@ -3180,21 +3216,29 @@ int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, doub
 
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
                   const double* V0, const double* V1, double* Z, const double* note_src, double* note_host,
-                  const double* ucur, const double* uprev) {
+                  const double* ucur, const double* uprev, double* zz_part, int zz_cols, int* zz_nblk) {
+  if (zz_nblk) *zz_nblk = 0;
   if (nc <= 0) return 0;
   if (ucur && (!uprev || nc != a_lo || (a_hi != 0 && a_hi != a_lo))) {
     snprintf(g_kerr, sizeof(g_kerr), "pa_k_update_z: lazy normalisation needs square blocks");
     return 1;
   }
   const double seq_ = take_note_seq(note_host);
+  // zz_part (8 / 16 columns, panels normalised in place): the launch also leaves Z^T Z of the new Z behind, one
+  // ts x ts block per workgroup (*zz_nblk of them, the partial blocks pa_k_finish sums); elsewhere *zz_nblk stays 0
+  double* zzp = (zz_part && zz_nblk && !ucur && (ts == 8 || ts == 16)) ? zz_part : nullptr;
   if (ts == 16) {   // matrix cores (k_update_z_mfma16), one 16-row tile per wavefront and step
-    PA_LAUNCH(k_update_z_mfma16, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
-                       beta, ldb, V0, V1, Z, note_src, note_host, seq_, ucur, uprev);
+    const int grid = grid_rows(m, 4);
+    PA_LAUNCH(k_update_z_mfma16, dim3(grid), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
+                       beta, ldb, V0, V1, Z, note_src, note_host, seq_, ucur, uprev, zzp, zz_cols);
+    if (zzp) *zz_nblk = grid;
     return kfail("k_update_z_mfma16");
   }
   if (ts == 8) {
-    PA_LAUNCH(k_update_z_mfma8, dim3(grid_rows(m, 4)), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
-                       beta, ldb, V0, V1, Z, note_src, note_host, seq_, ucur, uprev);
+    const int grid = grid_rows(m, 4);
+    PA_LAUNCH(k_update_z_mfma8, dim3(grid), dim3(WG), 0, cur_stream(), m, a_lo, a_hi, nc,
+                       beta, ldb, V0, V1, Z, note_src, note_host, seq_, ucur, uprev, zzp, zz_cols);
+    if (zzp) *zz_nblk = grid;
     return kfail("k_update_z_mfma8");
   }
   TS_DISPATCH(ts, PA_LAUNCH((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
