@@ -130,6 +130,33 @@ __device__ __forceinline__ void g4_wait_vm(int n) {
   }
 }
 
+// Few blocks (the pipelined chain below): ring depth, pieces per chunk and the buffer stride are compile-time
+// constants -- G4F_RING buffers of NLD = DQ KiB (a chunk of a band w <= 16 DQ - 16 is 8 (w + 4) doubles <= DQ KiB)
+// plus one more that receives the requests of chunks a block does not have: EVERY chunk step requests exactly NLD
+// pieces, so the wait counts are immediates (the run-time count went through a compare-and-branch tree of ~20
+// scalar instructions, twice per chunk), the buffer addresses are constants off the wavefront's base and the
+// request loop is unrolled.  A request reads NLD KiB from the chunk's start: up to 1 KiB - 8 bytes beyond the
+// chunk's end, i.e. into the next chunk / block or the slack behind the last one (block_jacobi.c allocates it).
+constexpr int G4F_RING = 4;
+template <int N>
+__device__ __forceinline__ void g4_wait_vm_c() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+template <int NLD>
+__device__ __forceinline__ void g4_issue_chunk_c(const double* __restrict__ src, double* lbuf, int lane) {
+  const char* g = reinterpret_cast<const char*>(src) + lane * 16;
+  char* l = reinterpret_cast<char*>(lbuf);
+#pragma unroll
+  for (int o = 0; o < NLD; ++o)
+    __builtin_amdgcn_global_load_lds((glb_ptr)(g + o * 1024), (lds_ptr)(l + o * 1024), 16, 0, 0);
+}
+// chunk cn of the block when the block has it (valid), chunk 0 into the spare buffer otherwise
+template <int NLD>
+__device__ __forceinline__ void g4_request_c(const double* __restrict__ rec, int chunk_doubles, int cn, bool valid,
+                                             double* lds0, int lane) {
+  const double* src = rec + (valid ? (size_t)cn * chunk_doubles : (size_t)0);
+  double* dst = lds0 + (valid ? (cn & (G4F_RING - 1)) : G4F_RING) * (NLD * 128);
+  g4_issue_chunk_c<NLD>(src, dst, lane);
+}
+
 // a value of a 16-lane row rotated by 4 * n lanes inside the row (DPP row_ror)
 template <int N>
 __device__ __forceinline__ double row_ror(double v) {
@@ -422,22 +449,22 @@ __device__ __forceinline__ void g4_bwd_math(double (&T)[NT], const g4_ops<DQ>& o
 // forward chunk C = 2 Q + H; on entry A holds the operands of its first group (waited for)
 template <int NT, int DQ, int Q, int H>
 __device__ __forceinline__ void g4_fwd_chunk_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
-                                               int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                               int ring, g4_ops<DQ>& A, g4_ops<DQ>& B) {
-  constexpr int C = 2 * Q + H;
-  const int nch = (b + 7) >> 3, nld = (chunk_doubles + 127) >> 7;
-  const int cn = C + ring - 1;
-  if (cn < nch) g4_issue_chunk(rec, chunk_doubles, cn, lds0 + (cn & (ring - 1)) * lstride, lane);
-  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (ring - 1)) * lstride);
+                                               int chunk_doubles, double* lds0, int lane, g4_lane ln,
+                                               g4_ops<DQ>& A, g4_ops<DQ>& B) {
+  constexpr int C = 2 * Q + H, NLD = DQ, LS = NLD * 128;
+  const int nch = (b + 7) >> 3;
+  constexpr int cn = C + G4F_RING - 1;
+  g4_request_c<NLD>(rec, chunk_doubles, cn, cn < nch, lds0, lane);
+  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (G4F_RING - 1)) * LS);
   g4_read_ops<NT, DQ, Q, 2 * H + 1, true>(cur + (unsigned)(w + 4) * 32u, w, ln, B);
   g4_fwd_math<NT, DQ, Q, 2 * H>(T, A);
   g4_ops_wait<DQ>(B);
   if (C + 1 < nch) {
-    // the next chunk: everything but the ring - 2 youngest of the chunks in flight must have landed
-    g4_wait_vm(max(0, min(ring - 1, nch - 1 - C) - 1) * nld);
+    // the next chunk was requested G4F_RING - 2 chunk steps before this one: all but the requests since
+    g4_wait_vm_c<(G4F_RING - 2) * NLD>();
     constexpr int Qn = H ? Q + 1 : Q, Gn = H ? 0 : 2;
     if constexpr (Qn < NT) {
-      const unsigned nxt = (unsigned)(uintptr_t)(lds_ptr)(lds0 + ((C + 1) & (ring - 1)) * lstride);
+      const unsigned nxt = (unsigned)(uintptr_t)(lds_ptr)(lds0 + ((C + 1) & (G4F_RING - 1)) * LS);
       g4_read_ops<NT, DQ, Qn, Gn, true>(nxt, w, ln, A);
     }
   }
@@ -447,28 +474,29 @@ __device__ __forceinline__ void g4_fwd_chunk_p(double (&T)[NT], int b, int w, co
 }
 template <int NT, int DQ, int Q>
 __device__ __forceinline__ void g4_fwd_tiles_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
-                                               int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                               int ring, g4_ops<DQ>& A, g4_ops<DQ>& B) {
+                                               int chunk_doubles, double* lds0, int lane, g4_lane ln,
+                                               g4_ops<DQ>& A, g4_ops<DQ>& B) {
   if constexpr (Q < NT) {
     if (16 * Q < b) {
-      g4_fwd_chunk_p<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
-      if (16 * Q + 8 < b) g4_fwd_chunk_p<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
-      g4_fwd_tiles_p<NT, DQ, Q + 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
+      g4_fwd_chunk_p<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
+      if (16 * Q + 8 < b) g4_fwd_chunk_p<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
+      g4_fwd_tiles_p<NT, DQ, Q + 1>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
     }
   }
 }
 
 // backward chunk C: groups 2 H + 1, then 2 H; on entry A holds the operands of group 2 H + 1 -- loaded here when
-// C is the sweep's first chunk (its two buffers are still where the forward sweep left them)
+// C is the sweep's first chunk (the last G4F_RING chunks are still where the forward sweep left them: the
+// requests of chunks the block does not have went to the spare buffer)
 template <int NT, int DQ, int Q, int H>
 __device__ __forceinline__ void g4_bwd_chunk_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
-                                               int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                               int ring, g4_ops<DQ>& A, g4_ops<DQ>& B) {
-  constexpr int C = 2 * Q + H;
-  const int nch = (b + 7) >> 3, nld = (chunk_doubles + 127) >> 7;
-  const int cn = C - (ring - 1);
-  if (cn >= 0 && C < nch - 1) g4_issue_chunk(rec, chunk_doubles, cn, lds0 + (cn & (ring - 1)) * lstride, lane);
-  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (ring - 1)) * lstride);
+                                               int chunk_doubles, double* lds0, int lane, g4_lane ln,
+                                               g4_ops<DQ>& A, g4_ops<DQ>& B) {
+  constexpr int C = 2 * Q + H, NLD = DQ, LS = NLD * 128;
+  const int nch = (b + 7) >> 3;
+  constexpr int cn = C - (G4F_RING - 1);
+  g4_request_c<NLD>(rec, chunk_doubles, cn >= 0 ? cn : 0, cn >= 0 && C < nch - 1, lds0, lane);
+  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (G4F_RING - 1)) * LS);
   if (C == nch - 1) {
     g4_read_ops<NT, DQ, Q, 2 * H + 1, false>(cur + (unsigned)(w + 4) * 32u, w, ln, A);
     g4_ops_wait<DQ>(A);
@@ -477,12 +505,11 @@ __device__ __forceinline__ void g4_bwd_chunk_p(double (&T)[NT], int b, int w, co
   g4_bwd_math<NT, DQ, Q, 2 * H + 1>(T, A, ln);
   g4_ops_wait<DQ>(B);
   if (C > 0) {
-    // chunk C - 1: of the chunks this sweep has requested so far, those below it may still be in flight
-    const int lo = max(0, C - ring + 1), hi = min(C - 2, nch - ring - 1);
-    g4_wait_vm(max(0, hi - lo + 1) * nld);
+    // chunk C - 1: requested G4F_RING - 2 chunk steps before this one, or still there from the forward sweep
+    g4_wait_vm_c<(G4F_RING - 2) * NLD>();
     constexpr int Qn = H ? Q : Q - 1, Gn = H ? 1 : 3;
     if constexpr (Qn >= 0) {
-      const unsigned nxt = (unsigned)(uintptr_t)(lds_ptr)(lds0 + ((C - 1) & (ring - 1)) * lstride);
+      const unsigned nxt = (unsigned)(uintptr_t)(lds_ptr)(lds0 + ((C - 1) & (G4F_RING - 1)) * LS);
       g4_read_ops<NT, DQ, Qn, Gn, false>(nxt + (unsigned)(w + 4) * 32u, w, ln, A);
     }
   }
@@ -492,14 +519,14 @@ __device__ __forceinline__ void g4_bwd_chunk_p(double (&T)[NT], int b, int w, co
 }
 template <int NT, int DQ, int Q>
 __device__ __forceinline__ void g4_bwd_tiles_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
-                                               int chunk_doubles, double* lds0, int lstride, int lane, g4_lane ln,
-                                               int ring, g4_ops<DQ>& A, g4_ops<DQ>& B) {
+                                               int chunk_doubles, double* lds0, int lane, g4_lane ln,
+                                               g4_ops<DQ>& A, g4_ops<DQ>& B) {
   if constexpr (Q >= 0) {
     if (16 * Q < b) {
-      if (16 * Q + 8 < b) g4_bwd_chunk_p<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
-      g4_bwd_chunk_p<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
+      if (16 * Q + 8 < b) g4_bwd_chunk_p<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
+      g4_bwd_chunk_p<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
     }
-    g4_bwd_tiles_p<NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, ln, ring, A, B);
+    g4_bwd_tiles_p<NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
   }
 }
 
@@ -539,7 +566,8 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
   lf.hi = hi;
   lf.blk = blk;
 
-  g4_issue_chunk(rec, chunk_doubles, 0, lds0, lane);
+  if constexpr (PIPE) g4_request_c<DQ>(rec, chunk_doubles, 0, true, lds0, lane);
+  else g4_issue_chunk(rec, chunk_doubles, 0, lds0, lane);
   double T[NC * NT];
   const int* __restrict__ mp = map_f + r0;
   // Where the block's rows lie in the panel: row r0 + map[j], map < b <= 256 -- four of them to a register,
@@ -574,16 +602,20 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
     for (int q = 0; q < NT; ++q) mpk[q >> 2] |= mpv[q] << (8 * (q & 3));
   }
   // the rest of the ring behind the panel loads, so that the newest requests are all chunks
-  for (int c = 1; c < ring - 1 && 8 * c < b; ++c) g4_issue_chunk(rec, chunk_doubles, c, lds0 + c * lstride, lane);
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int c = 1; c < G4F_RING - 1; ++c) g4_request_c<DQ>(rec, chunk_doubles, c, 8 * c < b, lds0, lane);
+  } else {
+    for (int c = 1; c < ring - 1 && 8 * c < b; ++c) g4_issue_chunk(rec, chunk_doubles, c, lds0 + c * lstride, lane);
+  }
 
   g4_ops<DQ> opA, opB;       // PIPE: the operands of the group at hand and of the next one
   if constexpr (PIPE) {
     static_assert(NC == 1, "the pipelined chain is built for panels of up to 4 columns");
-    const int nch = (b + 7) >> 3, nld = (chunk_doubles + 127) >> 7;
-    g4_wait_vm(min(ring - 2, nch - 1) * nld);           // chunk 0 (requested first, the rest of the ring behind it)
+    g4_wait_vm_c<(G4F_RING - 2) * DQ>();           // chunk 0 (requested first, the rest of the ring behind it)
     g4_read_ops<NT, DQ, 0, 0, true>((unsigned)(uintptr_t)(lds_ptr)lds0, w, lf, opA);
     g4_ops_wait<DQ>(opA);
-    g4_fwd_tiles_p<NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring, opA, opB);
+    g4_fwd_tiles_p<NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lane, lf, opA, opB);
   } else {
     g4_fwd_tiles<NC, NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring);
   }
@@ -632,7 +664,7 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
 #pragma unroll
         for (int q = 0; q < NT; ++q) apv[q] = gprev[gr.base + ((mpk[q >> 2] >> (8 * (q & 3))) & 255u) * gr.xs];
       }
-      g4_bwd_tiles_p<NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lb, ring, opA, opB);
+      g4_bwd_tiles_p<NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lane, lb, opA, opB);
       if constexpr (GP) {
 #pragma unroll
         for (int q = 1; q < NT; ++q) {
@@ -723,24 +755,30 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
   }
   const int blocks = (count + waves - 1) / waves;
   if constexpr (NC == 1 && NT == 12 && DQ <= 5) {
-    // few blocks (deep ring): the software-pipelined group chain
+    // few blocks (fewer than two per SIMD): the software-pipelined group chain with its compile-time ring
+    // (G4F_RING buffers of DQ KiB and the spare one per wavefront)
     if (ring >= 4) {
+      const int per_wave_f = (G4F_RING + 1) * DQ * 128;
+      int waves_f = (160 * 1024) / (per_wave_f * 8);
+      if (waves_f > 4) waves_f = 4;
+      const size_t lds_f = (size_t)waves_f * per_wave_f * 8;
       static size_t configured_p = 0;
-      if (lds > 64 * 1024 && lds > configured_p) {
+      if (lds_f > 64 * 1024 && lds_f > configured_p) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NC, NT, DQ, 1, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_g4<NC, NT, DQ, 1, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess)
           return kfail("hipFuncSetAttribute(k_bj_g4, pipelined)");
-        configured_p = lds;
+        configured_p = lds_f;
       }
+      const int blocks_f = (count + waves_f - 1) / waves_f;
       if (pa_g4_gram_part && xs == 4 && ncol == 4)
-        PA_LAUNCH((k_bj_g4<NC, NT, DQ, 1, true, true>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
-                  pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out,
+        PA_LAUNCH((k_bj_g4<NC, NT, DQ, 1, true, true>), dim3(blocks_f), dim3(64 * waves_f), lds_f, cur_stream(), list, count, pl->row0,
+                  pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave_f, G4F_RING, xs, ncol, in, out,
                   pa_g4_gram_prev, pa_g4_gram_part);
       else
-        PA_LAUNCH((k_bj_g4<NC, NT, DQ, 1, false, true>), dim3(blocks), dim3(64 * waves), lds, cur_stream(), list, count, pl->row0,
-                  pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave, ring, xs, ncol, in, out,
+        PA_LAUNCH((k_bj_g4<NC, NT, DQ, 1, false, true>), dim3(blocks_f), dim3(64 * waves_f), lds_f, cur_stream(), list, count, pl->row0,
+                  pl->nrows, pl->bw, pl->off2, pl->map_f, pl->Lg4, pl->invd_f, per_wave_f, G4F_RING, xs, ncol, in, out,
                   (const double*)nullptr, (double*)nullptr);
       return kfail("k_bj_g4");
     }

@@ -586,8 +586,8 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
       if (!s->d_off2 || pa_rt_h2d(s->d_off2, off2, ((size_t)np + 1) * sizeof(long long)))
         rc = PA_FAIL("allocating the second sweep records failed: %s", pa_rt_error());
       if (!rc && any_g4) {
-        s->d_Lg4 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
-        if (!s->d_Lg4 || pa_rt_memset(s->d_Lg4, 0, ((size_t)tot2 + 512) * sizeof(double)))
+        s->d_Lg4 = (double*)pa_rt_malloc(((size_t)tot2 + 1024) * sizeof(double));
+        if (!s->d_Lg4 || pa_rt_memset(s->d_Lg4, 0, ((size_t)tot2 + 1024) * sizeof(double)))
           rc = PA_FAIL("allocating the one-copy sweep records failed: %s", pa_rt_error());
         for (int c = 0; c < s->nclass && !rc; ++c)
           if (s->class_g4[c] &&
@@ -596,8 +596,8 @@ int preAlps_BlockJacobiCreate(CPLM_Mat_CSR_t* A, int* rowPos, int sizeRowPos, in
         if (!rc) s->g4_bytes = 8.0 * (double)tot2;
       }
       if (!rc && any_pairs) {
-        s->d_Lf2 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
-        s->d_Lb2 = (double*)pa_rt_malloc(((size_t)tot2 + 512) * sizeof(double));
+        s->d_Lf2 = (double*)pa_rt_malloc(((size_t)tot2 + 1024) * sizeof(double));
+        s->d_Lb2 = (double*)pa_rt_malloc(((size_t)tot2 + 1024) * sizeof(double));
         if (!s->d_Lf2 || !s->d_Lb2 ||
             pa_rt_memset(s->d_Lf2 + tot2, 0, 512 * sizeof(double)) || pa_rt_memset(s->d_Lb2 + tot2, 0, 512 * sizeof(double)))
           rc = PA_FAIL("allocating the paired sweep records failed: %s", pa_rt_error());
