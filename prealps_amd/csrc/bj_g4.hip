@@ -426,6 +426,43 @@ __device__ __forceinline__ void g4_read_ops(unsigned cur, int w, g4_lane ln, g4_
     }
   }
 }
+// Few blocks: where a lane reads its operands depends on (GQ, dq) and the band only, not on the chunk -- with the
+// compile-time ring the chunk's buffer is an immediate offset of the read.  The 12 + 4 DQ LDS addresses of a
+// sweep are formed once (they were 25 vector instructions per group: compare, select, clamp, shift-add) and the
+// eight reads of a group take no address arithmetic at all.  An odd group is the second record of its chunk.
+template <int DQ> struct g4_pre { unsigned ca[4], cb[4], cc[4], cf[DQ][4]; };
+template <int DQ, bool FWD>
+__device__ __forceinline__ void g4_make_pre(unsigned base, int w, g4_lane ln, g4_pre<DQ>& p) {
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const unsigned cur = base + (unsigned)(gq & 1) * (unsigned)(w + 4) * 32u;
+    const unsigned zero_ad = cur + (unsigned)w * 32u, mine = zero_ad + ln.cg;
+    const bool here = ln.blk == gq;
+    p.ca[gq] = (here && ln.hi == (FWD ? 0 : 3)) ? mine : zero_ad;
+    p.cb[gq] = (here && ln.hi == (FWD ? 1 : 2)) ? mine : zero_ad;
+    p.cc[gq] = (here && ln.hi == (FWD ? 2 : 1)) ? mine : zero_ad;
+    asm volatile("" : "+v"(p.ca[gq]), "+v"(p.cb[gq]), "+v"(p.cc[gq]));
+#pragma unroll
+    for (int dq = 0; dq < DQ; ++dq) {
+      const unsigned sidx = min((unsigned)(ln.cX - (16 * dq - 4 * gq)), (unsigned)w);
+      p.cf[dq][gq] = cur + sidx * 32u + ln.aX;
+      asm volatile("" : "+v"(p.cf[dq][gq]));
+    }
+  }
+}
+// the operands of group GQ of tile Q out of ring buffer BUF (LSB = bytes per buffer)
+template <int NT, int DQ, int Q, int GQ, int BUF>
+__device__ __forceinline__ void g4_read_ops_c(const g4_pre<DQ>& p, g4_ops<DQ>& o) {
+  constexpr int OFF = BUF * DQ * 1024;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(o.a0) : "v"(p.ca[GQ]), "n"(OFF));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(o.a1) : "v"(p.cb[GQ]), "n"(OFF));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(o.a2) : "v"(p.cc[GQ]), "n"(OFF));
+#pragma unroll
+  for (int dq = 0; dq < DQ; ++dq) {
+    o.cf[dq] = 0.0;
+    if (Q + dq < NT) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(o.cf[dq]) : "v"(p.cf[dq][GQ]), "n"(OFF));
+  }
+}
 template <int NT, int DQ, int Q, int GQ>
 __device__ __forceinline__ void g4_fwd_math(double (&T)[NT], const g4_ops<DQ>& o) {
   g4_corner_solve<1, NT, Q>(T, o.a0, o.a1, o.a2);
@@ -448,39 +485,35 @@ __device__ __forceinline__ void g4_bwd_math(double (&T)[NT], const g4_ops<DQ>& o
 
 // forward chunk C = 2 Q + H; on entry A holds the operands of its first group (waited for)
 template <int NT, int DQ, int Q, int H>
-__device__ __forceinline__ void g4_fwd_chunk_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
-                                               int chunk_doubles, double* lds0, int lane, g4_lane ln,
+__device__ __forceinline__ void g4_fwd_chunk_p(double (&T)[NT], int b, const double* __restrict__ rec,
+                                               int chunk_doubles, double* lds0, int lane, const g4_pre<DQ>& pre,
                                                g4_ops<DQ>& A, g4_ops<DQ>& B) {
   constexpr int C = 2 * Q + H, NLD = DQ, LS = NLD * 128;
   const int nch = (b + 7) >> 3;
   constexpr int cn = C + G4F_RING - 1;
   g4_request_c<NLD>(rec, chunk_doubles, cn, cn < nch, lds0, lane);
-  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (G4F_RING - 1)) * LS);
-  g4_read_ops<NT, DQ, Q, 2 * H + 1, true>(cur + (unsigned)(w + 4) * 32u, w, ln, B);
+  g4_read_ops_c<NT, DQ, Q, 2 * H + 1, (C & (G4F_RING - 1))>(pre, B);
   g4_fwd_math<NT, DQ, Q, 2 * H>(T, A);
   g4_ops_wait<DQ>(B);
   if (C + 1 < nch) {
     // the next chunk was requested G4F_RING - 2 chunk steps before this one: all but the requests since
     g4_wait_vm_c<(G4F_RING - 2) * NLD>();
     constexpr int Qn = H ? Q + 1 : Q, Gn = H ? 0 : 2;
-    if constexpr (Qn < NT) {
-      const unsigned nxt = (unsigned)(uintptr_t)(lds_ptr)(lds0 + ((C + 1) & (G4F_RING - 1)) * LS);
-      g4_read_ops<NT, DQ, Qn, Gn, true>(nxt, w, ln, A);
-    }
+    if constexpr (Qn < NT) g4_read_ops_c<NT, DQ, Qn, Gn, ((C + 1) & (G4F_RING - 1))>(pre, A);
   }
   g4_fwd_math<NT, DQ, Q, 2 * H + 1>(T, B);
   if (C + 1 < nch) g4_ops_wait<DQ>(A);
   asm volatile("" ::: "memory");
 }
 template <int NT, int DQ, int Q>
-__device__ __forceinline__ void g4_fwd_tiles_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
-                                               int chunk_doubles, double* lds0, int lane, g4_lane ln,
+__device__ __forceinline__ void g4_fwd_tiles_p(double (&T)[NT], int b, const double* __restrict__ rec,
+                                               int chunk_doubles, double* lds0, int lane, const g4_pre<DQ>& pre,
                                                g4_ops<DQ>& A, g4_ops<DQ>& B) {
   if constexpr (Q < NT) {
     if (16 * Q < b) {
-      g4_fwd_chunk_p<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
-      if (16 * Q + 8 < b) g4_fwd_chunk_p<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
-      g4_fwd_tiles_p<NT, DQ, Q + 1>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
+      g4_fwd_chunk_p<NT, DQ, Q, 0>(T, b, rec, chunk_doubles, lds0, lane, pre, A, B);
+      if (16 * Q + 8 < b) g4_fwd_chunk_p<NT, DQ, Q, 1>(T, b, rec, chunk_doubles, lds0, lane, pre, A, B);
+      g4_fwd_tiles_p<NT, DQ, Q + 1>(T, b, rec, chunk_doubles, lds0, lane, pre, A, B);
     }
   }
 }
@@ -489,44 +522,40 @@ __device__ __forceinline__ void g4_fwd_tiles_p(double (&T)[NT], int b, int w, co
 // C is the sweep's first chunk (the last G4F_RING chunks are still where the forward sweep left them: the
 // requests of chunks the block does not have went to the spare buffer)
 template <int NT, int DQ, int Q, int H>
-__device__ __forceinline__ void g4_bwd_chunk_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
-                                               int chunk_doubles, double* lds0, int lane, g4_lane ln,
+__device__ __forceinline__ void g4_bwd_chunk_p(double (&T)[NT], int b, const double* __restrict__ rec,
+                                               int chunk_doubles, double* lds0, int lane, g4_lane ln, const g4_pre<DQ>& pre,
                                                g4_ops<DQ>& A, g4_ops<DQ>& B) {
   constexpr int C = 2 * Q + H, NLD = DQ, LS = NLD * 128;
   const int nch = (b + 7) >> 3;
   constexpr int cn = C - (G4F_RING - 1);
   g4_request_c<NLD>(rec, chunk_doubles, cn >= 0 ? cn : 0, cn >= 0 && C < nch - 1, lds0, lane);
-  const unsigned cur = (unsigned)(uintptr_t)(lds_ptr)(lds0 + (C & (G4F_RING - 1)) * LS);
   if (C == nch - 1) {
-    g4_read_ops<NT, DQ, Q, 2 * H + 1, false>(cur + (unsigned)(w + 4) * 32u, w, ln, A);
+    g4_read_ops_c<NT, DQ, Q, 2 * H + 1, (C & (G4F_RING - 1))>(pre, A);
     g4_ops_wait<DQ>(A);
   }
-  g4_read_ops<NT, DQ, Q, 2 * H, false>(cur, w, ln, B);
+  g4_read_ops_c<NT, DQ, Q, 2 * H, (C & (G4F_RING - 1))>(pre, B);
   g4_bwd_math<NT, DQ, Q, 2 * H + 1>(T, A, ln);
   g4_ops_wait<DQ>(B);
   if (C > 0) {
     // chunk C - 1: requested G4F_RING - 2 chunk steps before this one, or still there from the forward sweep
     g4_wait_vm_c<(G4F_RING - 2) * NLD>();
     constexpr int Qn = H ? Q : Q - 1, Gn = H ? 1 : 3;
-    if constexpr (Qn >= 0) {
-      const unsigned nxt = (unsigned)(uintptr_t)(lds_ptr)(lds0 + ((C - 1) & (G4F_RING - 1)) * LS);
-      g4_read_ops<NT, DQ, Qn, Gn, false>(nxt + (unsigned)(w + 4) * 32u, w, ln, A);
-    }
+    if constexpr (Qn >= 0) g4_read_ops_c<NT, DQ, Qn, Gn, ((C - 1) & (G4F_RING - 1))>(pre, A);
   }
   g4_bwd_math<NT, DQ, Q, 2 * H>(T, B, ln);
   if (C > 0) g4_ops_wait<DQ>(A);
   asm volatile("" ::: "memory");
 }
 template <int NT, int DQ, int Q>
-__device__ __forceinline__ void g4_bwd_tiles_p(double (&T)[NT], int b, int w, const double* __restrict__ rec,
-                                               int chunk_doubles, double* lds0, int lane, g4_lane ln,
+__device__ __forceinline__ void g4_bwd_tiles_p(double (&T)[NT], int b, const double* __restrict__ rec,
+                                               int chunk_doubles, double* lds0, int lane, g4_lane ln, const g4_pre<DQ>& pre,
                                                g4_ops<DQ>& A, g4_ops<DQ>& B) {
   if constexpr (Q >= 0) {
     if (16 * Q < b) {
-      if (16 * Q + 8 < b) g4_bwd_chunk_p<NT, DQ, Q, 1>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
-      g4_bwd_chunk_p<NT, DQ, Q, 0>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
+      if (16 * Q + 8 < b) g4_bwd_chunk_p<NT, DQ, Q, 1>(T, b, rec, chunk_doubles, lds0, lane, ln, pre, A, B);
+      g4_bwd_chunk_p<NT, DQ, Q, 0>(T, b, rec, chunk_doubles, lds0, lane, ln, pre, A, B);
     }
-    g4_bwd_tiles_p<NT, DQ, Q - 1>(T, b, w, rec, chunk_doubles, lds0, lane, ln, A, B);
+    g4_bwd_tiles_p<NT, DQ, Q - 1>(T, b, rec, chunk_doubles, lds0, lane, ln, pre, A, B);
   }
 }
 
@@ -612,10 +641,12 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
   g4_ops<DQ> opA, opB;       // PIPE: the operands of the group at hand and of the next one
   if constexpr (PIPE) {
     static_assert(NC == 1, "the pipelined chain is built for panels of up to 4 columns");
+    g4_pre<DQ> pf;
+    g4_make_pre<DQ, true>((unsigned)(uintptr_t)(lds_ptr)lds0, w, lf, pf);
     g4_wait_vm_c<(G4F_RING - 2) * DQ>();           // chunk 0 (requested first, the rest of the ring behind it)
-    g4_read_ops<NT, DQ, 0, 0, true>((unsigned)(uintptr_t)(lds_ptr)lds0, w, lf, opA);
+    g4_read_ops_c<NT, DQ, 0, 0, 0>(pf, opA);
     g4_ops_wait<DQ>(opA);
-    g4_fwd_tiles_p<NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lane, lf, opA, opB);
+    g4_fwd_tiles_p<NT, DQ, 0>(T, b, rec, chunk_doubles, lds0, lane, pf, opA, opB);
   } else {
     g4_fwd_tiles<NC, NT, DQ, 0>(T, b, w, rec, chunk_doubles, lds0, lstride, lane, lf, ring);
   }
@@ -664,7 +695,9 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
 #pragma unroll
         for (int q = 0; q < NT; ++q) apv[q] = gprev[gr.base + ((mpk[q >> 2] >> (8 * (q & 3))) & 255u) * gr.xs];
       }
-      g4_bwd_tiles_p<NT, DQ, NT - 1>(T, b, w, rec, chunk_doubles, lds0, lane, lb, opA, opB);
+      g4_pre<DQ> pb;
+      g4_make_pre<DQ, false>((unsigned)(uintptr_t)(lds_ptr)lds0, w, lb, pb);
+      g4_bwd_tiles_p<NT, DQ, NT - 1>(T, b, rec, chunk_doubles, lds0, lane, lb, pb, opA, opB);
       if constexpr (GP) {
 #pragma unroll
         for (int q = 1; q < NT; ++q) {
