@@ -685,6 +685,15 @@ static int orthogonalise_z(preAlps_ECG_t* ecg, ecg_priv_t* pv) {
   int v_lo = vn < T ? vn : T, v_hi = vn - v_lo;
   int polled = note && pv->poll && ecg->Z->info.n > 0;
   if (polled) { pv->wait_seq = (pv->seq += 1.0); pa_k_note_seq(pv->wait_seq); }
+  /* several processes: the Z written here is the X of the product that follows (shift_directions rotates it into P);
+   * the rows the neighbours need are packed from the kernel's registers and the operator skips its pack launch
+   * (when P turns out to be another buffer -- copies instead of rotation, BF-Omin's permuted panel -- it packs) */
+  if ((g_own_loop > 0 || rci_fuse()) && pv->ts <= 4 && ecg->Z->info.n > 0 && !pv->use_graphs && pa_world_size() > 1) {
+    const int* pk_off = NULL; const int* pk_slot = NULL; double* sendbuf = NULL;
+    if (pa_operator_pack_hint(pv->ts, pv->buf_z, &pk_off, &pk_slot, &sendbuf) &&
+        !pa_k_update_z_pack(pv->ts, pk_off, pk_slot, sendbuf))
+      pa_operator_pack_hint(pv->ts, NULL, &pk_off, &pk_slot, &sendbuf);      /* (not taken: withdraw) */
+  }
   PA_CHECK(pa_k_update_z(pv->m, pv->ts, v_lo, v_hi, ecg->Z->info.n, pv->d_beta, ecg->beta->info.lda,
                          pv->buf_v[0], pv->buf_v[1], pv->buf_z, note, note ? pv->h_pin : NULL,
                          pv->lazy_norm ? pv->d_uu + (size_t)pv->uu_cur * T * T : NULL,

@@ -1248,7 +1248,11 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
                                                  const double* __restrict__ V1,
                                                  double* __restrict__ Z,
     const double* note_src, double* note_host, double note_seq,
-    const double* __restrict__ ucur, const double* __restrict__ uprev) {
+    const double* __restrict__ ucur, const double* __restrict__ uprev,
+    const int* __restrict__ pk_off, const int* __restrict__ pk_slot, double* __restrict__ sendbuf) {
+  // pk_off != null (several processes, pa_k_update_z_pack): the new rows of Z are the next product's X -- the rows
+  // the neighbours need go into the send buffer from here (row r into the slots pk_slot[pk_off[r] .. pk_off[r + 1])),
+  // k_pack_rows is not launched
   __shared__ double sb[2 * TS * TS];
   __shared__ double sc[7 * TS * TS];
   // (note_host: two words the host is waiting for -- the all-reduced residual norm and the
@@ -1332,6 +1336,7 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
         }
       }
       store_row<TS>(Z, row, o);
+      if (pk_off) for (int k = pk_off[row], k1 = pk_off[row + 1]; k < k1; ++k) store_row<TS>(sendbuf, (size_t)pk_slot[k], o);
     }
     return;
   }
@@ -1356,6 +1361,7 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
       }
     }
     store_row<TS>(Z, row, z);
+    if (pk_off) for (int k = pk_off[row], k1 = pk_off[row + 1]; k < k1; ++k) store_row<TS>(sendbuf, (size_t)pk_slot[k], z);
   }
 }
 
@@ -3214,9 +3220,21 @@ int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, doub
   return kfail("k_trace_finish");
 }
 
+/* One-shot: the next pa_k_update_z on a panel of up to 4 columns also packs the send rows of the Z it writes
+ * (pa_operator_pack_hint).  Returns 0 when that launch would not take it (wider panels). */
+static struct { const int* off; const int* slot; double* buf; } g_zpack;
+int pa_k_update_z_pack(int ts, const int* pk_off, const int* pk_slot, double* sendbuf) {
+  g_zpack.off = g_zpack.slot = nullptr; g_zpack.buf = nullptr;
+  if (ts > 4 || !pk_off || !pk_slot || !sendbuf) return 0;
+  g_zpack.off = pk_off; g_zpack.slot = pk_slot; g_zpack.buf = sendbuf;
+  return 1;
+}
+
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
                   const double* V0, const double* V1, double* Z, const double* note_src, double* note_host,
                   const double* ucur, const double* uprev, double* zz_part, int zz_cols, int* zz_nblk) {
+  const auto pk = g_zpack;
+  g_zpack.off = g_zpack.slot = nullptr; g_zpack.buf = nullptr;
   if (zz_nblk) *zz_nblk = 0;
   if (nc <= 0) return 0;
   if (ucur && (!uprev || nc != a_lo || (a_hi != 0 && a_hi != a_lo))) {
@@ -3242,7 +3260,8 @@ int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta,
     return kfail("k_update_z_mfma8");
   }
   TS_DISPATCH(ts, PA_LAUNCH((k_update_z<TS_>), dim3(grid_rows(m, 2)), dim3(WG), 0,
-                                     cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z, note_src, note_host, seq_, ucur, uprev));
+                                     cur_stream(), m, a_lo, a_hi, nc, beta, ldb, V0, V1, Z, note_src, note_host, seq_, ucur, uprev,
+                                     pk.off, pk.slot, pk.buf));
   return kfail("k_update_z");
 }
 

@@ -55,6 +55,8 @@ typedef struct {
   int* send_idx;     /* local rows packed for the peers, peer after peer */
   int* halo_cols;    /* global row of every halo slot, ascending */
   int* d_send_idx;
+  int* d_pk_off; int* d_pk_slot;   /* the inverse of send_idx: row r is packed into slots pk_slot[pk_off[r] .. pk_off[r + 1]) */
+  const double* prepacked;         /* the panel whose send rows the solver's update kernel has already packed (pa_operator_pack_hint) */
   double* d_sendbuf; double* d_halo;
   int buf_ts;        /* stride the buffers are sized for */
   void* ev_packed;   /* send buffer is packed (main stream) */
@@ -141,6 +143,7 @@ void preAlps_OperatorFree(void) {
   free(o->send_idx); free(o->halo_cols);
   pa_rt_event_destroy(o->ev_packed); pa_rt_event_destroy(o->ev_halo);
   pa_rt_free(o->d_send_idx); pa_rt_free(o->d_sendbuf); pa_rt_free(o->d_halo);
+  pa_rt_free(o->d_pk_off); pa_rt_free(o->d_pk_slot);
   free(o->colPos_dummy);
   memset(o, 0, sizeof(*o));
 }
@@ -1221,6 +1224,43 @@ static int ensure_halo_buffers(pa_operator_t* o, int ts) {
   return 0;
 }
 
+/* The kernel that WRITES the panel X the next preAlps_BlockOperator call will multiply (the second half of an ECG
+ * iteration: the new search directions) can pack the rows the neighbours need while it has them in registers -- one
+ * launch less per iteration (k_pack_rows: 5 us of the 83 us a one-of-eight shard of the headline problem takes).
+ * Returns 1 and the inverse send list (row -> slots of the send buffer, rows of `ts` doubles) when this process has
+ * neighbours; the operator then skips its own pack for exactly that panel pointer, once.  The caller promises that
+ * nothing else writes X in between (the library's own loops, PREALPS_RCI_FUSE=1). */
+static long long g_packs_fused = 0;       /* products whose send rows the solver's update kernel had packed */
+int pa_operator_pack_hint(int ts, const double* X, const int** pk_off, const int** pk_slot, double** sendbuf) {
+  pa_operator_t* o = &g_op;
+  o->prepacked = NULL;
+  if (!o->info.built || g_plan_only || pa_world_size() <= 1 || o->npeers <= 0 || o->nsend <= 0 || !X) return 0;
+  if (!env_int("PREALPS_PACK_FUSE", 1)) return 0;
+  if (ensure_halo_buffers(o, ts)) return 0;
+  if (o->buf_ts != ts) return 0;            /* (buffers sized for a wider panel: slots would be ts_buf apart) */
+  if (!o->d_pk_off) {
+    int m = o->info.m;
+    int* off = (int*)calloc((size_t)m + 2, sizeof(int));
+    int* slot = (int*)malloc((size_t)o->nsend * sizeof(int));
+    int ok = off && slot;
+    if (ok) {
+      for (int i = 0; i < o->nsend; ++i) ++off[o->send_idx[i] + 2];
+      for (int r = 0; r < m; ++r) off[r + 2] += off[r + 1];       /* off[r + 1] = first slot entry of row r */
+      for (int i = 0; i < o->nsend; ++i) slot[off[o->send_idx[i] + 1]++] = i;   /* ... now off[r + 1] = end of row r */
+      o->d_pk_off = (int*)pa_rt_malloc(((size_t)m + 1) * sizeof(int));
+      o->d_pk_slot = (int*)pa_rt_malloc((size_t)o->nsend * sizeof(int));
+      ok = o->d_pk_off && o->d_pk_slot && !pa_rt_h2d(o->d_pk_off, off, ((size_t)m + 1) * sizeof(int)) &&
+           !pa_rt_h2d(o->d_pk_slot, slot, (size_t)o->nsend * sizeof(int));
+      if (!ok) { pa_rt_free(o->d_pk_off); pa_rt_free(o->d_pk_slot); o->d_pk_off = o->d_pk_slot = NULL; }
+    }
+    free(off); free(slot);
+    if (!ok) return 0;
+  }
+  *pk_off = o->d_pk_off; *pk_slot = o->d_pk_slot; *sendbuf = o->d_sendbuf;
+  o->prepacked = X;
+  return 1;
+}
+
 /* Cut the SpMM plan for a given enlarging factor now instead of at the first
  * preAlps_BlockOperator call (it is host work proportional to the local nonzeros). */
 int preAlps_hip_prepare_operator(int enlFac) {
@@ -1293,8 +1333,12 @@ int preAlps_BlockOperator(CPLM_Mat_Dense_t* X, CPLM_Mat_Dense_t* AX) {
     if (overlap_env == -2) overlap_env = env_int("PREALPS_HALO_OVERLAP", -1);
     int overlap = overlap_env >= 0 ? overlap_env
                                    : (double)o->lnnz * o->plan.n_interior / (o->plan.nblk > 0 ? o->plan.nblk : 1) >= 12e6;
+    /* (the solver's update kernel has packed exactly this panel: pa_operator_pack_hint) */
+    int packed = o->prepacked && o->prepacked == X->val && o->buf_ts == ts;
+    o->prepacked = NULL;
+    g_packs_fused += packed;
     if (!overlap) {
-      PA_CHECK(pa_k_pack_rows(o->nsend, ts, o->d_send_idx, X->val, o->d_sendbuf));
+      if (!packed) PA_CHECK(pa_k_pack_rows(o->nsend, ts, o->d_send_idx, X->val, o->d_sendbuf));
       rc = pa_exchange(o->d_sendbuf, o->send_cnt, o->d_halo, o->recv_cnt, o->peers, o->npeers);
       if (rc) return rc;
       PA_CHECK(pa_k_spmm(&o->plan, ts, X->val, o->d_halo, AX->val, 2));
@@ -1307,7 +1351,7 @@ int preAlps_BlockOperator(CPLM_Mat_Dense_t* X, CPLM_Mat_Dense_t* AX) {
      * computes the blocks that read no halo row; the halo-reading blocks wait for it */
     void* main_stream = pa_rt_stream();
     void* side = pa_rt_side_stream();
-    PA_CHECK(pa_k_pack_rows(o->nsend, ts, o->d_send_idx, X->val, o->d_sendbuf));
+    if (!packed) PA_CHECK(pa_k_pack_rows(o->nsend, ts, o->d_send_idx, X->val, o->d_sendbuf));
     PA_CHECK(pa_rt_event_record_on(o->ev_packed, main_stream));
     PA_CHECK(pa_rt_stream_wait_event(side, o->ev_packed));
     pa_rt_set_stream(side);
@@ -1335,6 +1379,7 @@ int preAlps_hip_get_stat(const char* key, double* value) {
   else if (!strcmp(key, "spmm_blocks")) *value = o->plan.nblk;
   else if (!strcmp(key, "spmm_gram_launches")) *value = (double)pa_k_spmm_gram_launches();
   else if (!strcmp(key, "bj_gram_applies")) *value = (double)pa_k_bj_gram_applies();
+  else if (!strcmp(key, "packs_fused")) *value = (double)g_packs_fused;
   else if (!strcmp(key, "spmm_slices")) *value = o->plan.nslices;
   else if (!strcmp(key, "spmm_stored_entries")) *value = o->sell_entries;
   else if (!strcmp(key, "spmm_stream_bytes")) *value = o->stream_bytes;

@@ -188,6 +188,10 @@ int pa_k_trace_finish(const double* rtr_partials, int nblk, int ts, int nc, doub
 int pa_k_update_z(int m, int ts, int a_lo, int a_hi, int nc, const double* beta, int ldb,
                   const double* V0, const double* V1, double* Z, const double* note_src, double* note_host,
                   const double* ucur, const double* uprev, double* zz_part, int zz_cols, int* zz_nblk);
+/* One-shot request to the next pa_k_update_z (panels of up to 4 columns): also copy the new row r of Z into the slots
+ * pk_slot[pk_off[r] .. pk_off[r + 1]) of sendbuf (ts doubles each) -- the halo pack of the product that follows.
+ * 0: not taken (wider panels; the caller must not tell the operator the rows are packed). */
+int pa_k_update_z_pack(int ts, const int* pk_off, const int* pk_slot, double* sendbuf);
 /* ucur != NULL (lazy normalisation): V0 / Z belong to the factor ucur, V1 to uprev, beta holds the raw Gram
  * blocks [V0-side ; V1-side]^T Z; the kernel applies U^-1 where the reference's panels would carry it. */
 /* note_host != NULL: note_src[0..1] (device) are also written to note_host[0..1] (pinned, device-visible) */

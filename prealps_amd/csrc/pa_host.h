@@ -75,6 +75,9 @@ const pa_operator_info_t* pa_operator_info(void);
 /* Workgroups of the SpMM at panel stride ts when it can leave the ECG Gram block behind
  * (pa_k_spmm_gram_arm: run plan, 4 columns); builds the plan if need be.  0: it cannot. */
 int pa_operator_gram_blocks(int ts);
+/* 1: the caller's kernel packs the send rows of the panel X it is about to write (row r into the slots
+ * pk_slot[pk_off[r] .. pk_off[r + 1]) of sendbuf, ts doubles each); the next preAlps_BlockOperator(X, .) skips its pack */
+int pa_operator_pack_hint(int ts, const double* X, const int** pk_off, const int** pk_slot, double** sendbuf);
 
 int pa_panel_stride(int enlFac);
 static inline int pa_desc_stride(const CPLM_Mat_Dense_t* A) { return A->info.lda; }

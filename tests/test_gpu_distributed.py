@@ -39,6 +39,10 @@ def _worker(rank, world, port, alg, q):
             os.environ["PREALPS_BJ_ND_ROWS"] = "512"
             os.environ["PREALPS_ND_LEAF"] = "32"
             alg = "odir"
+        nopack = alg == "odir_nopack"
+        if nopack:                                   # k_pack_rows packs the send rows, not the solver's update kernel
+            os.environ["PREALPS_PACK_FUSE"] = "0"
+            alg = "odir"
         if alg == "odir_eager":                      # the residual norm reduced by itself, before the decision
             os.environ["PREALPS_ECG_LAZY_STOP"] = "0"
             alg = "odir"
@@ -65,6 +69,12 @@ def _worker(rank, world, port, alg, q):
         p0, p1 = rank * nparts // world, (rank + 1) * nparts // world
         lo, hi = int(rowpos[p0]), int(rowpos[p1])
         assert prob.stat("halo_rows") > 0
+        # Orthodir / Orthomin in the library's loop: the update kernel of the second half packs the rows the
+        # neighbours need (one product per iteration skips k_pack_rows); PREALPS_PACK_FUSE=0 keeps the launch
+        if alg in ("odir", "omin") and red[0] == pa.NO_BS_RED and not nopack:
+            assert prob.stat("packs_fused") >= got.iters - 2, (prob.stat("packs_fused"), got.iters)
+        if nopack:
+            assert prob.stat("packs_fused") == 0
         assert prob.stat("bj_nd_blocks") == (nparts // world if big else 0)
         assert got.iters == ref["iters"], (got.iters, ref["iters"])
         np.testing.assert_allclose(got.res, ref["res"], rtol=1e-8)
@@ -79,7 +89,7 @@ def _worker(rank, world, port, alg, q):
         q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize("alg,world", [("odir", 2), ("odir_eager", 2), ("omin", 2), ("fused", 2), ("dodir", 2),
+@pytest.mark.parametrize("alg,world", [("odir", 2), ("odir_eager", 2), ("odir_nopack", 2), ("omin", 2), ("fused", 2), ("dodir", 2),
                                        ("odir", 4), ("fused", 4), ("odir_nd", 2)])
 def test_two_ranks_one_gpu_match_oracle(alg, world):
     """(world = 4: every rank has more than one neighbour in the halo exchange)"""
