@@ -698,6 +698,9 @@ __global__ __launch_bounds__(256, OCC) void k_bj_g4(
       g4_pre<DQ> pb;
       g4_make_pre<DQ, false>((unsigned)(uintptr_t)(lds_ptr)lds0, w, lb, pb);
       g4_bwd_tiles_p<NT, DQ, NT - 1>(T, b, rec, chunk_doubles, lds0, lane, lb, pb, opA, opB);
+      // (the last steps' requests went to the spare buffer and nobody waits for them: no LDS-DMA in flight when the
+      // wavefront's LDS is given to the next workgroup)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if constexpr (GP) {
 #pragma unroll
         for (int q = 1; q < NT; ++q) {
@@ -792,8 +795,10 @@ int launch_occ(const int* list, int count, const pa_bj_plan_t* pl, int wmax, int
     // (G4F_RING buffers of DQ KiB and the spare one per wavefront)
     if (ring >= 4) {
       const int per_wave_f = (G4F_RING + 1) * DQ * 128;
-      int waves_f = (160 * 1024) / (per_wave_f * 8);
-      if (waves_f > 4) waves_f = 4;
+      // single-wavefront workgroups: they fill the 160 KiB of a CU to the last buffer set (six blocks per CU at
+      // DQ = 5; four-wavefront workgroups of 100 KiB leave room for one).  Measured 1 / 2 / 4 wavefronts per
+      // workgroup: 20.7 / 24.8 / 20.7 us on 709 blocks (1/8 of the headline problem), 28.5 / 28.3 / 28.9 us on 1418
+      const int waves_f = 1;
       const size_t lds_f = (size_t)waves_f * per_wave_f * 8;
       static size_t configured_p = 0;
       if (lds_f > 64 * 1024 && lds_f > configured_p) {
