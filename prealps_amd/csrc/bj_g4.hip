@@ -396,9 +396,10 @@ __device__ __forceinline__ void g4_bwd_tiles(double (&T)[NC * NT], int b, int w,
 // behind them: inside a chunk that is free; across chunks the wait for the next chunk moves half a chunk forward
 // (it was requested ring - 1 >= 3 chunks ago: with the deep ring of this configuration it has long arrived),
 // while the request for the chunk ring - 1 ahead stays where it was, at the chunk's entry, when both groups of
-// the buffer it overwrites have their operands in registers.  Only instantiated for NC = 1 and used for ring
-// depths >= 4; the memory-bound launch (ring 2, six wavefronts per SIMD) keeps the plain chain: there the early
-// wait would delay the next request.
+// the buffer it overwrites have their operands in registers.  Only instantiated for NC = 1 and launched when a GPU
+// holds fewer than two blocks per SIMD (or PREALPS_BJ_G4_RING = 4 / 8), with the compile-time ring of G4F_RING
+// buffers described above; the memory-bound launch (ring 2, six wavefronts per SIMD) keeps the plain chain:
+// there the early wait would delay the next request.
 template <int DQ> struct g4_ops { double a0, a1, a2; double cf[DQ]; };
 
 template <int DQ>
