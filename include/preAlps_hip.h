@@ -101,6 +101,10 @@ void preAlps_hip_plan_only(int on);
  * owns recv_rows[i] of our halo slots (their global rows in halo_cols). */
 int preAlps_OperatorGetHaloPlan(int* npeers, int** peers, int** send_rows, int** recv_rows,
                                 int** send_idx, int* nsend, int** halo_cols, int* nhalo);
+/* The inverse of send_idx, as the solver's update kernel uses it to pack the send buffer itself (several processes,
+ * DESIGN section 5): local row r goes into the send-buffer slots slot_out[off_out[r] .. off_out[r + 1]).
+ * off_out: m + 1 ints, slot_out: nsend ints (caller's arrays).  Works in plan-only mode. */
+int preAlps_hip_pack_map(int* off_out, int* slot_out);
 /* perm[new] = old, of the whole problem (library-owned, N ints). */
 int preAlps_OperatorGetPermPtr(int** perm, int* n);
 int preAlps_hip_nparts(void);

@@ -1230,6 +1230,25 @@ static int ensure_halo_buffers(pa_operator_t* o, int ts) {
  * Returns 1 and the inverse send list (row -> slots of the send buffer, rows of `ts` doubles) when this process has
  * neighbours; the operator then skips its own pack for exactly that panel pointer, once.  The caller promises that
  * nothing else writes X in between (the library's own loops, PREALPS_RCI_FUSE=1). */
+/* off (m + 2 ints, zero on entry; m + 1 used on return), slot (nsend ints): row r is packed into the send-buffer
+ * slots slot[off[r] .. off[r + 1]), ascending (a row goes to every neighbour that reads it) */
+static void inverse_send_list(int m, int nsend, const int* send_idx, int* off, int* slot) {
+  for (int i = 0; i < nsend; ++i) ++off[send_idx[i] + 2];
+  for (int r = 0; r < m; ++r) off[r + 2] += off[r + 1];       /* off[r + 1] = first slot entry of row r */
+  for (int i = 0; i < nsend; ++i) slot[off[send_idx[i] + 1]++] = i;   /* ... now off[r + 1] = end of row r */
+}
+/* The same list on the host, for tests without a GPU (plan-only mode): off_out[m + 1], slot_out[nsend]. */
+int preAlps_hip_pack_map(int* off_out, int* slot_out) {
+  pa_operator_t* o = &g_op;
+  if (!o->info.built) return PA_FAIL("operator not built");
+  int m = o->info.m;
+  int* off = (int*)calloc((size_t)m + 2, sizeof(int));
+  if (!off) return PA_FAIL("out of host memory");
+  inverse_send_list(m, o->nsend, o->send_idx, off, slot_out);
+  memcpy(off_out, off, ((size_t)m + 1) * sizeof(int));
+  free(off);
+  return 0;
+}
 static long long g_packs_fused = 0;       /* products whose send rows the solver's update kernel had packed */
 int pa_operator_pack_hint(int ts, const double* X, const int** pk_off, const int** pk_slot, double** sendbuf) {
   pa_operator_t* o = &g_op;
@@ -1244,9 +1263,7 @@ int pa_operator_pack_hint(int ts, const double* X, const int** pk_off, const int
     int* slot = (int*)malloc((size_t)o->nsend * sizeof(int));
     int ok = off && slot;
     if (ok) {
-      for (int i = 0; i < o->nsend; ++i) ++off[o->send_idx[i] + 2];
-      for (int r = 0; r < m; ++r) off[r + 2] += off[r + 1];       /* off[r + 1] = first slot entry of row r */
-      for (int i = 0; i < o->nsend; ++i) slot[off[o->send_idx[i] + 1]++] = i;   /* ... now off[r + 1] = end of row r */
+      inverse_send_list(m, o->nsend, o->send_idx, off, slot);
       o->d_pk_off = (int*)pa_rt_malloc(((size_t)m + 1) * sizeof(int));
       o->d_pk_slot = (int*)pa_rt_malloc((size_t)o->nsend * sizeof(int));
       ok = o->d_pk_off && o->d_pk_slot && !pa_rt_h2d(o->d_pk_off, off, ((size_t)m + 1) * sizeof(int)) &&

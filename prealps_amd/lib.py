@@ -70,7 +70,7 @@ EXPORTS = [
     "preAlps_hip_init", "preAlps_hip_shutdown", "preAlps_hip_set_stream", "preAlps_hip_get_stream",
     "preAlps_hip_sync", "preAlps_hip_set_abort_mode", "preAlps_hip_last_error", "preAlps_hip_panel_stride",
     "preAlps_hip_set_world", "preAlps_hip_set_comm", "preAlps_hip_rccl_unique_id", "preAlps_hip_rccl_init", "preAlps_hip_comm_selftest", "preAlps_OperatorBuildFromCSR",
-    "preAlps_OperatorGetPermPtr", "preAlps_hip_plan_only", "preAlps_hip_prepare_operator", "preAlps_OperatorGetHaloPlan", "preAlps_hip_nparts", "preAlps_hip_reference_rhs", "preAlps_ECGSolve", "preAlps_ECGAdvance", "preAlps_hip_hbm_probe",
+    "preAlps_OperatorGetPermPtr", "preAlps_hip_plan_only", "preAlps_hip_prepare_operator", "preAlps_OperatorGetHaloPlan", "preAlps_hip_pack_map", "preAlps_hip_nparts", "preAlps_hip_reference_rhs", "preAlps_ECGSolve", "preAlps_ECGAdvance", "preAlps_hip_hbm_probe",
     "preAlps_hip_panel_alloc", "preAlps_hip_panel_free", "preAlps_hip_panel_to_host",
     "preAlps_hip_panel_from_host", "preAlps_hip_get_stat", "preAlps_hip_timing",
     "preAlps_hip_timer_start", "preAlps_hip_timer_stop",

@@ -75,6 +75,15 @@ def _worker(rank, world, port, nparts, n, box, q, mode="box"):
         rrows = [rrows[i] for i in range(npeers)]
         sidx = np.array([sidx[i] for i in range(nsend)], dtype=np.int64)
         hcols = np.array([hcols[i] for i in range(nhalo)], dtype=np.int64)
+        # the inverse send list the update kernel packs with (row -> slots of the send buffer): every slot once,
+        # under the row it carries, ascending
+        off, slots = np.zeros(m + 1, dtype=np.int32), np.zeros(max(nsend, 1), dtype=np.int32)
+        check(L.preAlps_hip_pack_map(off.ctypes.data_as(pi), slots.ctypes.data_as(pi)), "pack_map")
+        assert off[0] == 0 and off[m] == nsend and np.all(np.diff(off) >= 0)
+        assert sorted(slots[:nsend].tolist()) == list(range(nsend))
+        for r in np.unique(sidx):
+            mine = slots[off[r]:off[r + 1]]
+            assert np.all(sidx[mine] == r) and np.all(np.diff(mine) > 0) and len(mine) == int(np.sum(sidx == r))
         # the global reference, identical on every rank
         import scipy.sparse as sp
         Ag = sp.csr_matrix((v, ci, rp), shape=(n ** 3, n ** 3))
