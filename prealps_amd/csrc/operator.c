@@ -1466,10 +1466,14 @@ static int build_plan_runs(pa_operator_t* o, int ts) {
    * panel (spmm.hip; staging area and pay-off test of stride 8).  One workgroup staging all 16 columns was
    * measured slower: 628 against 371 us, the LDS reads of 128 B per nonzero and lane dominate. */
   if (ts >= 16) ts /= 2;
-  int cap_rows = (ts <= 4 ? 32768 : 49152) / (ts * 8) - 2;
+  /* 8 columns: the rows of the staging area are 80 bytes apart (spmm.hip: spmm_row, no LDS bank conflicts) and a
+   * workgroup may stage 80 KiB, two workgroups per CU.  Block rows / staging budget measured with the padded rows
+   * (70^3, iterations/s at 8 | 16 columns): 192 / 60 KiB 1834 | 1038, 256 / 64 KiB 1776 | 977, **256 / 80 KiB
+   * 1849 | 1094**, 320 / 80 KiB 1763 | 998, 320 / 100 KiB 1679 | 912 (before the padding: 192 rows / 48 KiB,
+   * three workgroups per CU, 1832 | 1025). */
+  int cap_rows = (ts <= 4 ? 32768 : 81920) / (ts == 8 ? 80 : ts * 8) - 2;
   if (cap_rows > 65533) cap_rows = 65533;
-  /* 8-column panels: 192 rows and 48 KiB of staging (three workgroups per CU) measured 7 % faster */
-  int blk_rows = spmm_block_rows(m, ts <= 4 ? 256 : 192);
+  int blk_rows = spmm_block_rows(m, 256);
   if (blk_rows < 64) blk_rows = 64;
   blk_rows &= ~63;
   if (blk_rows > cap_rows) blk_rows = cap_rows & ~63;

@@ -203,14 +203,24 @@ __device__ __forceinline__ void spmm_runs_load(const unsigned short* __restrict_
     for (int i = 0; i < RL; ++i) vv[RL * j + i] = vk[64 * i + lane];
   }
 }
+// Row stride of the staging area in doubles.  8 columns: 64-byte rows lie on only four different bank quads of
+// the 64-bank LDS, so the 16 lanes of a ds_read_b128 group, which gather up to 16 different rows, conflict up to
+// four ways: SQ_LDS_BANK_CONFLICT counted 53.4 M of the kernel's 77.6 M LDS cycles (126 us of LDS time per CU in
+// a 180 us kernel; the two 8-column halves of a 16-column product: 252 of 372 us), while the HBM counters showed
+// 3.0-4.5 TB/s -- at 8 and 16 columns the product was bound by the LDS, not by memory.  Rows 80 bytes apart
+// (r * 20 mod 64 visits all sixteen quads) read without conflicts.  4 columns keep 32-byte rows: the padded
+// area would cost the fifth workgroup per CU, and there the kernel is bound by HBM.
+template <int TS> struct spmm_row { static constexpr int stride = TS == 8 ? TS + 2 : TS; };
+
 template <int TS, int RL>
 __device__ __forceinline__ void spmm_runs_fma(const double* sx, const int (&sl)[spmm_ru<RL>::n],
                                               const double (&vv)[RL * spmm_ru<RL>::n], double (&acc)[TS]) {
+  constexpr int TSP = spmm_row<TS>::stride;
 #pragma unroll
   for (int j = 0; j < spmm_ru<RL>::n; ++j) {
-    const double* __restrict__ xr = sx + (size_t)sl[j] * TS;
+    const double* __restrict__ xr = sx + (size_t)sl[j] * TSP;
 #pragma unroll
-    for (int i = 0; i < RL; ++i) spmm_fma_row<TS>(acc, vv[RL * j + i], xr + i * TS);
+    for (int i = 0; i < RL; ++i) spmm_fma_row<TS>(acc, vv[RL * j + i], xr + i * TSP);
   }
 }
 
@@ -289,7 +299,7 @@ __device__ __forceinline__ void spmm_runs_block(
   // id(L); H lanes per row, WG / H rows per pass, SB passes in flight at a time: all ids, then all rows,
   // then the LDS stores -- two memory latencies per batch instead of two per pass.
   {
-    constexpr int RPP = WG / H, SB = 8;
+    constexpr int RPP = WG / H, SB = 8, HP = spmm_row<TS>::stride / 2;      // HP: double2 per LDS row (padded)
     double2* dst = reinterpret_cast<double2*>(sx);
     const int j = tid % H, l0 = tid / H, nst = nown + next;
     // (no conditional anywhere: lanes beyond the last row repeat it -- same bytes to the same place --
@@ -311,9 +321,9 @@ __device__ __forceinline__ void spmm_runs_block(
         v[it] = reinterpret_cast<const double2*>(src)[j];
       }
 #pragma unroll
-      for (int it = 0; it < SB; ++it) dst[(size_t)L[it] * H + j] = v[it];
+      for (int it = 0; it < SB; ++it) dst[(size_t)L[it] * HP + j] = v[it];
     }
-    if constexpr (RL == 3) { if (tid < 2 * H) dst[(size_t)nst * H + tid] = make_double2(0.0, 0.0); }    // (a run may reach two rows past the last one)
+    if constexpr (RL == 3) { if (tid < 2 * H) dst[(size_t)(nst + tid / H) * HP + tid % H] = make_double2(0.0, 0.0); }    // (a run may reach two rows past the last one)
   }
   __syncthreads();
   double gw = 0.0, gg = 0.0;      // GRAM: D[i][j] of the lane's 4 x 4 block (lane = 16 i + 4 q + j)
@@ -350,7 +360,7 @@ __device__ __forceinline__ void spmm_runs_block(
       for (int i = 0; i < TS / 2; ++i) q[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
     }
     if constexpr (GRAM) {
-      const double* own = sx + (size_t)(nlow + row_s - r0) * 4;
+      const double* own = sx + (size_t)(nlow + row_s - r0) * 4;      // (GRAM: 4 columns, rows not padded)
       spmm_gram_slice(acc, nr, row_s, lane, rin, [&](int rr) { return own + (size_t)rr * 4; }, gw, gg);
     }
     if (s + WG / 64 < s1) {       // (a block of more than four slices: the wavefront's next one)
@@ -459,7 +469,7 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
     // the caches: 410-414 us against 372-375 us for the two workgroups, same process, profiles/r04_t16_spmm_seq_ab.txt.)
     constexpr int TC = TS >= 16 ? TS / 2 : TS;
     const int ns = TS / TC;
-    const size_t lds = (size_t)pl->stage_cap * TC * 8;
+    const size_t lds = (size_t)pl->stage_cap * spmm_row<TC>::stride * 8;
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TC, TS>),
@@ -475,7 +485,7 @@ static int launch_spmm(const pa_spmm_plan_t* pl, const int* order, int nlist, co
   }
   if (pl->staged) {
     // one staged row per slot: the same kernel with run length 1 (batched staging, double-buffered groups)
-    const size_t lds = (size_t)pl->stage_cap * TS * 8;
+    const size_t lds = (size_t)pl->stage_cap * spmm_row<TS>::stride * 8;
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_runs<TS, TS, 1>),
