@@ -1017,7 +1017,12 @@ __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, double
     double p[TS], ap[TS], x[TS], r[TS];
     load_row<TS>(P, row, p);
     load_row<TS>(AP, row, ap);
-    load_row<TS>(X, row, x);
+    // X is the one panel nobody reads again before the caches have turned over (its next reader is this kernel, an
+    // iteration later): read and written with the nontemporal hint its 2 x 33 MB do not push R -- which the block
+    // solve reads next -- out of the caches, nor wait there as dirty lines: the block solve behind this kernel
+    // 125.5 -> 121.0 us, this kernel +0.5 us (six alternations in one box, profiles/r04_nontemporal_x_ab.txt).  The
+    // hint on the store alone does nothing; on the loads of P / AP, or of P / P_prev in k_update_z, it costs 2-5 us.
+    load_row_nt<TS>(X, row, x);
     load_row<TS>(R, row, r);
 #pragma unroll
     for (int j = 0; j < TS; ++j) {
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, double
       store_row<TS>(P, row, p);
       store_row<TS>(AP, row, ap);
     }
-    store_row<TS>(X, row, x);
+    store_row_nt<TS>(X, row, x);
     store_row<TS>(R, row, r);
   }
   block_sum_cols<TS>(rr, rtr + (size_t)blockIdx.x * TS);
@@ -1070,7 +1075,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
                                                          double* __restrict__ P, double* __restrict__ AP,
                                                          double* __restrict__ X, double* __restrict__ R,
                                                          double* __restrict__ rtr, const double* gram, int* info,
-                                                         double* __restrict__ ukeep) {
+                                                         double* __restrict__ ukeep, int xnt) {
   static_assert(TS == 8 || TS == 16, "matrix-core variant: panels of 8 or 16 columns");
   __shared__ double su[16 * 16];    // U (column major, leading dimension 16, identity beyond t)
   __shared__ double si[16 * 16];    // Ui = U^-1
@@ -1149,7 +1154,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
       for (int q = 0; q < 4; ++q) {
         const size_t row = r0 + hi + 4 * q;
         const bool ok = row < (size_t)m;
-        x[q] = ok ? X[row * 16 + lo] : 0.0;
+        x[q] = ok ? (xnt ? __builtin_nontemporal_load(X + row * 16 + lo) : X[row * 16 + lo]) : 0.0;
         r[q] = ok ? R[row * 16 + lo] : 0.0;
       }
 #pragma unroll
@@ -1166,7 +1171,8 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
         const size_t row = r0 + hi + 4 * q;
         if (row < (size_t)m) {
           if (!ukeep) { P[row * 16 + lo] = pn[q]; AP[row * 16 + lo] = apn[q]; }
-          X[row * 16 + lo] = x[q]; R[row * 16 + lo] = r[q];
+          if (xnt) __builtin_nontemporal_store(x[q], X + row * 16 + lo); else X[row * 16 + lo] = x[q];
+          R[row * 16 + lo] = r[q];
           if (lo < nc) rr = fma(r[q], r[q], rr);
         }
       }
@@ -1184,7 +1190,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const size_t row = r0 + hi + 4 * q;
-        xr[q] = row < (size_t)m ? XR[row * 8 + cc] : 0.0;
+        xr[q] = row < (size_t)m ? ((xnt && lo < 8) ? __builtin_nontemporal_load(X + row * 8 + cc) : XR[row * 8 + cc]) : 0.0;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
@@ -1196,7 +1202,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
         const size_t row = r0 + hi + 4 * q;
         if (row < (size_t)m) {
           if (!ukeep) PA[row * 8 + cc] = pn[q];
-          XR[row * 8 + cc] = xr[q];
+          if (xnt && lo < 8) __builtin_nontemporal_store(xr[q], X + row * 8 + cc); else XR[row * 8 + cc] = xr[q];
           if (lo >= 8 && cc < nc) rr = fma(xr[q], xr[q], rr);
         }
       }
@@ -3189,10 +3195,12 @@ int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, dou
   // PREALPS_TRSM_MFMA=0: lane-per-row substitution at every width (the matrix-core variant forms U^-1)
   static int use_mfma = -1;
   if (use_mfma < 0) { const char* e = getenv("PREALPS_TRSM_MFMA"); use_mfma = e ? atoi(e) : 1; }
+  static int xnt = -1;
+  if (xnt < 0) { const char* e = getenv("PREALPS_X_NT"); xnt = e ? atoi(e) : 0; }
   if (ts == 16 && use_mfma)
-    PA_LAUNCH((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep);
+    PA_LAUNCH((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep, xnt);
   else if (ts == 8 && use_mfma)
-    PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep);
+    PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep, xnt);
   else {
     TS_DISPATCH(ts, PA_LAUNCH((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
                                        t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep));

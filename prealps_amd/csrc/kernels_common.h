@@ -48,6 +48,30 @@ __device__ __forceinline__ void load_row(const double* __restrict__ p, size_t ro
     r[2 * i + 1] = v.y;
   }
 }
+// The same with the nontemporal hint: a row that nobody reads again before the caches have turned over (see
+// k_trsm_update) does not take a line away from the panels that are read again right away.
+template <int TS>
+__device__ __forceinline__ void load_row_nt(const double* __restrict__ p, size_t row, double (&r)[TS]) {
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  if constexpr (TS >= 2) {
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) {
+      const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p + row * TS) + i);
+      r[2 * i] = v.x; r[2 * i + 1] = v.y;
+    }
+  } else r[0] = __builtin_nontemporal_load(p + row);
+}
+template <int TS>
+__device__ __forceinline__ void store_row_nt(double* __restrict__ p, size_t row, const double (&r)[TS]) {
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  if constexpr (TS >= 2) {
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) {
+      d2v v; v.x = r[2 * i]; v.y = r[2 * i + 1];
+      __builtin_nontemporal_store(v, reinterpret_cast<d2v*>(p + row * TS) + i);
+    }
+  } else __builtin_nontemporal_store(r[0], p + row);
+}
 template <int TS>
 __device__ __forceinline__ void store_row(double* __restrict__ p, size_t row, const double (&r)[TS]) {
   double2* q = reinterpret_cast<double2*>(p + row * TS);
