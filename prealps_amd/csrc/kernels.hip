@@ -992,7 +992,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, double
                                                     double* __restrict__ P, double* __restrict__ AP,
                                                     double* __restrict__ X, double* __restrict__ R,
                                                     double* __restrict__ rtr, const double* gram, int* info,
-                                                    double* __restrict__ ukeep) {
+                                                    double* __restrict__ ukeep, int xnt) {
   __shared__ double su[TS * TS];
   __shared__ double sd[TS];
   __shared__ double sa[TS * TS];
@@ -1021,8 +1021,11 @@ __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, double
     // iteration later): read and written with the nontemporal hint its 2 x 33 MB do not push R -- which the block
     // solve reads next -- out of the caches, nor wait there as dirty lines: the block solve behind this kernel
     // 125.5 -> 121.0 us, this kernel +0.5 us (six alternations in one box, profiles/r04_nontemporal_x_ab.txt).  The
-    // hint on the store alone does nothing; on the loads of P / AP, or of P / P_prev in k_update_z, it costs 2-5 us.
-    load_row_nt<TS>(X, row, x);
+    // hint on the store alone or on the load alone does nothing; on the loads of P / AP, or of P / P_prev in
+    // k_update_z, it costs 2-5 us; on the X accesses of k_trsm_update_mfma<8 / 16> it changes nothing.
+    // xnt = 0 (the launcher: a panel below 16 MiB, e.g. one GPU's share of a small problem): X stays in the
+    // caches from one iteration to the next and the hint would send it to memory
+    if (xnt) load_row_nt<TS>(X, row, x); else load_row<TS>(X, row, x);
     load_row<TS>(R, row, r);
 #pragma unroll
     for (int j = 0; j < TS; ++j) {
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update(int m, int t, int nc, double
       store_row<TS>(P, row, p);
       store_row<TS>(AP, row, ap);
     }
-    store_row_nt<TS>(X, row, x);
+    if (xnt) store_row_nt<TS>(X, row, x); else store_row<TS>(X, row, x);
     store_row<TS>(R, row, r);
   }
   block_sum_cols<TS>(rr, rtr + (size_t)blockIdx.x * TS);
@@ -1075,7 +1078,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
                                                          double* __restrict__ P, double* __restrict__ AP,
                                                          double* __restrict__ X, double* __restrict__ R,
                                                          double* __restrict__ rtr, const double* gram, int* info,
-                                                         double* __restrict__ ukeep, int xnt) {
+                                                         double* __restrict__ ukeep) {
   static_assert(TS == 8 || TS == 16, "matrix-core variant: panels of 8 or 16 columns");
   __shared__ double su[16 * 16];    // U (column major, leading dimension 16, identity beyond t)
   __shared__ double si[16 * 16];    // Ui = U^-1
@@ -1154,7 +1157,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
       for (int q = 0; q < 4; ++q) {
         const size_t row = r0 + hi + 4 * q;
         const bool ok = row < (size_t)m;
-        x[q] = ok ? (xnt ? __builtin_nontemporal_load(X + row * 16 + lo) : X[row * 16 + lo]) : 0.0;
+        x[q] = ok ? X[row * 16 + lo] : 0.0;
         r[q] = ok ? R[row * 16 + lo] : 0.0;
       }
 #pragma unroll
@@ -1171,8 +1174,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
         const size_t row = r0 + hi + 4 * q;
         if (row < (size_t)m) {
           if (!ukeep) { P[row * 16 + lo] = pn[q]; AP[row * 16 + lo] = apn[q]; }
-          if (xnt) __builtin_nontemporal_store(x[q], X + row * 16 + lo); else X[row * 16 + lo] = x[q];
-          R[row * 16 + lo] = r[q];
+          X[row * 16 + lo] = x[q]; R[row * 16 + lo] = r[q];
           if (lo < nc) rr = fma(r[q], r[q], rr);
         }
       }
@@ -1190,7 +1192,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const size_t row = r0 + hi + 4 * q;
-        xr[q] = row < (size_t)m ? ((xnt && lo < 8) ? __builtin_nontemporal_load(X + row * 8 + cc) : XR[row * 8 + cc]) : 0.0;
+        xr[q] = row < (size_t)m ? XR[row * 8 + cc] : 0.0;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
@@ -1202,7 +1204,7 @@ __global__ __launch_bounds__(WG) void k_trsm_update_mfma(int m, int t, int nc, d
         const size_t row = r0 + hi + 4 * q;
         if (row < (size_t)m) {
           if (!ukeep) PA[row * 8 + cc] = pn[q];
-          if (xnt && lo < 8) __builtin_nontemporal_store(xr[q], X + row * 8 + cc); else XR[row * 8 + cc] = xr[q];
+          XR[row * 8 + cc] = xr[q];
           if (lo >= 8 && cc < nc) rr = fma(xr[q], xr[q], rr);
         }
       }
@@ -3195,15 +3197,14 @@ int pa_k_trsm_update(int m, int ts, int t, int nc, double* U, double* alpha, dou
   // PREALPS_TRSM_MFMA=0: lane-per-row substitution at every width (the matrix-core variant forms U^-1)
   static int use_mfma = -1;
   if (use_mfma < 0) { const char* e = getenv("PREALPS_TRSM_MFMA"); use_mfma = e ? atoi(e) : 1; }
-  static int xnt = -1;
-  if (xnt < 0) { const char* e = getenv("PREALPS_X_NT"); xnt = e ? atoi(e) : 0; }
   if (ts == 16 && use_mfma)
-    PA_LAUNCH((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep, xnt);
+    PA_LAUNCH((k_trsm_update_mfma<16>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep);
   else if (ts == 8 && use_mfma)
-    PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep, xnt);
+    PA_LAUNCH((k_trsm_update_mfma<8>), dim3(blocks), dim3(WG), 0, cur_stream(), m, t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep);
   else {
     TS_DISPATCH(ts, PA_LAUNCH((k_trsm_update<TS_>), dim3(blocks), dim3(WG), 0, cur_stream(), m,
-                                       t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep));
+                                       t, nc, U, alpha, P, AP, X, R, rtr_partials, gram, info, ukeep,
+                                       (size_t)m * ts * sizeof(double) >= ((size_t)16 << 20) ? 1 : 0));
   }
   if (kfail("k_trsm_update")) return 1;
   if (trace_nc <= 0) return 0;
