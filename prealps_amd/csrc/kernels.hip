@@ -759,15 +759,18 @@ __global__ __launch_bounds__(WG) void k_finish32(const double* __restrict__ part
   const int b0 = blockIdx.x * per, b1 = min(nblk, b0 + per);
   const d4* __restrict__ q = reinterpret_cast<const d4*>(partials) + e4;
   d4 sum = {0.0, 0.0, 0.0, 0.0};
-  int b = b0 + sl;
-  for (; b + 3 * 32 < b1; b += 4 * 32) {
+  // four blocks per thread in flight, the last round too (blocks beyond the share: the thread's first block
+  // again, added as zero) -- with 4174 / 5670 partial blocks a share is 66 / 89 blocks, i.e. two or three per
+  // thread: the remainder loop this replaces took them one memory round trip after the other
+  for (int b = b0 + sl; b < b1; b += 4 * 32) {
     d4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = q[(size_t)(b + u * 32) * 8];
+    for (int u = 0; u < 4; ++u) v[u] = q[(size_t)(b + u * 32 < b1 ? b + u * 32 : b) * 8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) sum += v[u];
+    for (int u = 0; u < 4; ++u) {
+      if (b + u * 32 < b1) sum += v[u];
+    }
   }
-  for (; b < b1; b += 32) sum += q[(size_t)b * 8];
 #pragma unroll
   for (int u = 0; u < 4; ++u) red[sl * 32 + e4 * 4 + u] = sum[u];
   __syncthreads();
