@@ -1276,6 +1276,14 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
   }
   const int na = a_lo + a_hi;
   for (int e = threadIdx.x; e < na * nc; e += WG) sb[e] = beta[(e % na) + ldb * (e / na)];
+  // (lazy normalisation: the two factors come in with the same round trip as beta -- read from memory inside
+  // the back substitution below, behind run-time conditions, they cost several trips in a row at the head of
+  // every workgroup)
+  __shared__ double sfac[2 * TS * TS];
+  if (ucur) {
+    const int tt0 = a_lo * a_lo;
+    for (int e = threadIdx.x; e < 2 * tt0; e += WG) sfac[e] = e < tt0 ? ucur[e] : (uprev ? uprev[e - tt0] : 0.0);
+  }
   __syncthreads();
   const size_t stride = (size_t)gridDim.x * WG;
   if (ucur) {
@@ -1290,7 +1298,7 @@ __global__ __launch_bounds__(WG) void k_update_z(int m, int a_lo, int a_hi, int 
     double* C0 = sc + 4 * TS * TS; double* C1 = sc + 5 * TS * TS; double* C2 = sc + 6 * TS * TS;
     if (tid < 64) {
       if (tid < 2 * t) {          // column c of the inverse of an upper-triangular factor: back substitution on e_c
-        const double* __restrict__ Uf = tid < t ? ucur : uprev;
+        const double* Uf = tid < t ? sfac : sfac + tt;
         double* inv = tid < t ? Ui : Up;
         const int c = tid < t ? tid : tid - t;
         double x[TS];
