@@ -1401,6 +1401,10 @@ __device__ __forceinline__ void lazy_coeffs16(const double* __restrict__ beta, i
     const int i = e & 15, j = e >> 4;
     T1[e] = (i < t && j < t) ? ucur[i + t * j] : (i == j ? 1.0 : 0.0);
     T2[e] = (i < t && j < t) ? uprev[i + t * j] : (i == j ? 1.0 : 0.0);
+    // the raw Gram blocks with the same round trip (C1 / C2 serve as staging until they are written at the end):
+    // read from memory inside the loop over k below they cost t trips in a row at the head of every workgroup
+    C1[e] = (i < t && j < t) ? beta[i + ldb * j] : 0.0;
+    C2[e] = (a_hi > 0 && i < t && j < t) ? beta[t + i + ldb * j] : 0.0;
   }
   __syncthreads();
   if (tid < 32) {                             // column c of an inverse by back substitution on e_c
@@ -1424,8 +1428,8 @@ __device__ __forceinline__ void lazy_coeffs16(const double* __restrict__ beta, i
   {
     double s1 = 0.0, s2 = 0.0;                // T = G Ui
     if (on) for (int k = 0; k < t; ++k) {
-      s1 = fma(beta[r + ldb * k], Ui[k + 16 * c], s1);
-      if (a_hi > 0) s2 = fma(beta[t + r + ldb * k], Ui[k + 16 * c], s2);
+      s1 = fma(C1[r + 16 * k], Ui[k + 16 * c], s1);
+      if (a_hi > 0) s2 = fma(C2[r + 16 * k], Ui[k + 16 * c], s2);
     }
     __syncthreads();
     T1[tid] = s1; T2[tid] = s2;
